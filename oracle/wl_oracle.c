@@ -1,0 +1,337 @@
+/*
+ * oracle/wl_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU oracle for the hot path of JuliaDSP/Wavelets.jl v0.10.1 (periodic
+ * orthogonal filter-bank DWT/IDWT and lifting DWT/IDWT, 1-D/2-D/3-D, plus the
+ * 1-D wavelet-packet walk): a literal plain-C restatement of the reference's
+ * Julia loops (src/Transforms/transforms_filter.jl, transforms_lifting.jl,
+ * src/Util/util_main.jl, src/Util/non_dyadic.jl, src/WT/wt_main.jl).  Each
+ * function in wl_oracle_impl.h cites the file:line it follows.
+ *
+ * The reference is Julia and cannot be executed in this image (no julia, no
+ * network), so there is no oracle/_ref build.  The oracle is pinned instead
+ * against the reference's own golden vectors (test/data/filter{1d,2d}_*.txt,
+ * 27 filters x {64-vector, 8x8 matrix} + the 4x8 Haar case), committed as data
+ * fixtures under tests/golden/, with the reference's own tolerance
+ * 1e-9*sqrt(len) (test/transforms.jl:15-16,36-37) -- see
+ * tests/test_oracle_golden.py.  cdf9/7 lifting VALUES are not pinned by any
+ * golden vector in the reference (only round trip and lifting==filter for
+ * db1/db2, test/transforms.jl:57-128): "parity unpinned" for cdf9/7 values
+ * beyond the known-answer effective-filter test in tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libwavelets_mi355x.so) never links it.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WLO_MAXF 128        /* longest filter supported (batt6 = 59 taps)    */
+#define WLO_MAXC 8          /* max coefficients per lifting step             */
+#define WLO_MAXSTEPS 16
+
+enum {
+    WLO_OK = 0,
+    WLO_EINVAL_SIZE = -1,   /* ArgumentError: size must have a sufficient power of 2 factor */
+    WLO_EINVAL_L = -2,      /* ArgumentError: L must be positive              */
+    WLO_EALIAS = -3,        /* ArgumentError: in array is out array           */
+    WLO_EINVAL_DIMS = -4,
+    WLO_EINVAL_CUBE = -5,   /* ArgumentError: array must be square/cube       */
+    WLO_EINVAL_TREE = -6,   /* ArgumentError: invalid tree                    */
+    WLO_EINVAL_SCHEME = -7,
+    WLO_EINVAL_DTYPE = -8,
+    WLO_EINVAL_FILTER = -9
+};
+
+typedef struct { long lo, hi; } wlo_range;   /* Julia lo:hi, empty when hi<lo */
+
+typedef struct {
+    int nsteps;
+    const int32_t *is_update;   /* 0 = WT.Predict, 1 = WT.Update            */
+    const int32_t *ncoef;
+    const int32_t *shift;
+    const double *coefs;        /* flattened, table order                   */
+    double norm1, norm2;
+} wlo_scheme;
+
+/* Julia mod (floored), mod1, rem (truncated), x>>1 on signed                */
+static long wlo_mod(long a, long n) { long r = a % n; return (r != 0 && ((r < 0) != (n < 0))) ? r + n : r; }
+static long wlo_mod1(long a, long n) { return wlo_mod(a - 1, n) + 1; }
+static long wlo_rem(long a, long n) { return a % n; }
+static long wlo_fld2(long a) { return (a >= 0) ? (a >> 1) : -((-a + 1) >> 1); }
+
+/* Util/non_dyadic.jl:5,11 -- exact for sizes with a 2^l factor              */
+static long wlo_detailindex(long n, long l, long i) { return (n >> l) + i; }
+static long wlo_detailn(long n, long l) { return n >> l; }
+/* Util/util_main.jl:21-27                                                   */
+static int wlo_sufficientpoweroftwo(long n, int L) { return (L < 62) && (n % (1L << L) == 0); }
+/* Util/non_dyadic.jl:14-23                                                  */
+static int wlo_maxtransformlevels(long n)
+{
+    if (n <= 1) return 0;
+    int tl = 0;
+    while (wlo_sufficientpoweroftwo(n, tl)) tl += 1;
+    return tl - 1;
+}
+/* Util/util_main.jl:301-314 isvalidtree                                     */
+static int wlo_isvalidtree(long n, const unsigned char *b, long nb)
+{
+    int ns = wlo_maxtransformlevels(n);
+    if (nb != (1L << ns) - 1) return 0;
+    if (ns == 0) return 1;
+    for (long i = 1; i <= (1L << (ns - 1)) - 1; ++i)
+        if (!b[i - 1] && (b[(i << 1) - 1] || b[(i << 1)]))
+            return 0;
+    return 1;
+}
+static int wlo_scheme_ok(const wlo_scheme *sc)
+{
+    if (sc->nsteps < 0 || sc->nsteps > WLO_MAXSTEPS) return 0;
+    for (int i = 0; i < sc->nsteps; ++i)
+        if (sc->ncoef[i] < 1 || sc->ncoef[i] > 3) return 0;   /* see lift_inbounds note */
+    return 1;
+}
+
+/* Transforms/transforms_filter.jl:436-456 splitdownrangeper                 */
+static void wlo_splitdownrangeper(long istart, long ix, long nx, long shift,
+                                  wlo_range *r1, wlo_range *rin, wlo_range *r2)
+{
+    long ixsh = -1 + shift + ix;
+    if (wlo_mod(shift, nx) + ix == 1 + ixsh) {
+        long inxi = 1, iend = nx - 1;
+        while (wlo_mod(iend - 1 + shift, nx) + ix != iend + ixsh) iend -= 1;
+        r1->lo = 0; r1->hi = -1;
+        rin->lo = inxi; rin->hi = iend;
+        r2->lo = iend + 1; r2->hi = nx - 1 + istart;
+    } else if (wlo_mod(istart - 1 + shift, nx) + ix == istart + ixsh) {
+        long inxi = istart, iend = nx - 1 + istart;
+        while (wlo_mod(iend - 1 + shift, nx) + ix != iend + ixsh) iend -= 1;
+        r1->lo = 1; r1->hi = inxi - 1;
+        rin->lo = inxi; rin->hi = iend;
+        r2->lo = iend + 1; r2->hi = nx - 1 + istart;
+    } else {
+        r1->lo = 0; r1->hi = -1;
+        rin->lo = 0; rin->hi = -1;
+        r2->lo = 1; r2->hi = nx - 1 + istart;
+    }
+}
+/* Transforms/transforms_filter.jl:544-564 splituprangeper                   */
+static void wlo_splituprangeper(long istart, long ix, long nx, long nout, long shift,
+                                wlo_range *r1, wlo_range *rin, wlo_range *r2)
+{
+    long sh = wlo_fld2(shift);
+    long ixsh = sh + ix;
+    if (wlo_mod(sh, nx) + ix == ixsh) {
+        long inxi = 1, iend = nout - 1;
+        while (wlo_mod(((iend - 1) >> 1) + sh, nx) + ix != ((iend - 1) >> 1) + ixsh) iend -= 1;
+        r1->lo = 0; r1->hi = -1;
+        rin->lo = inxi; rin->hi = iend;
+        r2->lo = iend + 1; r2->hi = nout - 1 + istart;
+    } else if (wlo_mod(((istart - 1) >> 1) + sh, nx) + ix == ((istart - 1) >> 1) + ixsh) {
+        long inxi = istart, iend = nout - 1 + istart;
+        while (wlo_mod(((iend - 1) >> 1) + sh, nx) + ix != ((iend - 1) >> 1) + ixsh) iend -= 1;
+        r1->lo = 1; r1->hi = inxi - 1;
+        rin->lo = inxi; rin->hi = iend;
+        r2->lo = iend + 1; r2->hi = nout - 1 + istart;
+    } else {
+        r1->lo = 0; r1->hi = -1;
+        rin->lo = 0; rin->hi = -1;
+        r2->lo = 1; r2->hi = nout - 1 + istart;
+    }
+}
+
+/* Transforms/transforms_lifting.jl:383-434 irlimits + getliftranges         */
+static void wlo_getliftranges(long half, int nc, long shift, int is_update,
+                              wlo_range *lhsr, wlo_range *irange, wlo_range *rhsr, long *rhsis)
+{
+    long a = shift + 1, b = 1 - nc + shift;
+    long irmin = a > b ? a : b;
+    long c = half + 1 + shift - nc, d = half + shift;
+    long irmax = c < d ? c : d;
+    long off = is_update ? half : 0;
+    *rhsis = is_update ? (-shift - half) : (-shift + half);
+    int empty;
+    if (irmin > half || irmax < 1) {
+        irange->lo = 1; irange->hi = 0;
+        empty = 1;
+    } else {
+        if (irmin < 1) irmin = 1;
+        if (irmax > half) irmax = half;
+        irange->lo = irmin + off; irange->hi = irmax + off;
+        empty = (irange->hi < irange->lo);
+    }
+    if (empty) {
+        lhsr->lo = 1 + off; lhsr->hi = half + off;
+        rhsr->lo = 1 + off; rhsr->hi = 0 + off;
+    } else {
+        lhsr->lo = 1 + off; lhsr->hi = irmin - 1 + off;
+        rhsr->lo = irmax + 1 + off; rhsr->hi = half + off;
+    }
+}
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+#define T float
+#define FN(name) CAT(name, _f32)
+#include "wl_oracle_impl.h"
+#undef T
+#undef FN
+
+#define T double
+#define FN(name) CAT(name, _f64)
+#include "wl_oracle_impl.h"
+#undef T
+#undef FN
+
+/* ------------------------------------------------------------------------ */
+/*                       exported entry points (ctypes)                      */
+/* ------------------------------------------------------------------------ */
+#define WLO_API __attribute__((visibility("default")))
+
+WLO_API int wlo_maxtransformlevels_n(int64_t n) { return wlo_maxtransformlevels((long)n); }
+
+/* dwt/idwt with an OrthoFilter; dims in Julia order (dim 1 fastest).        */
+WLO_API int wlo_dwt_filter(int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                           const double *qmf, int flen, int L, int fw)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (ndims < 1 || ndims > 3) return WLO_EINVAL_DIMS;
+    long m = (long)dims[0], n = ndims > 1 ? (long)dims[1] : 1, d = ndims > 2 ? (long)dims[2] : 1;
+    if (dtype == 0) {
+        if (ndims == 1) return f_dwt1d_f32((float *)y, (const float *)x, m, qmf, flen, L, fw);
+        if (ndims == 2) return f_dwt2d_f32((float *)y, (const float *)x, m, n, qmf, flen, L, fw);
+        return f_dwt3d_f32((float *)y, (const float *)x, m, n, d, qmf, flen, L, fw);
+    } else if (dtype == 1) {
+        if (ndims == 1) return f_dwt1d_f64((double *)y, (const double *)x, m, qmf, flen, L, fw);
+        if (ndims == 2) return f_dwt2d_f64((double *)y, (const double *)x, m, n, qmf, flen, L, fw);
+        return f_dwt3d_f64((double *)y, (const double *)x, m, n, d, qmf, flen, L, fw);
+    }
+    return WLO_EINVAL_DTYPE;
+}
+
+/* dwt!/idwt! with a GLS lifting scheme, in place on y.                      */
+WLO_API int wlo_dwt_lifting(int dtype, void *y, int ndims, const int64_t *dims,
+                            int nsteps, const int32_t *is_update, const int32_t *ncoef,
+                            const int32_t *shift, const double *coefs, double norm1, double norm2,
+                            int L, int fw)
+{
+    wlo_scheme sc = { nsteps, is_update, ncoef, shift, coefs, norm1, norm2 };
+    if (ndims < 1 || ndims > 3) return WLO_EINVAL_DIMS;
+    long m = (long)dims[0], n = ndims > 1 ? (long)dims[1] : 1, d = ndims > 2 ? (long)dims[2] : 1;
+    if (dtype == 0) {
+        if (ndims == 1) return l_dwt1d_f32((float *)y, m, &sc, L, fw);
+        if (ndims == 2) return l_dwt2d_f32((float *)y, m, n, &sc, L, fw);
+        return l_dwt3d_f32((float *)y, m, n, d, &sc, L, fw);
+    } else if (dtype == 1) {
+        if (ndims == 1) return l_dwt1d_f64((double *)y, m, &sc, L, fw);
+        if (ndims == 2) return l_dwt2d_f64((double *)y, m, n, &sc, L, fw);
+        return l_dwt3d_f64((double *)y, m, n, d, &sc, L, fw);
+    }
+    return WLO_EINVAL_DTYPE;
+}
+
+/* wpt/iwpt with an OrthoFilter and a BitVector tree (1 byte per node).      */
+WLO_API int wlo_wpt_filter(int dtype, void *y, const void *x, int64_t n,
+                           const double *qmf, int flen, const unsigned char *tree, int64_t ntree, int fw)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (dtype == 0) return f_wpt1d_f32((float *)y, (const float *)x, (long)n, qmf, flen, tree, (long)ntree, fw);
+    if (dtype == 1) return f_wpt1d_f64((double *)y, (const double *)x, (long)n, qmf, flen, tree, (long)ntree, fw);
+    return WLO_EINVAL_DTYPE;
+}
+WLO_API int wlo_wpt_lifting(int dtype, void *y, int64_t n,
+                            int nsteps, const int32_t *is_update, const int32_t *ncoef,
+                            const int32_t *shift, const double *coefs, double norm1, double norm2,
+                            const unsigned char *tree, int64_t ntree, int fw)
+{
+    wlo_scheme sc = { nsteps, is_update, ncoef, shift, coefs, norm1, norm2 };
+    if (dtype == 0) return l_wpt1d_f32((float *)y, (long)n, &sc, tree, (long)ntree, fw);
+    if (dtype == 1) return l_wpt1d_f64((double *)y, (long)n, &sc, tree, (long)ntree, fw);
+    return WLO_EINVAL_DTYPE;
+}
+
+/* Batched column-wise transform ("dwtc": named at transforms_main.jl:179-181
+ * but never implemented by the reference).  Defined by this build as the 1-D
+ * _dwt! applied independently to each column of a len x nsignals column-major
+ * matrix with leading dimension ld -- so the oracle is the 1-D oracle per
+ * column.                                                                   */
+WLO_API int wlo_dwtc_filter(int dtype, void *y, const void *x, int64_t len, int64_t nsignals, int64_t ld,
+                            const double *qmf, int flen, int L, int fw)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    size_t es = dtype == 0 ? 4 : 8;
+    if (dtype != 0 && dtype != 1) return WLO_EINVAL_DTYPE;
+    for (int64_t j = 0; j < nsignals; ++j) {
+        void *yj = (char *)y + (size_t)(j * ld) * es;
+        const void *xj = (const char *)x + (size_t)(j * ld) * es;
+        int rc = dtype == 0 ? f_dwt1d_f32((float *)yj, (const float *)xj, (long)len, qmf, flen, L, fw)
+                            : f_dwt1d_f64((double *)yj, (const double *)xj, (long)len, qmf, flen, L, fw);
+        if (rc) return rc;
+    }
+    return 0;
+}
+WLO_API int wlo_dwtc_lifting(int dtype, void *y, int64_t len, int64_t nsignals, int64_t ld,
+                             int nsteps, const int32_t *is_update, const int32_t *ncoef,
+                             const int32_t *shift, const double *coefs, double norm1, double norm2,
+                             int L, int fw)
+{
+    wlo_scheme sc = { nsteps, is_update, ncoef, shift, coefs, norm1, norm2 };
+    size_t es = dtype == 0 ? 4 : 8;
+    if (dtype != 0 && dtype != 1) return WLO_EINVAL_DTYPE;
+    for (int64_t j = 0; j < nsignals; ++j) {
+        void *yj = (char *)y + (size_t)(j * ld) * es;
+        int rc = dtype == 0 ? l_dwt1d_f32((float *)yj, (long)len, &sc, L, fw)
+                            : l_dwt1d_f64((double *)yj, (long)len, &sc, L, fw);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* Building blocks, exported so tests can pin the closed forms used by the
+ * HIP kernels against the literal loops one function at a time.            */
+WLO_API int wlo_filtdown(int dtype, const void *f, int flen, void *out, int64_t iout, int64_t nout,
+                         const void *x, int64_t ix, int64_t shift, int ss)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (dtype == 0) { float si[WLO_MAXF]; filtdown_f32((const float *)f, flen, si, (float *)out, iout, nout, (const float *)x, ix, shift, ss); return 0; }
+    if (dtype == 1) { double si[WLO_MAXF]; filtdown_f64((const double *)f, flen, si, (double *)out, iout, nout, (const double *)x, ix, shift, ss); return 0; }
+    return WLO_EINVAL_DTYPE;
+}
+WLO_API int wlo_filtup(int dtype, int add2out, const void *f, int flen, void *out, int64_t iout, int64_t nout,
+                       const void *x, int64_t ix, int64_t shift, int ss)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (dtype == 0) { float si[WLO_MAXF]; filtup_f32(add2out, (const float *)f, flen, si, (float *)out, iout, nout, (const float *)x, ix, shift, ss); return 0; }
+    if (dtype == 1) { double si[WLO_MAXF]; filtup_f64(add2out, (const double *)f, flen, si, (double *)out, iout, nout, (const double *)x, ix, shift, ss); return 0; }
+    return WLO_EINVAL_DTYPE;
+}
+WLO_API int wlo_makereverseqmfpair(int dtype, const double *qmf, int flen, int fw, void *scfilter, void *dcfilter)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (dtype == 0) { makereverseqmfpair_f32(qmf, flen, fw, (float *)scfilter, (float *)dcfilter); return 0; }
+    if (dtype == 1) { makereverseqmfpair_f64(qmf, flen, fw, (double *)scfilter, (double *)dcfilter); return 0; }
+    return WLO_EINVAL_DTYPE;
+}
+/* one lift! call on x[1:2*half] with already direction-adjusted coefficients */
+WLO_API int wlo_lift(int dtype, void *x, int64_t half, int is_update, int nc, int shift, const void *coef)
+{
+    if (nc < 1 || nc > 3) return WLO_EINVAL_SCHEME;
+    if (dtype == 0) { lsstep_f32 st; st.is_update = is_update; st.nc = nc; st.shift = shift; memcpy(st.coef, coef, (size_t)nc * 4); lift_f32((float *)x, half, &st); return 0; }
+    if (dtype == 1) { lsstep_f64 st; st.is_update = is_update; st.nc = nc; st.shift = shift; memcpy(st.coef, coef, (size_t)nc * 8); lift_f64((double *)x, half, &st); return 0; }
+    return WLO_EINVAL_DTYPE;
+}
+WLO_API int wlo_split(int dtype, void *a, int64_t n)
+{
+    void *tmp = malloc((size_t)((n >> 2) + 2) * 8);
+    if (dtype == 0) split_ip_f32((float *)a, n, (float *)tmp); else split_ip_f64((double *)a, n, (double *)tmp);
+    free(tmp); return 0;
+}
+WLO_API int wlo_merge(int dtype, void *a, int64_t n)
+{
+    void *tmp = malloc((size_t)((n >> 2) + 2) * 8);
+    if (dtype == 0) merge_ip_f32((float *)a, n, (float *)tmp); else merge_ip_f64((double *)a, n, (double *)tmp);
+    free(tmp); return 0;
+}

@@ -1,0 +1,31 @@
+"""wavelets.jl_amd -- MI355X-native (gfx950, hand-written HIP) backend for the DWT hot path
+of JuliaDSP/Wavelets.jl, with a host-side mirror of the reference's transform API.
+
+    import wavelets_jl_amd as W            # (repo-root shim; the directory name has a dot)
+    from wavelets_jl_amd import WT, wavelet, dwt, idwt
+    x = W.to_device(np.random.randn(8192, 8192).astype(np.float32))
+    y = dwt(x, wavelet(WT.db4))            # runs on the current HIP device/stream
+    xr = idwt(y, wavelet(WT.db4))
+
+The compute lives in libwavelets_mi355x.so (csrc/, C ABI in include/wavelets_mi355x.h).
+"""
+from . import wt as WT
+from . import util as Util
+from .wt import wavelet, OrthoFilter, GLS
+from .util import (maxtransformlevels, sufficientpoweroftwo, detailindex, detailrange, detailn,
+                   ndyadicscales, maketree, isvalidtree, iscube, isdyadic)
+from .transforms import (dwt, idwt, dwt_, idwt_, dwtc, idwtc, wpt, iwpt, wpt_, iwpt_,
+                         to_device, to_host, similar, julia_layout, is_julia_layout,
+                         reserve_workspace, set_kernel_path, last_kernel,
+                         DimensionMismatch, ArgumentError, HIPError)
+from . import _lib
+
+__all__ = [
+    "WT", "Util", "wavelet", "OrthoFilter", "GLS",
+    "dwt", "idwt", "dwt_", "idwt_", "dwtc", "idwtc", "wpt", "iwpt", "wpt_", "iwpt_",
+    "maxtransformlevels", "sufficientpoweroftwo", "detailindex", "detailrange", "detailn",
+    "ndyadicscales", "maketree", "isvalidtree", "iscube", "isdyadic",
+    "to_device", "to_host", "similar", "julia_layout", "is_julia_layout",
+    "reserve_workspace", "set_kernel_path", "last_kernel",
+    "DimensionMismatch", "ArgumentError", "HIPError",
+]

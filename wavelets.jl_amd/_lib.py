@@ -1,0 +1,83 @@
+"""ctypes binding of libwavelets_mi355x.so (include/wavelets_mi355x.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no gfx950 device is
+present, importing the symbols works (so CPU-only tests can check the ABI) but creating a
+context raises -- the product path never runs on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwavelets_mi355x.so")
+
+WL_F32, WL_F64 = 0, 1
+
+STATUS = {
+    0: "WL_OK", -1: "WL_EINVAL_SIZE", -2: "WL_EINVAL_L", -3: "WL_EALIAS", -4: "WL_EDIMS",
+    -5: "WL_EINVAL_CUBE", -6: "WL_EINVAL_TREE", -7: "WL_EINVAL_SCHEME", -8: "WL_EINVAL_DTYPE",
+    -9: "WL_EINVAL_FILTER", -10: "WL_EINVAL_ARG", -11: "WL_ENOMEM", -12: "WL_EHIP", -13: "WL_ENODEVICE",
+}
+
+
+class WaveletsLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/wavelets_mi355x.h declares
+SIGNATURES = {
+    "wl_version": (C.c_int, []),
+    "wl_strerror": (C.c_char_p, [C.c_int]),
+    "wl_maxtransformlevels": (C.c_int, [C.c_int64]),
+    "wl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "wl_ctx_destroy": (C.c_int, [_vp]),
+    "wl_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, _i64p, C.c_int]),
+    "wl_ctx_reserve": (C.c_int, [_vp, C.c_size_t]),
+    "wl_stream_sync": (C.c_int, [_vp, _vp]),
+    "wl_last_hip_error": (C.c_int, [_vp]),
+    "wl_ctx_set_path": (C.c_int, [_vp, C.c_int]),
+    "wl_last_kernel": (C.c_char_p, [_vp]),
+    "wl_dwt_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, _f64p, C.c_int, C.c_int, C.c_int, _vp]),
+    "wl_dwt_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64p, C.c_int, _i32p, _i32p, _i32p, _f64p,
+                                 C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
+    "wl_dwt_lifting_oop": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, C.c_int, _i32p, _i32p, _i32p, _f64p,
+                                     C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
+    "wl_dwtc_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _f64p, C.c_int,
+                                 C.c_int, C.c_int, _vp]),
+    "wl_dwtc_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, _i32p, _i32p, _i32p,
+                                  _f64p, C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
+    "wl_wpt_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, _f64p, C.c_int, _u8p, C.c_int64, C.c_int, _vp]),
+    "wl_wpt_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _i32p, _i32p, _i32p, _f64p,
+                                 C.c_double, C.c_double, _u8p, C.c_int64, C.c_int, _vp]),
+}
+
+
+def load():
+    """Load the shared library (no GPU needed for this step) and bind every ABI symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WaveletsLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C wavelets.jl_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for nm, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, nm)          # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(rc: int) -> str:
+    return load().wl_strerror(rc).decode()

@@ -1,0 +1,570 @@
+// wl_api.hip -- the C ABI of libwavelets_mi355x.so (include/wavelets_mi355x.h):
+// argument contract of the reference's _dwt!/_wpt! methods, workspace management, and
+// the host-side level loops that sequence the HIP kernels on the caller's stream.
+#include "wl_internal.h"
+#include "wl_fast.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace wl;
+
+struct wl_ctx {
+    int device = 0;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    int last_hip = 0;
+    int path = 0;                       // 0 auto, 1 generic only
+    const char *last_kernel = "none";
+    int cu_count = 256;
+};
+
+namespace {
+
+inline int hip_fail(wl_ctx *ctx, hipError_t e)
+{
+    if (ctx) ctx->last_hip = (int)e;
+    return WL_EHIP;
+}
+#define WL_HIP(ctx, expr)                                  \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hip_fail((ctx), e__); \
+    } while (0)
+
+inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int64_t)1 << L)) == 0; }
+
+int ensure_ws(wl_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return WL_OK;
+    // grow-only; the old block may still be in use by kernels queued on the caller's
+    // stream, so synchronise the device before freeing it (rare: only on growth).
+    WL_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->ws) { WL_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    void *p = nullptr;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return WL_ENOMEM; }
+    ctx->ws = p;
+    ctx->ws_bytes = want;
+    return WL_OK;
+}
+
+// Workspace carve-up (elements of T), N = number of elements of the box:
+//   T0, T1 : N each   inter-pass buffers (T1 only for 3-D); T0 doubles as lifting "W"
+//   W      : N        lifting work buffer
+//   A, B   : N/2 each approximation ping-pong (level l writes the one level l+1 reads)
+// => 4 N elements is always enough (and is what wl_workspace_bytes reports).
+inline size_t ws_elems(int64_t N) { return (size_t)(4 * N + 64); }
+
+Strides3 dense_strides(const int64_t n[3])
+{
+    Strides3 s;
+    s.s[0] = 1; s.s[1] = n[0]; s.s[2] = n[0] * n[1];
+    return s;
+}
+
+template <typename T>
+void make_taps(const double *qmf, int flen, Taps<T> &t)
+{
+    t.F = flen;
+    for (int i = 0; i < WL_MAX_FLEN; ++i) { t.h[i] = (T)0; t.g[i] = (T)0; }
+    for (int i = 0; i < flen; ++i) {
+        t.h[i] = (T)qmf[i];                                   // copyto!(Vector{T}, qmf)
+        t.g[i] = (i % 2 == 0) ? t.h[i] : (T)(t.h[i] * (T)-1); // mirror(h), util_main.jl:30
+    }
+}
+
+// makescheme (transforms_lifting.jl:13-25)
+template <typename T>
+int make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift,
+                const double *coefs, double norm1, double norm2, int fw, LiftScheme<T> &sc)
+{
+    if (nsteps < 0 || nsteps > WL_MAX_STEPS) return WL_EINVAL_SCHEME;
+    if (nsteps > 0 && (!is_update || !ncoef || !shift || !coefs)) return WL_EINVAL_ARG;
+    int off[WL_MAX_STEPS];
+    int o = 0;
+    for (int i = 0; i < nsteps; ++i) {
+        if (ncoef[i] < 1 || ncoef[i] > WL_MAX_NCOEF) return WL_EINVAL_SCHEME;
+        off[i] = o;
+        o += ncoef[i];
+    }
+    sc.nsteps = nsteps;
+    for (int i = 0; i < nsteps; ++i) {
+        int j = fw ? i : nsteps - 1 - i;
+        LiftStep<T> &st = sc.step[i];
+        st.is_update = is_update[j] ? 1 : 0;
+        st.nc = ncoef[j];
+        st.shift = shift[j];
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) st.c[k] = (T)0;
+        for (int k = 0; k < st.nc; ++k) st.c[k] = (T)(coefs[off[j] + k] * (fw ? -1.0 : 1.0));
+    }
+    sc.norm1 = (T)(fw ? norm1 : 1.0 / norm1);
+    sc.norm2 = (T)(fw ? norm2 : 1.0 / norm2);
+    return WL_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// A "box transform" covers dwt (all axes of an nd box transformed) and dwtc (axis 0 of a
+// len x nsignals box).  taxes = number of leading axes that are transformed... dwtc
+// transforms axis 0 only, dwt transforms axes 0..nd-1.
+struct BoxSpec {
+    int nd;                 // rank of the array (1..3)
+    int nt;                 // transformed axes are 0..nt-1
+    int64_t dims[3];        // full extents (unused dims = 1)
+    Strides3 full;          // strides of x / y
+};
+
+template <typename T>
+struct Work {
+    T *T0, *T1, *W, *A, *B;
+};
+template <typename T>
+Work<T> carve(void *ws, int64_t N)
+{
+    Work<T> w;
+    T *p = (T *)ws;
+    w.T0 = p; p += N;
+    w.T1 = p; p += N;
+    w.W = p; p += N;
+    w.A = p; p += N / 2 + 8;
+    w.B = p;
+    return w;
+}
+
+inline void level_box(const BoxSpec &b, int l /*1-based*/, int64_t n[3])
+{
+    for (int d = 0; d < 3; ++d) n[d] = (d < b.nt) ? (b.dims[d] >> (l - 1)) : b.dims[d];
+}
+inline Extent3 low_corner(const BoxSpec &b, const int64_t n[3])
+{
+    Extent3 lo;
+    for (int d = 0; d < 3; ++d) lo.n[d] = (d < b.nt) ? (n[d] >> 1) : n[d];
+    return lo;
+}
+
+// ---- generic filter level loops ----------------------------------------------------------
+template <typename T>
+int generic_filter_fwd(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                       const Taps<T> &taps, int L, int l_first, const T *src0, Strides3 src0_st,
+                       int *pp_io)
+{
+    // l_first > 1 lets a fast path do the first levels and hand over the approximation
+    // (src0, dense strides) to the generic levels.
+    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ctx->ws, N);
+    const T *cur = src0;
+    Strides3 cur_st = src0_st;
+    int pp = pp_io ? *pp_io : 0;
+    for (int l = l_first; l <= L; ++l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        const bool last = (l == L);
+        T *llbuf = pp ? w.B : w.A;
+        int64_t hn[3] = {lo.n[0], lo.n[1], lo.n[2]};
+        Strides3 ll_st = dense_strides(hn);
+        Strides3 box_st = dense_strides(n);
+        const T *in = cur;
+        Strides3 in_st = cur_st;
+        int tog = 0;
+        for (int a = b.nt - 1; a >= 0; --a) {
+            if (a != 0) {
+                T *out = tog ? w.T1 : w.T0;
+                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, taps, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
+                in = out; in_st = box_st; tog ^= 1;
+            } else {
+                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, taps, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+            }
+        }
+        cur = llbuf; cur_st = ll_st; pp ^= 1;
+    }
+    if (pp_io) *pp_io = pp;
+    return WL_OK;
+}
+
+template <typename T>
+int generic_filter_inv(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                       const Taps<T> &taps, int L)
+{
+    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ctx->ws, N);
+    // reconstruction ping-pong: level l output box has N/2^(nt*(l-1)) elements; for l >= 2
+    // that is <= N/2, so A/B (N/2 each) suffice.
+    int pp = 0;
+    const T *llsrc = nullptr;
+    Strides3 llsrc_st = {{0, 0, 0}};
+    for (int l = L; l >= 1; --l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        Strides3 box_st = dense_strides(n);
+        const T *in = x;
+        Strides3 in_st = b.full;
+        int tog = 0;
+        T *res = nullptr;
+        for (int a = 0; a < b.nt; ++a) {
+            const bool firstp = (a == 0), lastp = (a == b.nt - 1);
+            T *out; Strides3 out_st;
+            if (lastp) {
+                if (l == 1) { out = y; out_st = b.full; }
+                else { out = pp ? w.B : w.A; out_st = box_st; }
+                res = out;
+            } else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
+            WL_HIP(ctx, generic_inv_filter_pass<T>(st, taps, in, in_st, firstp ? llsrc : (const T *)nullptr, llsrc_st,
+                                                   out, out_st, ext, a, lo));
+            in = out; in_st = out_st;
+        }
+        llsrc = res; llsrc_st = box_st; pp ^= 1;
+    }
+    return WL_OK;
+}
+
+// ---- generic lifting level loops -----------------------------------------------------------
+template <typename T>
+int generic_lifting_fwd(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                        const LiftScheme<T> &sc, int L)
+{
+    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ctx->ws, N);
+    const T *cur = x;
+    Strides3 cur_st = b.full;
+    int pp = 0;
+    for (int l = 1; l <= L; ++l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        const bool last = (l == L);
+        T *llbuf = pp ? w.B : w.A;
+        int64_t hn[3] = {lo.n[0], lo.n[1], lo.n[2]};
+        Strides3 ll_st = dense_strides(hn);
+        Strides3 box_st = dense_strides(n);
+        const T *in = cur;
+        Strides3 in_st = cur_st;
+        int tog = 0;
+        for (int a = b.nt - 1; a >= 0; --a) {
+            WL_HIP(ctx, generic_lift_split<T>(st, in, in_st, w.W, box_st, ext, a));
+            for (int s = 0; s < sc.nsteps; ++s)
+                WL_HIP(ctx, generic_lift_step<T>(st, sc.step[s], w.W, box_st, ext, a));
+            if (a != 0) {
+                T *out = tog ? w.T1 : w.T0;
+                WL_HIP(ctx, generic_lift_finish_fwd<T>(st, sc.norm1, sc.norm2, w.W, box_st, out, box_st,
+                                                       (T *)nullptr, box_st, ext, a, lo));
+                in = out; in_st = box_st; tog ^= 1;
+            } else {
+                WL_HIP(ctx, generic_lift_finish_fwd<T>(st, sc.norm1, sc.norm2, w.W, box_st, y, b.full,
+                                                       last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+            }
+        }
+        cur = llbuf; cur_st = ll_st; pp ^= 1;
+    }
+    return WL_OK;
+}
+
+template <typename T>
+int generic_lifting_inv(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                        const LiftScheme<T> &sc, int L)
+{
+    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ctx->ws, N);
+    int pp = 0;
+    const T *llsrc = nullptr;
+    Strides3 llsrc_st = {{0, 0, 0}};
+    for (int l = L; l >= 1; --l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        Strides3 box_st = dense_strides(n);
+        const T *in = x;
+        Strides3 in_st = b.full;
+        int tog = 0;
+        T *res = nullptr;
+        for (int a = 0; a < b.nt; ++a) {
+            const bool firstp = (a == 0), lastp = (a == b.nt - 1);
+            WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc.norm1, sc.norm2, in, in_st,
+                                                 firstp ? llsrc : (const T *)nullptr, llsrc_st, w.W, box_st, ext, a, lo));
+            for (int s = 0; s < sc.nsteps; ++s)
+                WL_HIP(ctx, generic_lift_step<T>(st, sc.step[s], w.W, box_st, ext, a));
+            T *out; Strides3 out_st;
+            if (lastp) {
+                if (l == 1) { out = y; out_st = b.full; }
+                else { out = pp ? w.B : w.A; out_st = box_st; }
+                res = out;
+            } else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
+            WL_HIP(ctx, generic_lift_merge<T>(st, w.W, box_st, out, out_st, ext, a));
+            in = out; in_st = out_st;
+        }
+        llsrc = res; llsrc_st = box_st; pp ^= 1;
+    }
+    return WL_OK;
+}
+
+// ---- argument contract (transforms_filter.jl:24-38, transforms_lifting.jl:33-43,131-143) ----
+int check_box(int ndims, const int64_t *dims, int L, BoxSpec &b)
+{
+    if (!dims) return WL_EINVAL_ARG;
+    if (ndims < 1 || ndims > 3) return WL_EDIMS;
+    b.nd = ndims; b.nt = ndims;
+    for (int d = 0; d < 3; ++d) b.dims[d] = (d < ndims) ? dims[d] : 1;
+    for (int d = 0; d < ndims; ++d)
+        if (b.dims[d] < 1) return WL_EDIMS;
+    if (L < 0) return WL_EINVAL_L;
+    for (int d = 0; d < ndims; ++d)
+        if (!sufficientpoweroftwo(b.dims[d], L)) return WL_EINVAL_SIZE;
+    b.full = dense_strides(b.dims);
+    return WL_OK;
+}
+
+template <typename T>
+int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                    const double *qmf, int flen, int L, int fw)
+{
+    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    if (L == 0) {
+        Extent3 ext = {{b.dims[0], b.dims[1], b.dims[2]}};
+        WL_HIP(ctx, generic_copy_box<T>(st, x, b.full, y, b.full, ext));
+        ctx->last_kernel = "copy";
+        return WL_OK;
+    }
+    int rc = ensure_ws(ctx, ws_elems(N) * sizeof(T));
+    if (rc) return rc;
+    Taps<T> taps;
+    make_taps<T>(qmf, flen, taps);
+    if (fw) {
+        if (ctx->path == 0) {
+            int handled = 0;
+            rc = fast_filter_fwd<T>(ctx->ws, ctx->cu_count, st, b.nd, b.nt, b.dims, b.full, y, x, taps, L,
+                                    &handled, &ctx->last_kernel, &ctx->last_hip);
+            if (rc) return rc;
+            if (handled) return WL_OK;
+        }
+        ctx->last_kernel = "k_generic_fwd_filter";
+        return generic_filter_fwd<T>(ctx, st, b, y, x, taps, L, 1, x, b.full, nullptr);
+    }
+    ctx->last_kernel = "k_generic_inv_filter";
+    return generic_filter_inv<T>(ctx, st, b, y, x, taps, L);
+}
+
+template <typename T>
+int dwt_lifting_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
+                     int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift,
+                     const double *coefs, double norm1, double norm2, int L, int fw)
+{
+    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    LiftScheme<T> sc;
+    int rc = make_scheme<T>(nsteps, is_update, ncoef, shift, coefs, norm1, norm2, fw, sc);
+    if (rc) return rc;
+    if (L == 0) {
+        if (y != x) {
+            Extent3 ext = {{b.dims[0], b.dims[1], b.dims[2]}};
+            WL_HIP(ctx, generic_copy_box<T>(st, x, b.full, y, b.full, ext));
+        }
+        ctx->last_kernel = "copy";
+        return WL_OK;
+    }
+    rc = ensure_ws(ctx, ws_elems(N) * sizeof(T));
+    if (rc) return rc;
+    ctx->last_kernel = fw ? "k_generic_lift_fwd" : "k_generic_lift_inv";
+    return fw ? generic_lifting_fwd<T>(ctx, st, b, y, x, sc, L) : generic_lifting_inv<T>(ctx, st, b, y, x, sc, L);
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+int wl_version(void) { return WL_VERSION; }
+
+const char *wl_strerror(int status)
+{
+    switch (status) {
+    case WL_OK: return "ok";
+    case WL_EINVAL_SIZE: return "size must have a sufficient power of 2 factor";
+    case WL_EINVAL_L: return "L must be positive";
+    case WL_EALIAS: return "in array is out array";
+    case WL_EDIMS: return "in and out array size must match / bad dimensions";
+    case WL_EINVAL_CUBE: return "array must be square/cube";
+    case WL_EINVAL_TREE: return "invalid tree";
+    case WL_EINVAL_SCHEME: return "invalid lifting scheme";
+    case WL_EINVAL_DTYPE: return "unsupported element type";
+    case WL_EINVAL_FILTER: return "unsupported filter length";
+    case WL_EINVAL_ARG: return "invalid argument";
+    case WL_ENOMEM: return "device workspace allocation failed";
+    case WL_EHIP: return "HIP runtime error";
+    case WL_ENODEVICE: return "no gfx950 HIP device";
+    default: return "unknown status";
+    }
+}
+
+int wl_maxtransformlevels(int64_t n)
+{
+    if (n <= 1) return 0;
+    int tl = 0;
+    while (sufficientpoweroftwo(n, tl)) tl += 1;
+    return tl - 1;
+}
+
+int wl_ctx_create(int device, wl_ctx **out)
+{
+    if (!out) return WL_EINVAL_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return WL_ENODEVICE;
+    if (device < 0 || device >= count) return WL_ENODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WL_ENODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return WL_ENODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return WL_ENODEVICE;
+    wl_ctx *c = new (std::nothrow) wl_ctx();
+    if (!c) return WL_ENOMEM;
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return WL_OK;
+}
+
+int wl_ctx_destroy(wl_ctx *ctx)
+{
+    if (!ctx) return WL_EINVAL_ARG;
+    if (ctx->ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->ws); }
+    delete ctx;
+    return WL_OK;
+}
+
+size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L)
+{
+    (void)L;
+    if (!dims || ndims < 1 || ndims > 3) return 0;
+    int64_t N = 1;
+    for (int d = 0; d < ndims; ++d) N *= dims[d];
+    return ws_elems(N) * (dtype == WL_F64 ? 8 : 4);
+}
+
+int wl_ctx_reserve(wl_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return WL_EINVAL_ARG;
+    return ensure_ws(ctx, bytes);
+}
+
+int wl_stream_sync(wl_ctx *ctx, void *stream)
+{
+    if (!ctx) return WL_EINVAL_ARG;
+    WL_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return WL_OK;
+}
+
+int wl_last_hip_error(const wl_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+int wl_ctx_set_path(wl_ctx *ctx, int path)
+{
+    if (!ctx || path < 0 || path > 1) return WL_EINVAL_ARG;
+    ctx->path = path;
+    return WL_OK;
+}
+const char *wl_last_kernel(const wl_ctx *ctx) { return ctx ? ctx->last_kernel : "none"; }
+
+int wl_dwt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                  const double *qmf, int flen, int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x || !qmf) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    BoxSpec b;
+    int rc = check_box(ndims, dims, L, b);
+    if (rc) return rc;
+    if (y == x) return WL_EALIAS;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? dwt_filter_impl<float>(ctx, st, b, (float *)y, (const float *)x, qmf, flen, L, fw)
+                           : dwt_filter_impl<double>(ctx, st, b, (double *)y, (const double *)x, qmf, flen, L, fw);
+}
+
+static int lifting_common(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                          int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift,
+                          const double *coefs, double norm1, double norm2, int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    BoxSpec b;
+    // iscube check comes first in the reference (transforms_lifting.jl:131-136)
+    if (dims && ndims >= 2 && ndims <= 3)
+        for (int d = 1; d < ndims; ++d)
+            if (dims[d] != dims[0]) return WL_EINVAL_CUBE;
+    int rc = check_box(ndims, dims, L, b);
+    if (rc) return rc;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32
+               ? dwt_lifting_impl<float>(ctx, st, b, (float *)y, (const float *)x, nsteps, is_update, ncoef, shift, coefs, norm1, norm2, L, fw)
+               : dwt_lifting_impl<double>(ctx, st, b, (double *)y, (const double *)x, nsteps, is_update, ncoef, shift, coefs, norm1, norm2, L, fw);
+}
+
+int wl_dwt_lifting(wl_ctx *ctx, int dtype, void *y, int ndims, const int64_t *dims,
+                   int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                   const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                   int L, int fw, void *stream)
+{
+    return lifting_common(ctx, dtype, y, y, ndims, dims, nsteps, step_is_update, step_ncoef, step_shift,
+                          coefs_flat, norm1, norm2, L, fw, stream);
+}
+
+int wl_dwt_lifting_oop(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                       int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                       const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                       int L, int fw, void *stream)
+{
+    return lifting_common(ctx, dtype, y, x, ndims, dims, nsteps, step_is_update, step_ncoef, step_shift,
+                          coefs_flat, norm1, norm2, L, fw, stream);
+}
+
+// ---- batched column-wise --------------------------------------------------------------------
+static int check_dwtc(int64_t len, int64_t nsignals, int64_t ld, int L, BoxSpec &b)
+{
+    if (len < 1 || nsignals < 1 || ld < len) return WL_EDIMS;
+    if (L < 0) return WL_EINVAL_L;
+    if (!sufficientpoweroftwo(len, L)) return WL_EINVAL_SIZE;
+    b.nd = 2; b.nt = 1;
+    b.dims[0] = len; b.dims[1] = nsignals; b.dims[2] = 1;
+    b.full.s[0] = 1; b.full.s[1] = ld; b.full.s[2] = ld * nsignals;
+    return WL_OK;
+}
+
+int wl_dwtc_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t len, int64_t nsignals, int64_t ld,
+                   const double *qmf, int flen, int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x || !qmf) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    BoxSpec b;
+    int rc = check_dwtc(len, nsignals, ld, L, b);
+    if (rc) return rc;
+    if (y == x) return WL_EALIAS;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? dwt_filter_impl<float>(ctx, st, b, (float *)y, (const float *)x, qmf, flen, L, fw)
+                           : dwt_filter_impl<double>(ctx, st, b, (double *)y, (const double *)x, qmf, flen, L, fw);
+}
+
+int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y, int64_t len, int64_t nsignals, int64_t ld,
+                    int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                    const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                    int L, int fw, void *stream)
+{
+    if (!ctx || !y) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    BoxSpec b;
+    int rc = check_dwtc(len, nsignals, ld, L, b);
+    if (rc) return rc;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32
+               ? dwt_lifting_impl<float>(ctx, st, b, (float *)y, (const float *)y, nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, L, fw)
+               : dwt_lifting_impl<double>(ctx, st, b, (double *)y, (const double *)y, nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, L, fw);
+}
+
+}  // extern "C"

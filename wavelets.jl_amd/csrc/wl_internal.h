@@ -1,0 +1,94 @@
+// wl_internal.h -- shared declarations of libwavelets_mi355x (not part of the ABI).
+//
+// Arithmetic contract (all kernels): products and sums are rounded separately
+// (no FMA contraction; the library is built with -ffp-contract=off and a unit
+// test greps the gfx950 ISA for v_fma/v_mac/v_fmac) and sums run in the order of
+// the reference's shift-register loops:
+//   forward  s[k] = ((h0*x[2k] + h1*x[2k+1]) + h2*x[2k+2]) + ...            (m ascending)
+//            d[k] = ((g[F-1]*x[2k+2-F] + g[F-2]*x[2k+3-F]) + ...) + g0*x[2k+1] (m descending)
+//   inverse  S[o] = sum over m descending, (o-m) even, of h[m]*s[(o-m)/2]
+//            D[o] = sum over m ascending, (o+m-1) even, of g[m]*d[(o+m-1)/2]
+//            x[o] = S[o] + D[o]
+// (transforms_filter.jl:362-369 @filtermainloop, :387-433 filtdown!, :467-541 filtup!;
+//  g[m] = (-1)^m h[m] = Util.mirror, util_main.jl:30), all indices periodic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/wavelets_mi355x.h"
+
+#pragma clang fp contract(off)
+
+namespace wl {
+
+template <typename T>
+struct Taps {
+    int F;
+    T h[WL_MAX_FLEN];   // qmf converted to T (makereverseqmfpair: copyto!(Vector{T}, qmf))
+    T g[WL_MAX_FLEN];   // mirror(h)
+};
+
+template <typename T>
+struct LiftStep {
+    int is_update;      // 0: Predict (writes the s half), 1: Update (writes the d half)
+    int nc;
+    int shift;
+    T c[WL_MAX_NCOEF];  // direction-adjusted (makescheme)
+};
+template <typename T>
+struct LiftScheme {
+    int nsteps;
+    LiftStep<T> step[WL_MAX_STEPS];
+    T norm1, norm2;     // direction-adjusted
+};
+
+// A strided 3-D view in elements.
+struct Strides3 { int64_t s[3]; };
+struct Extent3 { int64_t n[3]; };
+
+// ---- generic (any size, any filter length, any axis) kernels: wl_generic.hip ----
+template <typename T>
+hipError_t generic_fwd_filter_pass(hipStream_t st, const Taps<T> &taps,
+                                   const T *src, Strides3 sst,
+                                   T *dst, Strides3 dst_st,
+                                   T *ll, Strides3 ll_st,
+                                   Extent3 n, int axis, Extent3 lo);
+template <typename T>
+hipError_t generic_inv_filter_pass(hipStream_t st, const Taps<T> &taps,
+                                   const T *src, Strides3 sst,
+                                   const T *ll, Strides3 ll_st,
+                                   T *dst, Strides3 dst_st,
+                                   Extent3 n, int axis, Extent3 lo);
+// lifting building blocks (box n, [s;d] layout along `axis` in the dense work buffer w)
+template <typename T>
+hipError_t generic_lift_split(hipStream_t st, const T *src, Strides3 sst, T *w, Strides3 wst,
+                              Extent3 n, int axis);
+template <typename T>
+hipError_t generic_lift_step(hipStream_t st, const LiftStep<T> &step, T *w, Strides3 wst,
+                             Extent3 n, int axis);
+template <typename T>
+hipError_t generic_lift_finish_fwd(hipStream_t st, T n1, T n2, const T *w, Strides3 wst,
+                                   T *dst, Strides3 dst_st, T *ll, Strides3 ll_st,
+                                   Extent3 n, int axis, Extent3 lo);
+template <typename T>
+hipError_t generic_lift_norm_inv(hipStream_t st, T n1, T n2, const T *src, Strides3 sst,
+                                 const T *ll, Strides3 ll_st, T *w, Strides3 wst,
+                                 Extent3 n, int axis, Extent3 lo);
+template <typename T>
+hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, Strides3 dst_st,
+                              Extent3 n, int axis);
+template <typename T>
+hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, Strides3 dst_st, Extent3 n);
+
+// ---- un-fused arithmetic helpers ----
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+__device__ __forceinline__ int64_t pmod(int64_t a, int64_t n)
+{
+    int64_t r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+}  // namespace wl

@@ -1,0 +1,55 @@
+"""The C ABI: the shared library loads without a GPU and exports exactly the symbols
+include/wavelets_mi355x.h declares.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "wavelets_mi355x.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"WL_API[^;(]*?\b(wl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(W):
+    lib = W._lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 18, syms
+    out = subprocess.check_output(["nm", "-D", "--defined-only", W._lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (wl_[a-z0-9_]+)", out))
+    assert set(syms) == exported, (set(syms) ^ exported)
+    assert set(W._lib.SIGNATURES) == set(syms)
+    for s in syms:
+        assert getattr(lib, s) is not None
+
+
+def test_hostonly_entry_points(W):
+    lib = W._lib.load()
+    assert lib.wl_version() == 100
+    assert lib.wl_strerror(-1) == b"size must have a sufficient power of 2 factor"
+    assert lib.wl_strerror(-3) == b"in array is out array"
+    for n, e in ((1, 0), (2, 1), (40, 3), (1 << 24, 24), (8192, 13), (7, 0)):
+        assert lib.wl_maxtransformlevels(n) == e
+    dims = (C.c_int64 * 3)(8192, 8192, 1)
+    assert lib.wl_workspace_bytes(0, 2, dims, 13) >= 4 * 8192 * 8192 * 4
+
+
+def test_header_compiles_as_c():
+    """The boundary is plain C: no C++/HIP/torch types in the signatures."""
+    src = '#include "wavelets_mi355x.h"\nint main(void){ return wl_version == 0; }\n'
+    p = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                       input=src.encode(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+
+
+def test_no_device_is_loud(W):
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = W._lib.load()
+    out = C.c_void_p()
+    assert lib.wl_ctx_create(0, C.byref(out)) == -13      # WL_ENODEVICE, never a CPU fallback
+    assert not out.value

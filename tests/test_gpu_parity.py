@@ -1,0 +1,286 @@
+"""GPU parity: the HIP path (called through the C ABI via the host mirror) against the CPU oracle
+on the same seeded inputs.  The bar is BIT-EXACT equality for Float32 and Float64 (the kernels use
+the reference's summation order with un-fused multiply/add); -0.0 == +0.0 is accepted."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, golden_cases, make_filter, rng_array
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(W, a):
+    return W.to_device(a)
+
+
+def host(W, t):
+    import torch
+    torch.cuda.synchronize()
+    return W.to_host(t)
+
+
+# ---- the reference's golden vectors, through the GPU --------------------------------------------
+@pytest.mark.parametrize("fam,num,cls,vm", golden_cases())
+def test_golden_vectors_on_gpu(gpu, W, oracle, fam, num, cls, vm):
+    data = golden("filter1d_data.txt")
+    data2 = golden("filter2d_data.txt")
+    wt = make_filter(W, cls, vm)
+    y = host(W, W.dwt(dev(W, data), wt))
+    y2 = host(W, W.dwt(dev(W, data2), wt))
+    assert np.linalg.norm(y - golden(f"filter1d_{fam}{num}.txt")) <= 1e-9 * 8
+    assert np.linalg.norm(y2 - golden(f"filter2d_{fam}{num}.txt")) <= 1e-9 * 8
+    assert np.array_equal(y, oracle.dwt_filter(data, wt.qmf))
+    assert np.array_equal(y2, oracle.dwt_filter(data2, wt.qmf))
+    # inverse (adjoint for the non-orthogonal Battle tables) is bit-identical too
+    assert np.array_equal(host(W, W.idwt(dev(W, y), wt)), oracle.dwt_filter(y, wt.qmf, fw=False))
+    assert np.array_equal(host(W, W.idwt(dev(W, y2), wt)), oracle.dwt_filter(y2, wt.qmf, fw=False))
+
+
+def test_golden_nonsquare_on_gpu(gpu, W, oracle):
+    data2 = golden("filter2d_nonsquare_data.txt")
+    y2 = host(W, W.dwt(dev(W, data2), W.wavelet(W.WT.haar), 1))
+    assert np.linalg.norm(y2 - golden("filter2d_nonsquare_Haar0.txt")) <= 1e-9 * np.sqrt(32)
+
+
+# ---- filter bank, all ranks / sizes / levels -----------------------------------------------------
+SHAPES = [(2,), (8,), (40,), (96,), (1024,), (4096,), (1 << 16,),
+          (2, 2), (8, 8), (4, 8), (24, 40), (64, 64), (96, 32), (256, 128), (512, 512), (128, 1024),
+          (2, 2, 2), (8, 8, 8), (16, 8, 32), (32, 32, 32), (24, 8, 40)]
+FILTERS = ["haar", "db2", "db4", "db3", "sym8", "coif6", "batt2"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_filter_fwd_inv_bitexact(gpu, W, oracle, dtype, shape):
+    x = rng_array(shape, dtype, sum(shape))
+    Lmax = W.maxtransformlevels(x)
+    for fname in FILTERS:
+        wt = W.wavelet(getattr(W.WT, fname))
+        for L in sorted({0, 1, Lmax, max(Lmax - 1, 0)}):
+            ye = oracle.dwt_filter(x, wt.qmf, L)
+            y = host(W, W.dwt(dev(W, x), wt, L))
+            assert y.dtype == dtype and y.shape == x.shape
+            assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max(), W.last_kernel())
+            xr = host(W, W.idwt(dev(W, ye), wt, L))
+            assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fast_and_generic_paths_agree(gpu, W, oracle, dtype):
+    """wl_ctx_set_path(1) forces the generic kernels; both families must give identical bits."""
+    for shape, L in (((1 << 18,), 18), ((1 << 18,), 3), ((1024, 1024), 10), ((512, 2048), 4), ((2048, 256), 8),
+                     ((64, 64, 64), 6)):
+        x = rng_array(shape, dtype, 99)
+        for fname in ("db4", "db2", "haar", "db3", "sym4"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            try:
+                W.set_kernel_path(1)
+                yg = host(W, W.dwt(dev(W, x), wt, L))
+                kg = W.last_kernel()
+            finally:
+                W.set_kernel_path(0)
+            yf = host(W, W.dwt(dev(W, x), wt, L))
+            assert "generic" in kg
+            assert np.array_equal(yg, yf), (shape, L, fname, W.last_kernel(), np.abs(yg - yf).max())
+
+
+# ---- lifting ----------------------------------------------------------------------------------------
+LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256),
+           (4, 4, 4), (16, 16, 16), (24, 24, 24)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", LSHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_lifting_fwd_inv_bitexact(gpu, W, oracle, dtype, shape):
+    x = rng_array(shape, dtype, 5 + sum(shape))
+    Lmax = W.maxtransformlevels(x)
+    for sname in ("cdf97", "db2", "haar", "db1"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        for L in sorted({0, 1, Lmax}):
+            ye = oracle.dwt_lifting(x, sch, L)
+            y = host(W, W.dwt(dev(W, x), sch, L))
+            assert np.array_equal(y, ye), (sname, shape, L, np.abs(y - ye).max())
+            # in-place entry point dwt!(y, scheme, L)
+            t = dev(W, x)
+            r = W.dwt_(t, sch, L)
+            assert r is t and np.array_equal(host(W, t), ye)
+            xr = host(W, W.idwt(dev(W, ye), sch, L))
+            assert np.array_equal(xr, oracle.dwt_lifting(ye, sch, L, fw=False)), (sname, shape, L, "inv")
+            t = dev(W, ye)
+            W.idwt_(t, sch, L)
+            assert np.array_equal(host(W, t), xr)
+
+
+def test_lifting_equals_filter_on_gpu(gpu, W):
+    """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
+    for nd in (1, 2, 3):
+        x = rng_array((32,) * nd, np.float64, nd)
+        for wname in ("db1", "db2"):
+            wf, wl = W.wavelet(getattr(W.WT, wname)), W.wavelet(getattr(W.WT, wname), W.WT.Lifting)
+            for L in (5, 0, 1, 2):
+                yf, yl = host(W, W.dwt(dev(W, x), wf, L)), host(W, W.dwt(dev(W, x), wl, L))
+                assert np.linalg.norm(yf - yl) <= 1e-9 * np.sqrt(x.size)
+                assert np.linalg.norm(host(W, W.idwt(dev(W, yl), wl, L)) - x) <= 1e-9 * np.sqrt(x.size)
+
+
+# ---- dwt! / types / views (test/transforms.jl:130-201) ---------------------------------------------
+def test_inplace_api_and_types(gpu, W, oracle):
+    import torch
+    wt = W.wavelet(W.WT.db2)
+    x = rng_array((64,), np.float32, 1)
+    xd = dev(W, x)
+    y = W.similar(xd)
+    r = W.dwt_(y, xd, wt, 2)
+    assert r is y and y.dtype == torch.float32
+    assert np.array_equal(host(W, y), oracle.dwt_filter(x, wt.qmf, 2))
+    assert np.array_equal(host(W, W.dwt_(W.similar(xd), xd, wt)), host(W, W.dwt(xd, wt)))
+    # Int -> Float (transforms_main.jl:188-190)
+    xi = torch.arange(-8, 8, device=gpu)
+    yi = W.dwt(xi, wt, 2)
+    assert yi.dtype == torch.float64
+    assert np.array_equal(host(W, yi), oracle.dwt_filter(np.arange(-8, 8).astype(np.float64), wt.qmf, 2))
+    # a row-major (non Julia-layout) 2-D tensor is accepted by dwt (copied into Julia layout)
+    a = rng_array((16, 32), np.float64, 3)
+    yt = W.dwt(torch.from_numpy(a).to(gpu), wt, 2)
+    assert np.array_equal(host(W, yt), oracle.dwt_filter(a, wt.qmf, 2))
+
+
+def test_argument_contract_on_gpu(gpu, W):
+    import torch
+    wt = W.wavelet(W.WT.db2)
+    x = dev(W, rng_array((24,), np.float64, 1))
+    with pytest.raises(W.ArgumentError, match="power of 2"):
+        W.dwt(x, wt, 4)
+    with pytest.raises(W.ArgumentError, match="positive"):
+        W.dwt(x, wt, -1)
+    with pytest.raises(W.ArgumentError, match="in array is out array"):
+        W.dwt_(x, x, wt, 1)
+    with pytest.raises(W.DimensionMismatch):
+        W.dwt_(W.similar(x)[:12], x, wt, 1)
+    with pytest.raises(W.ArgumentError, match="square/cube"):
+        W.dwt(dev(W, rng_array((8, 16), np.float64, 1)), W.wavelet(W.WT.db2, W.WT.Lifting), 1)
+    with pytest.raises(TypeError):
+        W.dwt(x.to(torch.complex128), wt, 1)
+    # status codes straight from the ABI
+    lib = W._lib.load()
+    h = C.c_void_p()
+    assert lib.wl_ctx_create(0, C.byref(h)) == 0
+    dims = (C.c_int64 * 3)(24, 1, 1)
+    q = (C.c_double * 4)(*wt.qmf)
+    y = W.similar(x)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.wl_dwt_filter(h, 1, p(y), p(x), 1, dims, q, 4, 4, 1, None) == -1
+    assert lib.wl_dwt_filter(h, 1, p(y), p(x), 1, dims, q, 4, -1, 1, None) == -2
+    assert lib.wl_dwt_filter(h, 1, p(x), p(x), 1, dims, q, 4, 1, 1, None) == -3
+    assert lib.wl_dwt_filter(h, 1, p(y), p(x), 4, dims, q, 4, 1, 1, None) == -4
+    assert lib.wl_dwt_filter(h, 7, p(y), p(x), 1, dims, q, 4, 1, 1, None) == -8
+    assert lib.wl_dwt_filter(h, 1, p(y), p(x), 1, dims, q, 1, 1, 1, None) == -9
+    assert lib.wl_dwt_filter(h, 1, None, p(x), 1, dims, q, 4, 1, 1, None) == -10
+    assert lib.wl_dwt_filter(h, 1, p(y), p(x), 1, dims, q, 4, 1, 1, None) == 0
+    assert lib.wl_stream_sync(h, None) == 0
+    assert lib.wl_ctx_destroy(h) == 0
+
+
+# ---- batched column-wise ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dwtc_bitexact(gpu, W, oracle, dtype):
+    for (n, ns) in ((8, 3), (64, 7), (1024, 33), (4096, 64), (1 << 14, 16)):
+        x = rng_array((n, ns), dtype, n + ns)
+        Lmax = W.maxtransformlevels(n)
+        for fname in ("db4", "haar", "db2"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in sorted({1, Lmax, Lmax // 2}):
+                ye = oracle.dwtc_filter(x, wt.qmf, L)
+                y = host(W, W.dwtc(dev(W, x), wt, L))
+                assert np.array_equal(y, ye), (n, ns, fname, L, W.last_kernel())
+                assert np.array_equal(host(W, W.idwtc(dev(W, ye), wt, L)), oracle.dwtc_filter(ye, wt.qmf, L, fw=False))
+        sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+        ye = oracle.dwtc_lifting(x, sch, Lmax)
+        assert np.array_equal(host(W, W.dwtc(dev(W, x), sch, Lmax)), ye)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ye), sch, Lmax)), oracle.dwtc_lifting(ye, sch, Lmax, fw=False))
+
+
+# ---- wavelet packets ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wpt_bitexact(gpu, W, oracle, dtype):
+    rs = np.random.default_rng(4)
+    for n in (8, 32, 40, 256, 4096):
+        x = rng_array((n,), dtype, n)
+        Lmax = W.maxtransformlevels(n)
+        trees = [W.maketree(n, L, "full") for L in range(0, Lmax + 1)] + [W.maketree(n, L, "dwt") for L in (1, Lmax)]
+        # a random valid tree
+        t = np.zeros(2 ** Lmax - 1, dtype=np.uint8)
+        t[0] = 1
+        for i in range(1, len(t)):
+            parent = (i + 1) // 2 - 1
+            t[i] = 1 if (t[parent] and rs.random() < 0.6) else 0
+        assert W.isvalidtree(np.zeros(n), t)
+        trees.append(t)
+        for tree in trees:
+            for fname in ("db2", "db4"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                ye = oracle.wpt_filter(x, wt.qmf, tree)
+                y = host(W, W.wpt(dev(W, x), wt, tree))
+                assert np.array_equal(y, ye), (n, fname, tree.tolist())
+                assert np.array_equal(host(W, W.iwpt(dev(W, ye), wt, tree)), oracle.wpt_filter(ye, wt.qmf, tree, fw=False))
+            for sname in ("cdf97", "db2"):
+                sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+                ye = oracle.wpt_lifting(x, sch, tree)
+                assert np.array_equal(host(W, W.wpt(dev(W, x), sch, tree)), ye), (n, sname, tree.tolist())
+                assert np.array_equal(host(W, W.iwpt(dev(W, ye), sch, tree)), oracle.wpt_lifting(ye, sch, tree, fw=False))
+    # wpt(x, wt, L) == full tree of depth L; invalid tree is an ArgumentError
+    x = rng_array((64,), np.float64, 1)
+    wt = W.wavelet(W.WT.db2)
+    assert np.array_equal(host(W, W.wpt(dev(W, x), wt, 2)), oracle.wpt_filter(x, wt.qmf, W.maketree(64, 2, "full")))
+    bad = W.maketree(64, 2, "full")
+    bad[0] = 0
+    with pytest.raises(W.ArgumentError, match="invalid tree"):
+        W.wpt(dev(W, x), wt, bad)
+
+
+# ---- BASELINE.json full sizes: size-independent properties -------------------------------------------
+def test_full_size_properties(gpu, W, oracle):
+    """configs[1..3] at full size: round trip, linearity, energy, and exact equality with the oracle on
+    sub-problems the oracle finishes in seconds (a column band of the first level / the deep levels)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(42)
+    wt = W.wavelet(W.WT.db4)
+    # C3: 8192 x 8192 f32, L = 13 (API default), L = 4 and L = 1
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(gpu).t()     # Julia layout view
+    assert W.is_julia_layout(x)
+    nx2 = float(torch.linalg.vector_norm(x.double()))
+    for L in (13, 4, 1):
+        y = W.dwt(x, wt, L)
+        assert abs(float(torch.linalg.vector_norm(y.double())) - nx2) / nx2 < 1e-5      # orthogonal: energy
+        xr = W.idwt(y, wt, L)
+        rel = float(torch.linalg.vector_norm((xr - x).double())) / nx2
+        assert rel < 1e-5, (L, rel)                                                     # round trip
+    # linearity: dwt(a x + b z) ~ a dwt(x) + b dwt(z)
+    z = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(gpu).t()
+    lhs = W.dwt(2.0 * x - 0.5 * z, wt, 13)
+    rhs = 2.0 * W.dwt(x, wt, 13) - 0.5 * W.dwt(z, wt, 13)
+    assert float(torch.linalg.vector_norm((lhs - rhs).double())) / nx2 < 1e-5
+    # exact vs oracle on the coarse part: the level-4.. transform of the LL4 band (512 x 512) equals
+    # the oracle run on that band
+    y4 = W.dwt(x, wt, 4)
+    ll4 = W.to_host(y4[:512, :512])
+    y13 = W.to_host(W.dwt(x, wt, 13)[:512, :512])
+    assert np.array_equal(y13, oracle.dwt_filter(np.ascontiguousarray(ll4), wt.qmf, 9))
+    del x, z, lhs, rhs, y4
+    # C2: 1-D db4 f32 2^24, L = 24 -- exact vs the oracle (the 1-D oracle does 2^24 in about a second)
+    v = torch.randn(1 << 24, generator=g, dtype=torch.float32)
+    yv = W.dwt(v.to(gpu), wt)
+    assert np.array_equal(W.to_host(yv), oracle.dwt_filter(v.numpy(), wt.qmf))
+    assert float(torch.linalg.vector_norm((W.idwt(yv, wt).cpu() - v).double())) / float(torch.linalg.vector_norm(v.double())) < 1e-5
+    # C4: 1-D cdf9/7 lifting f32 2^24, L = 24 -- exact vs the oracle
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    yl = W.dwt(v.to(gpu), sch)
+    assert np.array_equal(W.to_host(yl), oracle.dwt_lifting(v.numpy(), sch))
+    # C1: 1-D db2 f64 2^20 dwt + idwt
+    u = torch.rand(1 << 20, generator=g, dtype=torch.float64)
+    w2 = W.wavelet(W.WT.db2)
+    yu = W.dwt(u.to(gpu), w2)
+    assert np.array_equal(W.to_host(yu), oracle.dwt_filter(u.numpy(), w2.qmf))
+    assert float(torch.linalg.vector_norm(W.idwt(yu, w2).cpu() - u)) / float(torch.linalg.vector_norm(u)) < 1e-12

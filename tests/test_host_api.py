@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference interface (WT types, Util helpers, argument contract).
+No GPU needed: these tests stop at the ABI boundary."""
+import re
+
+import numpy as np
+import pytest
+
+
+def test_wavelet_constructors(W):
+    WT, wavelet = W.WT, W.wavelet
+    f = wavelet(WT.db4)
+    assert isinstance(f, W.OrthoFilter) and len(f) == 8 and f.name == "db4"
+    assert isinstance(wavelet(WT.db4, WT.Filter), W.OrthoFilter)
+    assert isinstance(wavelet(WT.db4, WT.Filter, WT.Periodic), W.OrthoFilter)
+    g = wavelet(WT.cdf97, WT.Lifting)
+    assert isinstance(g, W.GLS) and g.name == "cdf9/7" and len(g.step) == 4
+    assert [type(s.steptype).__name__ for s in g.step] == ["UpdateStep", "PredictStep", "UpdateStep", "PredictStep"]
+    assert g.norm1 == 1.1496043988603355 and g.norm2 == 0.8698644516247099
+    # cdf9/7 exists only as a lifting scheme (wt_main.jl:262-264)
+    with pytest.raises(TypeError):
+        wavelet(WT.cdf97)
+    with pytest.raises(TypeError):
+        wavelet(WT.cdf97, WT.Filter)
+    with pytest.raises(ValueError):
+        wavelet(WT.db4, WT.Lifting)          # "scheme not found"
+    with pytest.raises(ValueError):
+        wavelet(WT.Coiflet(12))              # "filter not found"
+    with pytest.raises(TypeError):
+        wavelet("db4")
+
+
+def test_all_filters_normalised(W):
+    WT, wavelet = W.WT, W.wavelet
+    names = (["haar", "beyl", "vaid"] + [f"db{i}" for i in range(1, 11)] + [f"coif{i}" for i in (2, 4, 6, 8)]
+             + [f"sym{i}" for i in range(4, 11)] + [f"batt{i}" for i in (2, 4, 6)])
+    for nm in names:
+        f = wavelet(getattr(WT, nm))
+        assert f.name == nm
+        assert abs(np.linalg.norm(f.qmf) - 1) < 1e-12
+        assert abs(f.qmf.sum() - np.sqrt(2)) < (1e-3 if nm.startswith("batt") else 1e-8), nm
+    assert len(wavelet(WT.db1)) == 2 and len(wavelet(WT.db10)) == 20 and len(wavelet(WT.batt6)) == 59
+    assert np.allclose(wavelet(WT.db1).qmf, wavelet(WT.haar).qmf)
+
+
+def test_daubechies_values(W):
+    db4 = [0.23037781330889653, 0.7148465705529158, 0.630880767929859, -0.02798376941686001,
+           -0.18703481171909314, 0.03084138183556073, 0.03288301166688519, -0.01059740178506904]
+    db2 = [0.4829629131445342, 0.8365163037378079, 0.2241438680420133, -0.12940952255126045]
+    assert np.abs(W.wavelet(W.WT.db4).qmf - db4).max() < 1e-13
+    assert np.abs(W.wavelet(W.WT.db2).qmf - db2).max() < 1e-13
+
+
+def test_qmf_pairs(W):
+    f = W.wavelet(W.WT.db2)
+    sc, dc = W.WT.makereverseqmfpair(f, True)
+    assert np.array_equal(sc, f.qmf[::-1]) and np.array_equal(dc, f.qmf * [1, -1, 1, -1])
+    sc, dc = W.WT.makereverseqmfpair(f, False)
+    assert np.array_equal(sc, f.qmf) and np.array_equal(dc, (f.qmf * [1, -1, 1, -1])[::-1])
+    s32, _ = W.WT.makereverseqmfpair(f, True, np.float32)
+    assert s32.dtype == np.float32
+
+
+def test_util(W):
+    assert W.maxtransformlevels(1) == 0 and W.maxtransformlevels(40) == 3 and W.maxtransformlevels(2 ** 20) == 20
+    assert W.maxtransformlevels(np.zeros((8, 32))) == 3
+    assert W.sufficientpoweroftwo(24, 3) and not W.sufficientpoweroftwo(24, 4)
+    assert W.detailindex(64, 2, 1) == 17 and W.detailn(64, 2) == 16
+    assert list(W.detailrange(64, 1)) == list(range(33, 65))
+    t = W.maketree(16, 2, "full")
+    assert t.tolist() == [1, 1, 1] + [0] * 12 and W.isvalidtree(np.zeros(16), t)
+    t = W.maketree(16, 3, "dwt")
+    assert np.nonzero(t)[0].tolist() == [0, 1, 3]
+    bad = np.zeros(15, dtype=np.uint8)
+    bad[1] = 1
+    assert not W.isvalidtree(np.zeros(16), bad)
+    assert W.iscube(np.zeros((4, 4, 4))) and not W.iscube(np.zeros((4, 8)))
+
+
+def test_scheme_flatten(W):
+    g = W.wavelet(W.WT.db2, W.WT.Lifting)
+    iu, nc, sh, cf = g.flatten()
+    assert iu.tolist() == [0, 1, 0] and nc.tolist() == [1, 2, 1] and sh.tolist() == [0, 1, -1]
+    assert cf.tolist() == [-1.7320508075688772, -0.0669872981077807, 0.4330127018922193, 1.0]
+
+
+def test_no_cpu_path(W):
+    """The product must fail loudly without a device -- never fall back to the CPU."""
+    import torch
+    x = np.zeros(16, dtype=np.float32)
+    with pytest.raises(TypeError):
+        W.dwt(x, W.wavelet(W.WT.db2))
+    with pytest.raises(W.HIPError):
+        W.dwt(torch.zeros(16), W.wavelet(W.WT.db2))
+    with pytest.raises(W.HIPError):
+        W.dwt_(torch.zeros(16), torch.zeros(16), W.wavelet(W.WT.db2))
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under wavelets.jl_amd/ (nor the C ABI sources) may reference the oracle."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavelets.jl_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"wl_oracle|libwl_oracle|import oracle|from oracle|wlo_", txt), (dp, f)

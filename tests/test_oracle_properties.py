@@ -1,0 +1,171 @@
+"""Properties of the oracle that the reference's own tests assert (test/transforms.jl:57-128,
+266-323, test/util.jl:76-115), plus CPU proofs that the closed forms used by the HIP kernels are
+bit-identical to the literal shift-register loops."""
+import numpy as np
+import pytest
+
+import closed_form as cf
+from conftest import rng_array
+
+DB2 = None
+
+
+def _wts(W):
+    WT = W.WT
+    return WT, W.wavelet
+
+
+@pytest.mark.parametrize("wname", ["db1", "db2"])
+@pytest.mark.parametrize("nd", [1, 2, 3])
+def test_lifting_vs_filter(oracle, W, wname, nd):
+    WT, wavelet = _wts(W)
+    n = 32
+    wf = wavelet(getattr(WT, wname), WT.Filter)
+    wls = wavelet(getattr(WT, wname), WT.Lifting)
+    x = rng_array((n,) * nd, np.float64, 7 + nd)
+    tol = 1e-10 * np.sqrt(x.size)
+    for L in (5, 0, 1, 2):
+        yf = oracle.dwt_filter(x, wf.qmf, L)
+        yls = oracle.dwt_lifting(x, wls, L)
+        assert np.linalg.norm(yf - yls) <= tol * max(1, nd - 1) * 10
+        assert np.linalg.norm(oracle.dwt_filter(yf, wf.qmf, L, fw=False) - x) <= tol * 10
+        assert np.linalg.norm(oracle.dwt_lifting(yls, wls, L, fw=False) - x) <= tol * 10
+
+
+def test_cdf97_known_answer(oracle, W):
+    """cdf9/7 has no golden vector in the reference; pin it on the published CDF 9/7 analysis
+    filters (x sqrt 2): the level-1 response to a unit impulse must be those taps."""
+    WT, wavelet = _wts(W)
+    sch = wavelet(WT.cdf97, WT.Lifting)
+    n = 64
+    lo = np.array([0.0378284555, -0.0238494650, -0.1106244044, 0.3774028556, 0.8526986790,
+                   0.3774028556, -0.1106244044, -0.0238494650, 0.0378284555])
+    hi = np.array([0.0645388826, -0.0406894176, -0.4180922732, 0.7884856164,
+                   -0.4180922732, -0.0406894176, 0.0645388826])
+    # s[k] = sum_i lo[i] x[2k + i - 4], d[k] = sum_i hi[i] x[2k + 1 + i - 3] (centred on x[2k], x[2k+1])
+    x = rng_array((n,), np.float64, 3)
+    y = oracle.dwt_lifting(x, sch, 1)
+    k = np.arange(n // 2)
+    s = sum(lo[i] * x[(2 * k + i - 4) % n] for i in range(9))
+    d = sum(hi[i] * x[(2 * k + 1 + i - 3) % n] for i in range(7))
+    # the reference's sign convention for the detail band may differ from the textbook's
+    assert np.allclose(y[: n // 2], s, atol=2e-9)
+    assert np.allclose(np.abs(y[n // 2:]), np.abs(d), atol=2e-9)
+    assert np.allclose(y[n // 2:], d, atol=2e-9) or np.allclose(y[n // 2:], -d, atol=2e-9)
+    # and perfect reconstruction
+    for L in (1, 3, 6):
+        assert np.linalg.norm(oracle.dwt_lifting(oracle.dwt_lifting(x, sch, L), sch, L, fw=False) - x) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_roundtrip_types(oracle, W, dtype):
+    WT, wavelet = _wts(W)
+    x = rng_array((64, 32), dtype, 11)
+    for wt in (wavelet(WT.db4), wavelet(WT.sym6), wavelet(WT.coif4)):
+        y = oracle.dwt_filter(x, wt.qmf, 3)
+        assert y.dtype == dtype
+        xr = oracle.dwt_filter(y, wt.qmf, 3, fw=False)
+        assert np.linalg.norm(xr - x) / np.linalg.norm(x) < (1e-5 if dtype == np.float32 else 1e-9)
+
+
+def test_error_contract(oracle, W):
+    WT, wavelet = _wts(W)
+    q = wavelet(WT.db2).qmf
+    x = rng_array((24,), np.float64, 1)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.dwt_filter(x, q, 4)            # 24 % 16 != 0
+    assert e.value.rc == -1
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.dwt_filter(x, q, -1)
+    assert e.value.rc == -2
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.dwt_lifting(rng_array((8, 16), np.float64, 1), wavelet(WT.db2, WT.Lifting), 1)
+    assert e.value.rc == -5
+    assert np.array_equal(oracle.dwt_filter(x, q, 0), x)
+    assert oracle.maxtransformlevels(40) == 3 and oracle.maxtransformlevels(1) == 0
+
+
+def test_split_merge(oracle):
+    for n in (2, 4, 6, 8, 10, 16, 64):
+        a = np.arange(1, n + 1, dtype=np.float64)
+        s = oracle.split(a.copy())
+        assert np.array_equal(s[: n // 2], a[0::2]) and np.array_equal(s[n // 2:], a[1::2])
+        assert np.array_equal(oracle.merge(s.copy()), a)
+
+
+def test_wpt_vs_dwt(oracle, W):
+    """test/transforms.jl:266-323: a :dwt tree equals dwt; full tree of depth 2 equals composed dwts;
+    non-dyadic length."""
+    WT, wavelet = _wts(W)
+    wf = wavelet(WT.db2)
+    wl = wavelet(WT.db2, WT.Lifting)
+    for n in (32, 40):
+        x = rng_array((n,), np.float64, n)
+        Lmax = W.maxtransformlevels(n)
+        for L in range(0, Lmax + 1):
+            t = W.maketree(n, L, "dwt")
+            assert np.allclose(oracle.wpt_filter(x, wf.qmf, t), oracle.dwt_filter(x, wf.qmf, L), atol=1e-12)
+            assert np.allclose(oracle.wpt_lifting(x, wl, t), oracle.dwt_lifting(x, wl, L), atol=1e-12)
+        t = W.maketree(n, 2, "full")
+        y = oracle.wpt_filter(x, wf.qmf, t)
+        y1 = oracle.dwt_filter(x, wf.qmf, 1)
+        e = np.concatenate([oracle.dwt_filter(y1[: n // 2], wf.qmf, 1), oracle.dwt_filter(y1[n // 2:], wf.qmf, 1)])
+        assert np.allclose(y, e, atol=1e-12)
+        assert np.allclose(oracle.wpt_filter(y, wf.qmf, t, fw=False), x, atol=1e-10)
+        yl = oracle.wpt_lifting(x, wl, t)
+        assert np.allclose(oracle.wpt_lifting(yl, wl, t, fw=False), x, atol=1e-10)
+    bad = W.maketree(32, 2, "full")
+    bad[0] = 0
+    with pytest.raises(oracle.OracleError):
+        oracle.wpt_filter(rng_array((32,), np.float64, 1), wf.qmf, bad)
+
+
+def test_dwtc_is_columnwise(oracle, W):
+    WT, wavelet = _wts(W)
+    x = rng_array((64, 5), np.float32, 5)
+    wf = wavelet(WT.db4)
+    y = oracle.dwtc_filter(x, wf.qmf, 3)
+    for j in range(5):
+        assert np.array_equal(y[:, j], oracle.dwt_filter(np.ascontiguousarray(x[:, j]), wf.qmf, 3))
+    sch = wavelet(WT.cdf97, WT.Lifting)
+    yl = oracle.dwtc_lifting(x, sch, 4)
+    for j in range(5):
+        assert np.array_equal(yl[:, j], oracle.dwt_lifting(np.ascontiguousarray(x[:, j]), sch, 4))
+
+
+# ---- closed forms == literal loops, bit for bit ----------------------------------------------------
+FILTS = ["haar", "db2", "db3", "db4", "db7", "db10", "sym5", "coif4", "batt2", "batt4", "batt6", "beyl", "vaid"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fname", FILTS)
+def test_closed_form_filter_bitexact(oracle, W, dtype, fname):
+    WT, wavelet = _wts(W)
+    wt = wavelet(getattr(WT, fname) if hasattr(WT, fname) else None)
+    for n in (2, 4, 8, 16, 64, 96, 40):
+        x = rng_array((n,), dtype, n + len(wt))
+        Lmax = W.maxtransformlevels(n)
+        for L in sorted({1, Lmax}):
+            y_o = oracle.dwt_filter(x, wt.qmf, L)
+            y_c = cf.dwt1d(x, wt.qmf, L)
+            assert np.array_equal(y_o, y_c), (fname, n, L, np.abs(y_o - y_c).max())
+            xr_o = oracle.dwt_filter(y_o, wt.qmf, L, fw=False)
+            xr_c = cf.dwt1d(y_o, wt.qmf, L, fw=False)
+            assert np.array_equal(xr_o, xr_c), (fname, n, L, "inverse", np.abs(xr_o - xr_c).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_closed_form_lift_bitexact(oracle, W, dtype):
+    WT, wavelet = _wts(W)
+    for sname in ("cdf97", "db2", "haar", "db1"):
+        sch = wavelet(getattr(WT, sname), WT.Lifting)
+        for half in (1, 2, 3, 4, 8, 32, 20):
+            for st in sch.step:
+                for sign in (-1.0, 1.0):
+                    c = (st.param.coef * sign).astype(dtype)
+                    w = rng_array((2 * half,), dtype, half * 7 + len(c))
+                    w_o = w.copy()
+                    is_upd = isinstance(st.steptype, WT.UpdateStep)
+                    oracle.lift(w_o, half, is_upd, st.param.shift, c)
+                    w_c = cf.lift_step(w.copy(), half, is_upd, st.param.shift, c)
+                    assert np.array_equal(w_o, w_c), (sname, half, st, np.abs(w_o - w_c).max())

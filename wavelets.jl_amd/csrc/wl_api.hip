@@ -568,3 +568,130 @@ int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y, int64_t len, int64_t nsigna
 }
 
 }  // extern "C"
+
+// ---- wavelet packet transforms (1-D) -------------------------------------------------------------
+// The reference walks the tree one depth at a time (transforms_filter.jl:325-356,
+// transforms_lifting.jl:297-316): at depth d the vector is 2^d segments of length n/2^d, and
+// every segment whose node bit is set gets one [s ; d] level.  Here one depth = one launch over
+// the box (n/2^d, 2^d) with the node bits as a per-segment mask (unset segments are copied
+// through), ping-ponging between y and a work buffer so that the last launch lands in y.
+static bool isvalidtree(int64_t n, const uint8_t *b, int64_t nb)
+{
+    int ns = wl_maxtransformlevels(n);
+    if (nb != ((int64_t)1 << ns) - 1) return false;
+    if (ns == 0) return true;
+    for (int64_t i = 1; i <= ((int64_t)1 << (ns - 1)) - 1; ++i)
+        if (!b[i - 1] && (b[(i << 1) - 1] || b[i << 1])) return false;
+    return true;
+}
+
+template <typename T>
+static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
+                    const Taps<T> *taps, const LiftScheme<T> *sc,
+                    const uint8_t *tree, int64_t ntree, int fw)
+{
+    const bool lifting = (sc != nullptr);
+    Extent3 full = {{n, 1, 1}};
+    Strides3 fst = {{1, n, n}};
+    if (ntree == 0 || !tree[0]) {
+        if (y != x) WL_HIP(ctx, generic_copy_box<T>(st, x, fst, y, fst, full));
+        ctx->last_kernel = "copy";
+        return WL_OK;
+    }
+    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)ntree + 256);
+    if (rc) return rc;
+    Work<T> w = carve<T>(ctx->ws, n);
+    uint8_t *dtree = (uint8_t *)ctx->ws + ws_elems(n) * sizeof(T);
+    WL_HIP(ctx, hipMemcpyAsync(dtree, tree, (size_t)ntree, hipMemcpyHostToDevice, st));
+
+    const int Lmax = wl_maxtransformlevels(n);
+    // depths in processing order, skipping depths where no node is set (pure copy-through)
+    std::vector<int> depths;
+    for (int L = Lmax; L > 0; --L) {
+        int d = fw ? Lmax - L : L - 1;
+        int64_t first = ((int64_t)1 << d) - 1, cnt = (int64_t)1 << d;
+        bool any = false;
+        for (int64_t k = 0; k < cnt && !any; ++k) any = tree[first + k] != 0;
+        if (any) depths.push_back(d);
+    }
+    const int K = (int)depths.size();
+    const T *cur = x;
+    for (int i = 0; i < K; ++i) {
+        const int d = depths[i];
+        const int64_t nj = n >> d, nseg = (int64_t)1 << d;
+        Extent3 ext = {{nj, nseg, 1}};
+        Strides3 bst = {{1, nj, n}};
+        Extent3 lo = {{nj >> 1, nseg, 1}};
+        const uint8_t *mask = dtree + (((int64_t)1 << d) - 1);
+        if (lifting) {
+            // reads of `cur` all happen in the first kernel, so in-place (cur == y) is safe
+            if (fw) {
+                WL_HIP(ctx, generic_lift_split<T>(st, cur, bst, w.W, bst, ext, 0, mask));
+                for (int s = 0; s < sc->nsteps; ++s)
+                    WL_HIP(ctx, generic_lift_step<T>(st, sc->step[s], w.W, bst, ext, 0, mask));
+                WL_HIP(ctx, generic_lift_finish_fwd<T>(st, sc->norm1, sc->norm2, w.W, bst, y, bst, (T *)nullptr, bst, ext, 0, lo, mask));
+            } else {
+                WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc->norm1, sc->norm2, cur, bst, (const T *)nullptr, bst, w.W, bst, ext, 0, lo, mask));
+                for (int s = 0; s < sc->nsteps; ++s)
+                    WL_HIP(ctx, generic_lift_step<T>(st, sc->step[s], w.W, bst, ext, 0, mask));
+                WL_HIP(ctx, generic_lift_merge<T>(st, w.W, bst, y, bst, ext, 0, mask));
+            }
+            cur = y;
+        } else {
+            T *out = ((K - 1 - i) % 2 == 0) ? y : w.T0;
+            if (fw)
+                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, *taps, cur, bst, out, bst, (T *)nullptr, bst, ext, 0, lo, mask));
+            else
+                WL_HIP(ctx, generic_inv_filter_pass<T>(st, *taps, cur, bst, (const T *)nullptr, bst, out, bst, ext, 0, lo, mask));
+            cur = out;
+        }
+    }
+    ctx->last_kernel = lifting ? "k_generic_lift_wpt" : "k_generic_filter_wpt";
+    return WL_OK;
+}
+
+extern "C" {
+
+int wl_wpt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n, const double *qmf, int flen,
+                  const uint8_t *tree, int64_t ntree, int fw, void *stream)
+{
+    if (!ctx || !y || !x || !qmf || (!tree && ntree > 0)) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (n < 1) return WL_EDIMS;
+    if (y == x) return WL_EALIAS;
+    if (!isvalidtree(n, tree, ntree)) return WL_EINVAL_TREE;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == WL_F32) {
+        Taps<float> t; make_taps<float>(qmf, flen, t);
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)x, n, &t, nullptr, tree, ntree, fw);
+    }
+    Taps<double> t; make_taps<double>(qmf, flen, t);
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)x, n, &t, nullptr, tree, ntree, fw);
+}
+
+int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
+                   int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                   const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                   const uint8_t *tree, int64_t ntree, int fw, void *stream)
+{
+    if (!ctx || !y || (!tree && ntree > 0)) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (n < 1) return WL_EDIMS;
+    if (!isvalidtree(n, tree, ntree)) return WL_EINVAL_TREE;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == WL_F32) {
+        LiftScheme<float> sc;
+        int rc = make_scheme<float>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
+        if (rc) return rc;
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)y, n, nullptr, &sc, tree, ntree, fw);
+    }
+    LiftScheme<double> sc;
+    int rc = make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
+    if (rc) return rc;
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, tree, ntree, fw);
+}
+
+}  // extern "C"

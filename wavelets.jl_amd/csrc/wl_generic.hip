@@ -47,7 +47,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_generic_fwd_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
                      T *__restrict__ dst, Strides3 dst_st, T *__restrict__ ll, Strides3 ll_st,
-                     Extent3 n, int axis, Extent3 lo)
+                     Extent3 n, int axis, Extent3 lo, const uint8_t *__restrict__ mask)
 {
     const int F = taps.F;
     const int64_t nax = n.n[axis], nx = nax >> 1, sa = sst.s[axis];
@@ -62,6 +62,14 @@ k_generic_fwd_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
         for (int d = 0; d < 3; ++d)
             if (d != axis) base += c.i[d] * sst.s[d];
         const T *p = src + base;
+        if (mask != nullptr && !mask[c.i[1]]) {      // WPT: node not split -> copy the segment through
+            int64_t o0 = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) o0 += (d == axis ? 0 : c.i[d]) * dst_st.s[d];
+            dst[o0 + (2 * k) * dst_st.s[axis]] = p[(2 * k) * sa];
+            dst[o0 + (2 * k + 1) * dst_st.s[axis]] = p[(2 * k + 1) * sa];
+            continue;
+        }
         // scaling branch: m ascending
         T s = taps.h[0] * p[pmod(2 * k, nax) * sa];
         for (int m = 1; m < F; ++m) s = s + taps.h[m] * p[pmod(2 * k + m, nax) * sa];
@@ -91,7 +99,8 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_generic_inv_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
                      const T *__restrict__ ll, Strides3 ll_st,
-                     T *__restrict__ dst, Strides3 dst_st, Extent3 n, int axis, Extent3 lo)
+                     T *__restrict__ dst, Strides3 dst_st, Extent3 n, int axis, Extent3 lo,
+                     const uint8_t *__restrict__ mask)
 {
     const int F = taps.F;
     const int64_t nax = n.n[axis], nx = nax >> 1;
@@ -103,6 +112,13 @@ k_generic_inv_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             if (d != axis) { base += c.i[d] * sst.s[d]; lbase += c.i[d] * ll_st.s[d]; }
+        if (mask != nullptr && !mask[c.i[1]]) {
+            int64_t off = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) off += c.i[d] * dst_st.s[d];
+            dst[off] = src[base + o * sst.s[axis]];
+            continue;
+        }
         const bool use_ll = (ll != nullptr) && in_low_corner(c, axis, lo);
         const T *ps = use_ll ? (ll + lbase) : (src + base);
         const int64_t ss = use_ll ? ll_st.s[axis] : sst.s[axis];
@@ -140,7 +156,8 @@ k_generic_inv_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
 // split: Util.split! (util_main.jl:142-204): w[k] = src[2k], w[nx+k] = src[2k+1] along axis
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_generic_lift_split(const T *__restrict__ src, Strides3 sst, T *__restrict__ w, Strides3 wst, Extent3 n, int axis)
+k_generic_lift_split(const T *__restrict__ src, Strides3 sst, T *__restrict__ w, Strides3 wst, Extent3 n, int axis,
+                     const uint8_t *__restrict__ mask)
 {
     const int64_t nx = n.n[axis] >> 1;
     int64_t e[3] = {n.n[0], n.n[1], n.n[2]};
@@ -153,6 +170,11 @@ k_generic_lift_split(const T *__restrict__ src, Strides3 sst, T *__restrict__ w,
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             if (d != axis) { sb += c.i[d] * sst.s[d]; wb += c.i[d] * wst.s[d]; }
+        if (mask != nullptr && !mask[c.i[1]]) {      // copy through in natural order
+            w[wb + (2 * k) * wst.s[axis]] = src[sb + (2 * k) * sst.s[axis]];
+            w[wb + (2 * k + 1) * wst.s[axis]] = src[sb + (2 * k + 1) * sst.s[axis]];
+            continue;
+        }
         w[wb + k * wst.s[axis]] = src[sb + (2 * k) * sst.s[axis]];
         w[wb + (nx + k) * wst.s[axis]] = src[sb + (2 * k + 1) * sst.s[axis]];
     }
@@ -165,7 +187,8 @@ k_generic_lift_split(const T *__restrict__ src, Strides3 sst, T *__restrict__ w,
 //   in bounds: x += (c1*a + c2*b [+ c3*c]);   boundary: x += c1*a; x += c2*b; ...
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_generic_lift_step(LiftStep<T> st, T *__restrict__ w, Strides3 wst, Extent3 n, int axis)
+k_generic_lift_step(LiftStep<T> st, T *__restrict__ w, Strides3 wst, Extent3 n, int axis,
+                    const uint8_t *__restrict__ mask)
 {
     const int64_t half = n.n[axis] >> 1;
     int64_t e[3] = {n.n[0], n.n[1], n.n[2]};
@@ -175,6 +198,7 @@ k_generic_lift_step(LiftStep<T> st, T *__restrict__ w, Strides3 wst, Extent3 n, 
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         Idx3 c = unflatten(t, e[0], e[1]);
         const int64_t j = c.i[axis];
+        if (mask != nullptr && !mask[c.i[1]]) continue;
         int64_t wb = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -202,7 +226,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_generic_lift_finish_fwd(T n1, T n2, const T *__restrict__ w, Strides3 wst,
                           T *__restrict__ dst, Strides3 dst_st, T *__restrict__ ll, Strides3 ll_st,
-                          Extent3 n, int axis, Extent3 lo)
+                          Extent3 n, int axis, Extent3 lo, const uint8_t *__restrict__ mask)
 {
     const int64_t nx = n.n[axis] >> 1;
     int64_t e[3] = {n.n[0], n.n[1], n.n[2]};
@@ -215,6 +239,14 @@ k_generic_lift_finish_fwd(T n1, T n2, const T *__restrict__ w, Strides3 wst,
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             if (d != axis) wb += c.i[d] * wst.s[d];
+        if (mask != nullptr && !mask[c.i[1]]) {
+            int64_t o0 = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) o0 += (d == axis ? 0 : c.i[d]) * dst_st.s[d];
+            dst[o0 + (2 * k) * dst_st.s[axis]] = w[wb + (2 * k) * wst.s[axis]];
+            dst[o0 + (2 * k + 1) * dst_st.s[axis]] = w[wb + (2 * k + 1) * wst.s[axis]];
+            continue;
+        }
         T s = w[wb + k * wst.s[axis]] * n1;
         T dd = w[wb + (nx + k) * wst.s[axis]] * n2;
         if (ll != nullptr && in_low_corner(c, axis, lo)) {
@@ -240,7 +272,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_generic_lift_norm_inv(T n1, T n2, const T *__restrict__ src, Strides3 sst,
                         const T *__restrict__ ll, Strides3 ll_st, T *__restrict__ w, Strides3 wst,
-                        Extent3 n, int axis, Extent3 lo)
+                        Extent3 n, int axis, Extent3 lo, const uint8_t *__restrict__ mask)
 {
     const int64_t nx = n.n[axis] >> 1;
     int64_t e[3] = {n.n[0], n.n[1], n.n[2]};
@@ -253,6 +285,11 @@ k_generic_lift_norm_inv(T n1, T n2, const T *__restrict__ src, Strides3 sst,
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             if (d != axis) { sb += c.i[d] * sst.s[d]; lb += c.i[d] * ll_st.s[d]; wb += c.i[d] * wst.s[d]; }
+        if (mask != nullptr && !mask[c.i[1]]) {
+            w[wb + (2 * k) * wst.s[axis]] = src[sb + (2 * k) * sst.s[axis]];
+            w[wb + (2 * k + 1) * wst.s[axis]] = src[sb + (2 * k + 1) * sst.s[axis]];
+            continue;
+        }
         const bool use_ll = (ll != nullptr) && in_low_corner(c, axis, lo);
         T s = use_ll ? ll[lb + k * ll_st.s[axis]] : src[sb + k * sst.s[axis]];
         T dd = src[sb + (nx + k) * sst.s[axis]];
@@ -264,7 +301,8 @@ k_generic_lift_norm_inv(T n1, T n2, const T *__restrict__ src, Strides3 sst,
 // merge: Util.merge! (util_main.jl:216-278): dst[2k] = w[k], dst[2k+1] = w[nx+k]
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_generic_lift_merge(const T *__restrict__ w, Strides3 wst, T *__restrict__ dst, Strides3 dst_st, Extent3 n, int axis)
+k_generic_lift_merge(const T *__restrict__ w, Strides3 wst, T *__restrict__ dst, Strides3 dst_st, Extent3 n, int axis,
+                     const uint8_t *__restrict__ mask)
 {
     const int64_t nx = n.n[axis] >> 1;
     int64_t e[3] = {n.n[0], n.n[1], n.n[2]};
@@ -277,6 +315,11 @@ k_generic_lift_merge(const T *__restrict__ w, Strides3 wst, T *__restrict__ dst,
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             if (d != axis) { db += c.i[d] * dst_st.s[d]; wb += c.i[d] * wst.s[d]; }
+        if (mask != nullptr && !mask[c.i[1]]) {
+            dst[db + (2 * k) * dst_st.s[axis]] = w[wb + (2 * k) * wst.s[axis]];
+            dst[db + (2 * k + 1) * dst_st.s[axis]] = w[wb + (2 * k + 1) * wst.s[axis]];
+            continue;
+        }
         dst[db + (2 * k) * dst_st.s[axis]] = w[wb + k * wst.s[axis]];
         dst[db + (2 * k + 1) * dst_st.s[axis]] = w[wb + (nx + k) * wst.s[axis]];
     }
@@ -301,60 +344,63 @@ k_generic_copy_box(const T *__restrict__ src, Strides3 sst, T *__restrict__ dst,
 template <typename T>
 hipError_t generic_fwd_filter_pass(hipStream_t st, const Taps<T> &taps, const T *src, Strides3 sst,
                                    T *dst, Strides3 dst_st, T *ll, Strides3 ll_st,
-                                   Extent3 n, int axis, Extent3 lo)
+                                   Extent3 n, int axis, Extent3 lo, const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
     hipLaunchKernelGGL(k_generic_fwd_filter<T>, grid_for(total), dim3(kBlock), 0, st,
-                       taps, src, sst, dst, dst_st, ll, ll_st, n, axis, lo);
+                       taps, src, sst, dst, dst_st, ll, ll_st, n, axis, lo, mask);
     return hipGetLastError();
 }
 template <typename T>
 hipError_t generic_inv_filter_pass(hipStream_t st, const Taps<T> &taps, const T *src, Strides3 sst,
                                    const T *ll, Strides3 ll_st, T *dst, Strides3 dst_st,
-                                   Extent3 n, int axis, Extent3 lo)
+                                   Extent3 n, int axis, Extent3 lo, const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2];
     hipLaunchKernelGGL(k_generic_inv_filter<T>, grid_for(total), dim3(kBlock), 0, st,
-                       taps, src, sst, ll, ll_st, dst, dst_st, n, axis, lo);
+                       taps, src, sst, ll, ll_st, dst, dst_st, n, axis, lo, mask);
     return hipGetLastError();
 }
 template <typename T>
-hipError_t generic_lift_split(hipStream_t st, const T *src, Strides3 sst, T *w, Strides3 wst, Extent3 n, int axis)
+hipError_t generic_lift_split(hipStream_t st, const T *src, Strides3 sst, T *w, Strides3 wst, Extent3 n, int axis,
+                              const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
-    hipLaunchKernelGGL(k_generic_lift_split<T>, grid_for(total), dim3(kBlock), 0, st, src, sst, w, wst, n, axis);
+    hipLaunchKernelGGL(k_generic_lift_split<T>, grid_for(total), dim3(kBlock), 0, st, src, sst, w, wst, n, axis, mask);
     return hipGetLastError();
 }
 template <typename T>
-hipError_t generic_lift_step(hipStream_t st, const LiftStep<T> &step, T *w, Strides3 wst, Extent3 n, int axis)
+hipError_t generic_lift_step(hipStream_t st, const LiftStep<T> &step, T *w, Strides3 wst, Extent3 n, int axis,
+                             const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
-    hipLaunchKernelGGL(k_generic_lift_step<T>, grid_for(total), dim3(kBlock), 0, st, step, w, wst, n, axis);
+    hipLaunchKernelGGL(k_generic_lift_step<T>, grid_for(total), dim3(kBlock), 0, st, step, w, wst, n, axis, mask);
     return hipGetLastError();
 }
 template <typename T>
 hipError_t generic_lift_finish_fwd(hipStream_t st, T n1, T n2, const T *w, Strides3 wst, T *dst, Strides3 dst_st,
-                                   T *ll, Strides3 ll_st, Extent3 n, int axis, Extent3 lo)
+                                   T *ll, Strides3 ll_st, Extent3 n, int axis, Extent3 lo, const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
     hipLaunchKernelGGL(k_generic_lift_finish_fwd<T>, grid_for(total), dim3(kBlock), 0, st,
-                       n1, n2, w, wst, dst, dst_st, ll, ll_st, n, axis, lo);
+                       n1, n2, w, wst, dst, dst_st, ll, ll_st, n, axis, lo, mask);
     return hipGetLastError();
 }
 template <typename T>
 hipError_t generic_lift_norm_inv(hipStream_t st, T n1, T n2, const T *src, Strides3 sst, const T *ll, Strides3 ll_st,
-                                 T *w, Strides3 wst, Extent3 n, int axis, Extent3 lo)
+                                 T *w, Strides3 wst, Extent3 n, int axis, Extent3 lo, const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
     hipLaunchKernelGGL(k_generic_lift_norm_inv<T>, grid_for(total), dim3(kBlock), 0, st,
-                       n1, n2, src, sst, ll, ll_st, w, wst, n, axis, lo);
+                       n1, n2, src, sst, ll, ll_st, w, wst, n, axis, lo, mask);
     return hipGetLastError();
 }
 template <typename T>
-hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, Strides3 dst_st, Extent3 n, int axis)
+hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, Strides3 dst_st, Extent3 n, int axis,
+                              const uint8_t *mask)
 {
     int64_t total = n.n[0] * n.n[1] * n.n[2] / 2;
-    hipLaunchKernelGGL(k_generic_lift_merge<T>, grid_for(total), dim3(kBlock), 0, st, w, wst, dst, dst_st, n, axis);
+    hipLaunchKernelGGL(k_generic_lift_merge<T>, grid_for(total), dim3(kBlock), 0, st, w, wst, dst, dst_st, n, axis, mask);
     return hipGetLastError();
 }
 template <typename T>
@@ -367,16 +413,19 @@ hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, 
 
 #define WL_INSTANTIATE(T)                                                                                              \
     template hipError_t generic_fwd_filter_pass<T>(hipStream_t, const Taps<T> &, const T *, Strides3, T *, Strides3,  \
-                                                   T *, Strides3, Extent3, int, Extent3);                              \
+                                                   T *, Strides3, Extent3, int, Extent3, const uint8_t *);             \
     template hipError_t generic_inv_filter_pass<T>(hipStream_t, const Taps<T> &, const T *, Strides3, const T *,       \
-                                                   Strides3, T *, Strides3, Extent3, int, Extent3);                    \
-    template hipError_t generic_lift_split<T>(hipStream_t, const T *, Strides3, T *, Strides3, Extent3, int);          \
-    template hipError_t generic_lift_step<T>(hipStream_t, const LiftStep<T> &, T *, Strides3, Extent3, int);           \
+                                                   Strides3, T *, Strides3, Extent3, int, Extent3, const uint8_t *);   \
+    template hipError_t generic_lift_split<T>(hipStream_t, const T *, Strides3, T *, Strides3, Extent3, int,           \
+                                              const uint8_t *);                                                        \
+    template hipError_t generic_lift_step<T>(hipStream_t, const LiftStep<T> &, T *, Strides3, Extent3, int,            \
+                                             const uint8_t *);                                                         \
     template hipError_t generic_lift_finish_fwd<T>(hipStream_t, T, T, const T *, Strides3, T *, Strides3, T *,         \
-                                                   Strides3, Extent3, int, Extent3);                                   \
+                                                   Strides3, Extent3, int, Extent3, const uint8_t *);                  \
     template hipError_t generic_lift_norm_inv<T>(hipStream_t, T, T, const T *, Strides3, const T *, Strides3, T *,     \
-                                                 Strides3, Extent3, int, Extent3);                                     \
-    template hipError_t generic_lift_merge<T>(hipStream_t, const T *, Strides3, T *, Strides3, Extent3, int);          \
+                                                 Strides3, Extent3, int, Extent3, const uint8_t *);                    \
+    template hipError_t generic_lift_merge<T>(hipStream_t, const T *, Strides3, T *, Strides3, Extent3, int,           \
+                                              const uint8_t *);                                                        \
     template hipError_t generic_copy_box<T>(hipStream_t, const T *, Strides3, T *, Strides3, Extent3);
 WL_INSTANTIATE(float)
 WL_INSTANTIATE(double)

@@ -51,31 +51,31 @@ hipError_t generic_fwd_filter_pass(hipStream_t st, const Taps<T> &taps,
                                    const T *src, Strides3 sst,
                                    T *dst, Strides3 dst_st,
                                    T *ll, Strides3 ll_st,
-                                   Extent3 n, int axis, Extent3 lo);
+                                   Extent3 n, int axis, Extent3 lo, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_inv_filter_pass(hipStream_t st, const Taps<T> &taps,
                                    const T *src, Strides3 sst,
                                    const T *ll, Strides3 ll_st,
                                    T *dst, Strides3 dst_st,
-                                   Extent3 n, int axis, Extent3 lo);
+                                   Extent3 n, int axis, Extent3 lo, const uint8_t *mask = nullptr);
 // lifting building blocks (box n, [s;d] layout along `axis` in the dense work buffer w)
 template <typename T>
 hipError_t generic_lift_split(hipStream_t st, const T *src, Strides3 sst, T *w, Strides3 wst,
-                              Extent3 n, int axis);
+                              Extent3 n, int axis, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_lift_step(hipStream_t st, const LiftStep<T> &step, T *w, Strides3 wst,
-                             Extent3 n, int axis);
+                             Extent3 n, int axis, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_lift_finish_fwd(hipStream_t st, T n1, T n2, const T *w, Strides3 wst,
                                    T *dst, Strides3 dst_st, T *ll, Strides3 ll_st,
-                                   Extent3 n, int axis, Extent3 lo);
+                                   Extent3 n, int axis, Extent3 lo, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_lift_norm_inv(hipStream_t st, T n1, T n2, const T *src, Strides3 sst,
                                  const T *ll, Strides3 ll_st, T *w, Strides3 wst,
-                                 Extent3 n, int axis, Extent3 lo);
+                                 Extent3 n, int axis, Extent3 lo, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, Strides3 dst_st,
-                              Extent3 n, int axis);
+                              Extent3 n, int axis, const uint8_t *mask = nullptr);
 template <typename T>
 hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, Strides3 dst_st, Extent3 n);
 

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X DWT backend (driver contract: one JSON line).
+
+A "step" is one full forward transform of one synthetic array already resident in HBM:
+    default workload  C3 = 2-D dwt, WT.db4 filter bank, 8192 x 8192 Float32, L = 13 (API default)
+                      (BASELINE.json configs[2], the configuration the metric is quoted on)
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank transforms
+its own independent 8192 x 8192 array (a batch of N images sharded one per GPU: weak scaling, no
+data-path collective; the filter taps are broadcast from rank 0 over RCCL/xGMI before the timed
+region, as north_star prescribes).  value = whole-job Msamples/s = N * samples / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the level-1 launch of k_fwd2d_stream, which moves 8 B/sample):
+                algorithmic bytes / average launch duration measured with HIP events on the launch
+                stream around single-launch (L = 1) calls; peak = 8000 GB/s (MI355X HBM3E spec)
+  cpu_baseline  the oracle (literal C restatement of the reference's loops, 1 thread -- the
+                reference has no threading) timed on this host on a bounded sample
+
+Other workloads (parity-test configs, not the headline): --workload c1|c2|c4|c5.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--levels", type=int, default=None, help="override L (default: maxtransformlevels)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--path", type=int, default=0, help="0 fast kernels, 1 generic kernels only")
+    return ap.parse_args()
+
+
+def make_workload(W, name, device, seed):
+    """returns (label, x (device tensor), wt, default L, sample count, call(x) -> y, dtype tag)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    WT = W.WT
+    if name == "c3":
+        x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t()
+        return "2-D dwt db4 filter 8192x8192 f32", x, W.wavelet(WT.db4), W.maxtransformlevels(x), "f32"
+    if name == "c2":
+        x = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
+        return "1-D dwt db4 filter 2^24 f32", x, W.wavelet(WT.db4), 24, "f32"
+    if name == "c4":
+        x = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
+        return "1-D dwt cdf9/7 lifting 2^24 f32", x, W.wavelet(WT.cdf97, WT.Lifting), 24, "f32"
+    if name == "c1":
+        x = torch.rand(1 << 20, generator=g, dtype=torch.float64).to(device)
+        return "1-D dwt db2 filter 2^20 f64", x, W.wavelet(WT.db2), 20, "f64"
+    if name == "c5":
+        # per-GPU shard of the 65536 x 2^16 batch on 8 GPUs: 8192 signals of length 2^16
+        x = torch.randn(8192, 1 << 16, generator=g, dtype=torch.float32).to(device).t()
+        return "batched column-wise dwt db4, 8192 signals x 2^16 f32 per GPU", x, W.wavelet(WT.db4), 16, "f32"
+    raise ValueError(name)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
+    import wavelets_jl_amd as W
+    from wavelets_jl_amd import sharding
+    W._lib.load()
+    W.set_kernel_path(args.path)
+
+    label, x, wt, Ldef, dtag = make_workload(W, args.workload, device, 42 + 1000 * rank)
+    L = Ldef if args.levels is None else args.levels
+    # filter taps / scheme coefficients travel from rank 0 over RCCL (xGMI): the only collective
+    wt = sharding.broadcast_wavelet(wt, dist, device)
+    batched = args.workload == "c5"
+    fn = (lambda t: W.dwtc(t, wt, L)) if batched else (lambda t: W.dwt(t, wt, L))
+    W.reserve_workspace(x, L)
+    nsamples = x.numel()
+
+    for _ in range(args.warmup):
+        y = fn(x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = fn(x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt, dist, device)
+    kernel = W.last_kernel()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * nsamples / (dt / args.steps) / 1e6          # whole-job Msamples/s
+    esize = x.element_size()
+    gbps = 2 * esize * value * 1e6 / 1e9                        # algorithmic bytes: 2*N*sizeof(T) per call
+
+    # device-only time of one step (HIP events on the launch stream), for reference
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(args.steps):
+        y = fn(x)
+    ev1.record()
+    torch.cuda.synchronize()
+    dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+
+    out = {
+        "metric": "Msamples/s, 2-D db4 dwt 8192x8192 f32" if args.workload == "c3" else "Msamples/s, " + label,
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtag, "data": "synthetic (standard normal, seed 42 + 1000*rank), resident in HBM",
+        "config": {"workload": label, "L": int(L), "arrays": world, "parallelism": f"{world} independent arrays, one per GPU",
+                   "kernel": kernel, "kernel_path": "generic" if args.path else "fast"},
+        "achieved_hbm_GBps_algorithmic": round(gbps, 1),
+        "device_ms_per_step": round(dev_ms_per_step, 5),
+    }
+
+    if rank == 0:
+        out["roofline"] = roofline_leg(W, x, wt, batched, esize, args)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline_leg(W, args.workload, wt, L)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_leg(W, x, wt, batched, esize, args):
+    """Dominant kernel = the level-1 launch (it alone moves 2*N*sizeof(T) bytes = the whole
+    algorithmic traffic; deeper levels add 1/3 (2-D) or 1x (1-D) on top in total).  A call with
+    L = 1 is exactly one launch of that kernel, so HIP events around back-to-back L = 1 calls on
+    the launch stream give its average duration."""
+    fn1 = (lambda t: W.dwtc(t, wt, 1)) if batched else (lambda t: W.dwt(t, wt, 1))
+    for _ in range(3):
+        fn1(x)
+    torch.cuda.synchronize()
+    reps = max(20, args.steps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn1(x)
+        b.record()
+    torch.cuda.synchronize()
+    durs = sorted(a.elapsed_time(b) for a, b in evs)
+    avg_ms = sum(durs) / len(durs)
+    alg_bytes = 2 * x.numel() * esize
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    note = "traffic: no PMC summary committed yet"
+    if os.path.exists(pmc):
+        try:
+            j = json.load(open(pmc))
+            traffic = j.get("hbm_bytes_per_launch")
+            note = j.get("note", "")
+        except Exception:
+            pass
+    return {"bound": "hbm", "kernel": W.last_kernel() + " (level 1)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
+            "median_launch_ms": round(durs[len(durs) // 2], 5), "min_launch_ms": round(durs[0], 5),
+            "launches_timed": reps, "traffic_note": note,
+            "frac_of_measured_copy_6290GBps": round(achieved / 6290.0, 4)}
+
+
+def cpu_baseline_leg(W, workload, wt, L):
+    """The oracle (kind 'port': literal C restatement of the reference's single-threaded loops)
+    on this host's cores, on a bounded sample (about 10-30 s of CPU work)."""
+    import oracle                      # the checker / baseline -- never the product path
+    oracle.build()
+    rng = np.random.default_rng(42)
+    if workload == "c3":
+        # the full 8192 x 8192 f32 array once (67.1 Msamples; about 5-20 s on one core)
+        n = 8192
+        xs = rng.standard_normal((n, n), dtype=np.float32)
+        t0 = time.perf_counter()
+        oracle.dwt_filter(xs, wt.qmf, L)
+        dt = time.perf_counter() - t0
+        sample = f"one full 2-D db4 dwt of the {n}x{n} f32 array, L={L}, 1 thread (the reference has no threading)"
+        ns = xs.size
+    elif workload in ("c1", "c2"):
+        n = (1 << 20) if workload == "c1" else (1 << 24)
+        xs = rng.standard_normal(n).astype(np.float64 if workload == "c1" else np.float32)
+        reps = 8 if workload == "c1" else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.dwt_filter(xs, wt.qmf, L)
+        dt = (time.perf_counter() - t0) / reps
+        sample = f"{reps} full-size 1-D transforms, 1 thread"
+        ns = n
+    elif workload == "c4":
+        xs = rng.standard_normal(1 << 24).astype(np.float32)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            oracle.dwt_lifting(xs, wt, L)
+        dt = (time.perf_counter() - t0) / 3
+        sample = "3 full-size 1-D cdf9/7 lifting transforms, 1 thread"
+        ns = xs.size
+    else:
+        xs = rng.standard_normal((1 << 16, 128)).astype(np.float32)
+        t0 = time.perf_counter()
+        oracle.dwtc_filter(xs, wt.qmf, L)
+        dt = time.perf_counter() - t0
+        sample = "128 of the 8192 signals (1/64 sub-batch), 1 thread"
+        ns = xs.size
+    return {"value": round(ns / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": sample, "seconds": round(dt, 2), "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

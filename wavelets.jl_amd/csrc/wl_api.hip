@@ -52,20 +52,6 @@ int ensure_ws(wl_ctx *ctx, size_t bytes)
     return WL_OK;
 }
 
-// Workspace carve-up (elements of T), N = number of elements of the box:
-//   T0, T1 : N each   inter-pass buffers (T1 only for 3-D); T0 doubles as lifting "W"
-//   W      : N        lifting work buffer
-//   A, B   : N/2 each approximation ping-pong (level l writes the one level l+1 reads)
-// => 4 N elements is always enough (and is what wl_workspace_bytes reports).
-inline size_t ws_elems(int64_t N) { return (size_t)(4 * N + 64); }
-
-Strides3 dense_strides(const int64_t n[3])
-{
-    Strides3 s;
-    s.s[0] = 1; s.s[1] = n[0]; s.s[2] = n[0] * n[1];
-    return s;
-}
-
 template <typename T>
 void make_taps(const double *qmf, int flen, Taps<T> &t)
 {
@@ -106,86 +92,7 @@ int make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, cons
     return WL_OK;
 }
 
-// ----------------------------------------------------------------------------------------
-// A "box transform" covers dwt (all axes of an nd box transformed) and dwtc (axis 0 of a
-// len x nsignals box).  taxes = number of leading axes that are transformed... dwtc
-// transforms axis 0 only, dwt transforms axes 0..nd-1.
-struct BoxSpec {
-    int nd;                 // rank of the array (1..3)
-    int nt;                 // transformed axes are 0..nt-1
-    int64_t dims[3];        // full extents (unused dims = 1)
-    Strides3 full;          // strides of x / y
-};
-
-template <typename T>
-struct Work {
-    T *T0, *T1, *W, *A, *B;
-};
-template <typename T>
-Work<T> carve(void *ws, int64_t N)
-{
-    Work<T> w;
-    T *p = (T *)ws;
-    w.T0 = p; p += N;
-    w.T1 = p; p += N;
-    w.W = p; p += N;
-    w.A = p; p += N / 2 + 8;
-    w.B = p;
-    return w;
-}
-
-inline void level_box(const BoxSpec &b, int l /*1-based*/, int64_t n[3])
-{
-    for (int d = 0; d < 3; ++d) n[d] = (d < b.nt) ? (b.dims[d] >> (l - 1)) : b.dims[d];
-}
-inline Extent3 low_corner(const BoxSpec &b, const int64_t n[3])
-{
-    Extent3 lo;
-    for (int d = 0; d < 3; ++d) lo.n[d] = (d < b.nt) ? (n[d] >> 1) : n[d];
-    return lo;
-}
-
 // ---- generic filter level loops ----------------------------------------------------------
-template <typename T>
-int generic_filter_fwd(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
-                       const Taps<T> &taps, int L, int l_first, const T *src0, Strides3 src0_st,
-                       int *pp_io)
-{
-    // l_first > 1 lets a fast path do the first levels and hand over the approximation
-    // (src0, dense strides) to the generic levels.
-    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
-    Work<T> w = carve<T>(ctx->ws, N);
-    const T *cur = src0;
-    Strides3 cur_st = src0_st;
-    int pp = pp_io ? *pp_io : 0;
-    for (int l = l_first; l <= L; ++l) {
-        int64_t n[3];
-        level_box(b, l, n);
-        Extent3 ext = {{n[0], n[1], n[2]}};
-        Extent3 lo = low_corner(b, n);
-        const bool last = (l == L);
-        T *llbuf = pp ? w.B : w.A;
-        int64_t hn[3] = {lo.n[0], lo.n[1], lo.n[2]};
-        Strides3 ll_st = dense_strides(hn);
-        Strides3 box_st = dense_strides(n);
-        const T *in = cur;
-        Strides3 in_st = cur_st;
-        int tog = 0;
-        for (int a = b.nt - 1; a >= 0; --a) {
-            if (a != 0) {
-                T *out = tog ? w.T1 : w.T0;
-                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, taps, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
-                in = out; in_st = box_st; tog ^= 1;
-            } else {
-                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, taps, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
-            }
-        }
-        cur = llbuf; cur_st = ll_st; pp ^= 1;
-    }
-    if (pp_io) *pp_io = pp;
-    return WL_OK;
-}
-
 template <typename T>
 int generic_filter_inv(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
                        const Taps<T> &taps, int L)
@@ -336,17 +243,9 @@ int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T
     if (rc) return rc;
     Taps<T> taps;
     make_taps<T>(qmf, flen, taps);
-    if (fw) {
-        if (ctx->path == 0) {
-            int handled = 0;
-            rc = fast_filter_fwd<T>(ctx->ws, ctx->cu_count, st, b.nd, b.nt, b.dims, b.full, y, x, taps, L,
-                                    &handled, &ctx->last_kernel, &ctx->last_hip);
-            if (rc) return rc;
-            if (handled) return WL_OK;
-        }
-        ctx->last_kernel = "k_generic_fwd_filter";
-        return generic_filter_fwd<T>(ctx, st, b, y, x, taps, L, 1, x, b.full, nullptr);
-    }
+    if (fw)
+        return filter_fwd_levels<T>(ctx->ws, ctx->cu_count, ctx->path, st, b, y, x, taps, L,
+                                    &ctx->last_kernel, &ctx->last_hip);
     ctx->last_kernel = "k_generic_inv_filter";
     return generic_filter_inv<T>(ctx, st, b, y, x, taps, L);
 }

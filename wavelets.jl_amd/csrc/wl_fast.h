@@ -1,15 +1,16 @@
-// wl_fast.h -- fast-path dispatcher (large power-of-two levels, short even filters).
+// wl_fast.h -- forward filter-bank level loop with fast-path dispatch (wl_fwd.hip).
 // Every fast kernel must produce results bit-identical to the generic kernels.
 #pragma once
 #include "wl_internal.h"
 
 namespace wl {
 
-// Forward filter-bank transform.  Sets *handled = 1 when the whole transform (all L levels)
-// was enqueued by fast kernels; otherwise leaves *handled = 0 and enqueues nothing.
+// Enqueue all L forward levels of a filter-bank transform.  path: 0 = pick the best kernel
+// per level (streaming kernels for large levels, one LDS-resident kernel for the tail,
+// generic otherwise), 1 = generic kernels only.  *kernel_name = dominant kernel used.
 template <typename T>
-int fast_filter_fwd(void *ws, int cu_count, hipStream_t st, int nd, int nt, const int64_t dims[3], Strides3 full,
-                    T *y, const T *x, const Taps<T> &taps, int L,
-                    int *handled, const char **kernel_name, int *hip_err);
+int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+                      T *y, const T *x, const Taps<T> &taps, int L,
+                      const char **kernel_name, int *hip_err);
 
 }  // namespace wl

@@ -1,0 +1,829 @@
+// wl_fwd.hip -- forward filter-bank DWT: the level loop and its CDNA4 fast paths.
+//
+// Hot path of the build (BASELINE.json north_star): one fused kernel per level.
+//
+//   k_fwd2d_stream  2-D level, rows (dim 2) + columns (dim 1) fused, register streaming.
+//                   One wave owns a strip of 64*RPL rows (RPL contiguous rows per lane, one
+//                   16-byte load per lane per column => 1 KiB per wave-instruction, coalesced
+//                   along dim 1) and marches along dim 2 with an F-column sliding window held
+//                   in VGPRs (the dim-2 pass never leaves registers).  The dim-1 pass takes
+//                   the neighbouring rows from adjacent lanes with wave shuffles; strips
+//                   overlap by 16 rows instead of exchanging halos through LDS, so there is no
+//                   barrier and no LDS traffic at all.  The detail column computed from a
+//                   window is d[k+(F-2)/2] (same F inputs as s[k]), which halves the halo.
+//                   HBM traffic: each level's block is read once and written once.
+//   k_fwd1d_stream  1-D level (also one line per blockIdx.y: batched columns / WPT segments):
+//                   8 samples per lane, halo from the two neighbouring lanes by shuffle.
+//   k_tail_fwd      all remaining levels of a small block (<= 16 Ki f32 / 8 Ki f64 elements) in
+//                   ONE workgroup with the block resident in LDS (true periodic indexing, so
+//                   lines shorter than the filter are handled) -- removes ~2 launches per level
+//                   for the deep levels of a full-depth transform.
+//
+// All three evaluate the closed forms of wl_internal.h in the reference's summation order
+// with separate multiply/add roundings: results are bit-identical to the generic kernels.
+#include "wl_fast.h"
+
+#include <cstdlib>
+
+namespace wl {
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int F>
+struct TapsF {
+    T h[F];
+    T g[F];
+};
+template <typename T, int F>
+static TapsF<T, F> shrink(const Taps<T> &t)
+{
+    TapsF<T, F> r;
+    for (int i = 0; i < F; ++i) { r.h[i] = t.h[i]; r.g[i] = t.g[i]; }
+    return r;
+}
+
+template <typename T, int N>
+struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T>
+struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int N>
+__device__ __forceinline__ void vload(const T *p, T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    V t = *reinterpret_cast<const V *>(p);
+    if constexpr (N == 1) v[0] = t;
+    else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void vstore(T *p, const T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    if constexpr (N == 1) *p = v[0];
+    else {
+        V t;
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = v[i];
+        *reinterpret_cast<V *>(p) = t;
+    }
+}
+// 16-byte-granular load/store of N elements (N*sizeof(T) may exceed 16 bytes)
+template <typename T, int N>
+__device__ __forceinline__ void vload16(const T *p, T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    static_assert(N % C == 0, "chunking");
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        T t[C];
+        vload<T, C>(p + c * C, t);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void vstore16(T *p, const T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    static_assert(N % C == 0, "chunking");
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        T t[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        vstore<T, C>(p + c * C, t);
+    }
+}
+
+constexpr __host__ __device__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Whole-wave lane shifts on the VALU (DPP wave_shl:1 / wave_shr:1 -- gfx9-family controls, valid
+// on gfx950): lane i receives the value of lane i+1 (shl) or lane i-1 (shr).  No LDS round trip,
+// unlike __shfl (ds_bpermute).  Lanes shifted in from outside the wave get an unspecified value;
+// callers never store results that depend on them.
+__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_next(float v) { return __int_as_float(dpp_from_next(__float_as_int(v))); }
+__device__ __forceinline__ float from_prev(float v) { return __int_as_float(dpp_from_prev(__float_as_int(v))); }
+__device__ __forceinline__ double from_next(double v)
+{
+    int lo = dpp_from_next(__double2loint(v)), hi = dpp_from_next(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_prev(double v)
+{
+    int lo = dpp_from_prev(__double2loint(v)), hi = dpp_from_prev(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// One level of the QMF pair along the lane axis.  v[] holds this lane's PER consecutive
+// samples of the line; sample offsets outside [0, PER) come from lane + floordiv(off, PER).
+// Produces PER/2 (s, d) pairs: pair q uses s: offsets 2q..2q+F-1, d: offsets 2q+2-F..2q+1.
+template <typename T, int F, int PER>
+__device__ __forceinline__ void lane_axis_pair(const T (&v)[PER], const TapsF<T, F> &tp,
+                                               T (&so)[PER / 2], T (&dO)[PER / 2])
+{
+    constexpr int LO = -(F - 2), HI = PER + F - 2;
+    T ext[HI - LO];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) ext[e - LO] = v[e];
+    {   // offsets >= PER: repeated shifts towards lower lanes
+        T cur[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cur[e] = v[e];
+#pragma unroll
+        for (int base = PER; base < HI; base += PER) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+                if (base + e < HI) {            // only elements still needed at this or a later distance
+                    cur[e] = from_next(cur[e]);
+                    ext[base + e - LO] = cur[e];
+                }
+        }
+    }
+    {   // offsets < 0: repeated shifts towards higher lanes
+        T cur[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cur[e] = v[e];
+#pragma unroll
+        for (int base = -PER; base + PER > LO; base -= PER) {
+#pragma unroll
+            for (int e = PER - 1; e >= 0; --e)
+                if (base + e >= LO) {
+                    cur[e] = from_prev(cur[e]);
+                    ext[base + e - LO] = cur[e];
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER / 2; ++q) {
+        T s = tp.h[0] * ext[2 * q - LO];
+#pragma unroll
+        for (int m = 1; m < F; ++m) s = s + tp.h[m] * ext[2 * q + m - LO];
+        T d = tp.g[F - 1] * ext[2 * q + 1 - (F - 1) - LO];
+#pragma unroll
+        for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * ext[2 * q + 1 - m - LO];
+        so[q] = s;
+        dO[q] = d;
+    }
+}
+
+// Packed variant for the 2-D kernel: v[] holds PER pairs {a, b} (two independent lines, e.g. the
+// dim-2 scaling and detail results of the same row); both lines get the same QMF pair along the
+// lane axis.  Written on 2-vectors so that f32 maps onto v_pk_mul_f32 / v_pk_add_f32 with the tap
+// broadcast from an SGPR -- no operand shuffling moves.
+//   P[q] = { s-of-a, s-of-b } = sum_m asc  h[m] * E[2q+m]
+//   Q[q] = { d-of-a, d-of-b } = sum_m desc g[m] * E[2q+1-m]
+template <typename T, int F, int PER>
+__device__ __forceinline__ void lane_axis_pair2(const typename VecOf<T, 2>::type (&v)[PER], const TapsF<T, F> &tp,
+                                                typename VecOf<T, 2>::type (&P)[PER / 2],
+                                                typename VecOf<T, 2>::type (&Q)[PER / 2])
+{
+    typedef typename VecOf<T, 2>::type T2;
+    constexpr int LO = -(F - 2), HI = PER + F - 2;
+    T2 ext[HI - LO];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) ext[e - LO] = v[e];
+    {
+        T2 cur[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cur[e] = v[e];
+#pragma unroll
+        for (int base = PER; base < HI; base += PER) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+                if (base + e < HI) {
+                    cur[e].x = from_next(cur[e].x);
+                    cur[e].y = from_next(cur[e].y);
+                    ext[base + e - LO] = cur[e];
+                }
+        }
+    }
+    {
+        T2 cur[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) cur[e] = v[e];
+#pragma unroll
+        for (int base = -PER; base + PER > LO; base -= PER) {
+#pragma unroll
+            for (int e = PER - 1; e >= 0; --e)
+                if (base + e >= LO) {
+                    cur[e].x = from_prev(cur[e].x);
+                    cur[e].y = from_prev(cur[e].y);
+                    ext[base + e - LO] = cur[e];
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER / 2; ++q) {
+        T2 s = tp.h[0] * ext[2 * q - LO];
+#pragma unroll
+        for (int m = 1; m < F; ++m) s = s + tp.h[m] * ext[2 * q + m - LO];
+        T2 d = tp.g[F - 1] * ext[2 * q + 1 - (F - 1) - LO];
+#pragma unroll
+        for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * ext[2 * q + 1 - m - LO];
+        P[q] = s;
+        Q[q] = d;
+    }
+}
+// swap with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float from_partner(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double from_partner(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// ==========================================================================================
+// 2-D fused level
+template <typename T, int F>
+struct Fwd2DArgs {
+    const T *src; int64_t lds;      // input block (ms x ns), leading dimension
+    T *y; int64_t ldy;              // output array (detail quadrants, and LL when ll == nullptr)
+    T *ll; int64_t ldll;            // approximation buffer for the next level (or nullptr)
+    int64_t ms, ns;
+    int TJ;                         // input columns per chunk (even)
+    int nstrips, nchunks;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F, int RPL, int LVL1>
+__global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
+{
+    constexpr int ML = 8 / RPL;            // margin lanes on each side (8 rows)
+    constexpr int VR = 64 * RPL - 16;      // rows of output responsibility per wave
+    constexpr int NO = RPL / 2;            // output rows per lane per subband
+    constexpr int SH = (F - 2) / 2;        // detail-column shift
+    const int lane = threadIdx.x;
+
+    // XCD-aware bijective remap: consecutive logical ids (strip fastest) share an XCD's L2,
+    // so the 16-row overlap of neighbouring strips is an L2 hit.
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+
+    const int64_t ms = a.ms, ns = a.ns, nxj = ns >> 1, hm = ms >> 1;
+    const int64_t gi = (int64_t)strip * VR + (int64_t)(lane - ML) * RPL;   // first row of this lane
+    int64_t row = gi;
+    if (row < 0) row += ms;
+    if (row >= ms) row -= ms;
+    const bool valid = (lane >= ML) && (lane < 64 - ML) && (gi < ms);
+    const int64_t ko = gi >> 1;
+
+    const int64_t j0 = (int64_t)chunk * a.TJ;
+    const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
+    const int S = (int)((jend - j0) >> 1);
+    const T *base = a.src + row;
+
+    // Column ring of R = 16 register slots: input column c (relative to j0) lives in slot c % R.
+    // Step t consumes columns 2t .. 2t+F-1 and refills the two slots freed by step t-1 with
+    // columns 2t+R-2, 2t+R-1, i.e. loads run PFD = (R-F)/2 steps ahead of their use.  The loop is
+    // unrolled by R/2 = 8 steps so every slot index is a compile-time constant: no register
+    // rotation moves, no waits on just-issued loads.  (S % 8 == 0 is guaranteed by the launcher.)
+    constexpr int R = 16, U = R / 2, PFD = (R - F) / 2;
+    T ring[R][RPL];
+#pragma unroll
+    for (int c = 0; c < R - 2; ++c) {
+        int64_t jc = j0 + c;
+        if (jc >= ns) jc -= ns;
+        vload<T, RPL>(base + jc * a.lds, ring[c]);
+    }
+
+    T *const yl = a.y + ko;
+    T *const llp = (a.ll != nullptr) ? (a.ll + ko) : yl;
+    const int64_t ldl = (a.ll != nullptr) ? a.ldll : a.ldy;
+    const int64_t kbase = j0 >> 1;
+
+    // u = t % U is a compile-time constant at every call site
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        if (prefetch) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int64_t jc = j0 + 2 * t + (R - 2) + e;
+                if (jc >= ns) jc -= ns;
+                vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+            }
+        }
+        // dim-2 pass in registers on row pairs (adjacent registers of the 16-byte loads):
+        // A2[p] = scaling, B2[p] = detail of rows 2p, 2p+1 for this column pair
+        typedef typename VecOf<T, 2>::type T2;
+        T2 A2[RPL / 2], B2[RPL / 2];
+#pragma unroll
+        for (int pr = 0; pr < RPL / 2; ++pr) {
+            T2 x0 = T2{ring[(2 * u) % R][2 * pr], ring[(2 * u) % R][2 * pr + 1]};
+            T2 sa = a.tp.h[0] * x0;
+            T2 da = a.tp.g[F - 1] * x0;
+#pragma unroll
+            for (int m = 1; m < F; ++m) {
+                T2 xm = T2{ring[(2 * u + m) % R][2 * pr], ring[(2 * u + m) % R][2 * pr + 1]};
+                sa = sa + a.tp.h[m] * xm;
+                da = da + a.tp.g[F - 1 - m] * xm;
+            }
+            A2[pr] = sa;
+            B2[pr] = da;
+        }
+        // re-pair as RD[q] = { scaling, detail } of row q for the lane-axis pass
+        T2 RD[RPL];
+#pragma unroll
+        for (int pr = 0; pr < RPL / 2; ++pr) {
+            RD[2 * pr] = T2{A2[pr].x, B2[pr].x};
+            RD[2 * pr + 1] = T2{A2[pr].y, B2[pr].y};
+        }
+        // dim-1 pass across lanes: P[q] = {ss, sd}, Q[q] = {ds, dd} for output row ko + q
+        T2 P[NO], Q[NO];
+        if constexpr (LVL1 == 2) {
+            // bandwidth probe (WL_PROBE=1, never used by the product path): same loads and stores,
+            // no arithmetic -- measures what this access pattern can reach
+#pragma unroll
+            for (int qq = 0; qq < NO; ++qq) {
+                P[qq] = T2{ring[(2 * u) % R][qq], ring[(2 * u + 1) % R][qq]};
+                Q[qq] = T2{ring[(2 * u) % R][NO + qq], ring[(2 * u + 1) % R][NO + qq]};
+            }
+        } else {
+            lane_axis_pair2<T, F, RPL>(RD, a.tp, P, Q);
+        }
+        const int64_t k = kbase + t;
+        int64_t kd = k + SH;
+        if (kd >= nxj) kd -= nxj;
+        if constexpr (RPL == 4) {
+            // Lane pairs (2i, 2i+1) own output rows ko..ko+1 and ko+2..ko+3 of the same columns.  They
+            // swap halves so that the even lane stores rows ko..ko+3 of the two s_j subbands' column k
+            // and the odd lane rows ko-2..ko+1 of the d_j subbands' column kd: 16-byte stores instead
+            // of 8-byte ones (measured +8 % on the store-side of this access pattern).
+            const bool odd = (lane & 1) != 0;
+            T rP[NO], rQ[NO];
+#pragma unroll
+            for (int qq = 0; qq < NO; ++qq) {
+                rP[qq] = from_partner(odd ? P[qq].x : P[qq].y);
+                rQ[qq] = from_partner(odd ? Q[qq].x : Q[qq].y);
+            }
+            T vP[4], vQ[4];
+#pragma unroll
+            for (int qq = 0; qq < NO; ++qq) {
+                vP[qq] = odd ? rP[qq] : P[qq].x;  vP[NO + qq] = odd ? P[qq].y : rP[qq];
+                vQ[qq] = odd ? rQ[qq] : Q[qq].x;  vQ[NO + qq] = odd ? Q[qq].y : rQ[qq];
+            }
+            if (valid) {
+                // even: LL / ds of column k at row ko;   odd: sd / dd of column kd at row ko-2
+                T *pP = odd ? (yl - NO + (nxj + kd) * a.ldy) : (llp + k * ldl);
+                T *pQ = odd ? (yl - NO + (nxj + kd) * a.ldy + hm) : (yl + k * a.ldy + hm);
+                vstore<T, 4>(pP, vP);
+                vstore<T, 4>(pQ, vQ);
+            }
+        } else {
+            if (valid) {
+                T ss[NO], ds[NO], sd[NO], dd[NO];
+#pragma unroll
+                for (int qq = 0; qq < NO; ++qq) { ss[qq] = P[qq].x; sd[qq] = P[qq].y; ds[qq] = Q[qq].x; dd[qq] = Q[qq].y; }
+                vstore<T, NO>(llp + k * ldl, ss);
+                vstore<T, NO>(yl + k * a.ldy + hm, ds);
+                vstore<T, NO>(yl + (nxj + kd) * a.ldy, sd);
+                vstore<T, NO>(yl + (nxj + kd) * a.ldy + hm, dd);
+            }
+        }
+    };
+
+    int t0 = 0;
+    for (; t0 < S - U; t0 += U) {            // steady state: every prefetch is inside the chunk's range
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - PFD);   // last group: stop prefetching PFD steps early
+}
+
+// ==========================================================================================
+// 1-D level (one line per blockIdx.y)
+template <typename T, int F>
+struct Fwd1DArgs {
+    const T *src; int64_t src_ls;   // line stride of the source
+    T *sdst; int64_t s_ls;          // approximation destination
+    T *ddst; int64_t d_ls;          // detail destination
+    int64_t n;                      // line length (multiple of 8, >= 512)
+    int64_t ntiles;                 // tiles of 248 pairs
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F, int LVL1>
+__global__ void __launch_bounds__(256) k_fwd1d_stream(Fwd1DArgs<T, F> a)
+{
+    constexpr int SPL = 8, VP = 62 * 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t n = a.n, nx = n >> 1;
+    const T *src = a.src + (int64_t)blockIdx.y * a.src_ls;
+    T *sdst = a.sdst + (int64_t)blockIdx.y * a.s_ls;
+    T *ddst = a.ddst + (int64_t)blockIdx.y * a.d_ls;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k0 = tile * VP + (int64_t)(lane - 1) * 4;     // first pair of this lane
+        int64_t gs = 2 * k0;
+        if (gs < 0) gs += n;
+        if (gs >= n) gs -= n;
+        T v[SPL];
+        vload16<T, SPL>(src + gs, v);
+        T so[4], dO[4];
+        lane_axis_pair<T, F, SPL>(v, a.tp, so, dO);
+        if (lane >= 1 && lane <= 62 && k0 < nx) {
+            vstore16<T, 4>(sdst + k0, so);
+            vstore16<T, 4>(ddst + k0, dO);
+        }
+    }
+}
+
+// ==========================================================================================
+// tail: all remaining levels of a small block inside one workgroup, block resident in LDS
+template <typename T>
+struct TailArgs {
+    const T *src; int64_t s1;       // source block: element (i, j) at src[i + j*s1]
+    T *y; int64_t ldy;              // destination array (same origin as the block)
+    int64_t src_item, y_item;       // per-blockIdx.x offsets (batched lines)
+    int m0, m1;                     // block extents (m1 == 1 for 1-D lines)
+    int nt;                         // 1: transform dim 1 only; 2: both dims
+    int nlev;                       // levels to run (>= 1)
+    int cap;                        // elements per LDS buffer
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
+// release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); the tail kernel
+// streams its detail coefficients to HBM between barriers and nothing in the kernel reads them back,
+// so waiting for them (~1-2 us per barrier, 14 barriers) was most of its run time.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ int wrap_idx(int i, int n)
+{
+    // periodic index without integer division: one trip for n >= F, a few for tiny lines
+    while (i >= n) i -= n;
+    while (i < 0) i += n;
+    return i;
+}
+// (s, d) pair k of a line of length n stored at p with element stride `stride`.
+// FC > 0: compile-time filter length (all operands fetched before the arithmetic, so the LDS
+// reads are issued back to back); FC == 0: run-time length.
+template <typename T, int FC>
+__device__ __forceinline__ void tail_pair(const T *p, int stride, int k, int n, const Taps<T> &tp, T &s, T &d)
+{
+    if constexpr (FC > 0) {
+        // window x[2k-(FC-2) .. 2k+FC-1] covers both branches
+        T xv[2 * FC - 2];
+        const int lo = 2 * k - (FC - 2);
+        if (lo >= 0 && lo + 2 * FC - 2 <= n) {
+            // interior pair: no periodic wrap, plain strided reads (no per-element index math)
+            const T *q = p + lo * stride;
+#pragma unroll
+            for (int e = 0; e < 2 * FC - 2; ++e) xv[e] = q[e * stride];
+        } else {
+            int i = wrap_idx(lo, n);
+#pragma unroll
+            for (int e = 0; e < 2 * FC - 2; ++e) {
+                xv[e] = p[i * stride];
+                if (++i >= n) i -= n;
+            }
+        }
+        s = tp.h[0] * xv[FC - 2];
+#pragma unroll
+        for (int m = 1; m < FC; ++m) s = s + tp.h[m] * xv[FC - 2 + m];
+        d = tp.g[FC - 1] * xv[0];
+#pragma unroll
+        for (int m = FC - 2; m >= 0; --m) d = d + tp.g[m] * xv[FC - 1 - m];
+    } else {
+        const int F = tp.F;
+        int i = wrap_idx(2 * k, n);
+        s = tp.h[0] * p[i * stride];
+        for (int m = 1; m < F; ++m) {
+            if (++i >= n) i -= n;
+            s = s + tp.h[m] * p[i * stride];
+        }
+        i = wrap_idx(2 * k + 1 - (F - 1), n);
+        d = tp.g[F - 1] * p[i * stride];
+        for (int m = F - 2; m >= 0; --m) {
+            if (++i >= n) i -= n;
+            d = d + tp.g[m] * p[i * stride];
+        }
+    }
+}
+// idx -> (idx % m, idx / m) with a shift when m is a power of two
+__device__ __forceinline__ void split_idx(int idx, int m, int lg, int &lo, int &hi)
+{
+    if (lg >= 0) { lo = idx & (m - 1); hi = idx >> lg; }
+    else { hi = idx / m; lo = idx - hi * m; }
+}
+__device__ __forceinline__ int ilog2_or_neg(int m) { return (m & (m - 1)) == 0 ? (31 - __clz(m)) : -1; }
+
+// LDS layout: column j of the current block starts at j * ld with ld = m0 + 1 (odd pad) whenever
+// the block has more than one column, so that both the dim-2 pass (threads along i) and the dim-1
+// pass (threads along k, stride-2 reads) are free of systematic bank conflicts.
+template <typename T, int FC>
+__global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *A = reinterpret_cast<T *>(smem_raw);
+    T *B = A + a.cap;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
+    T *y = a.y + (int64_t)blockIdx.x * a.y_item;
+    int m0 = a.m0, m1 = a.m1;
+    const int ld = (m1 > 1) ? (a.m0 | 1) : a.m0;      // fixed for all levels
+    {
+        const int lg = ilog2_or_neg(m0);
+        const int total = m0 * m1;
+        constexpr int VW = 16 / sizeof(T);
+        const bool vec_ok = (m0 % VW) == 0 && (a.s1 % VW) == 0 && (a.src_item % VW) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
+        if (vec_ok) {
+            // 16-byte loads, four per thread in flight (covers a 16 Ki-element block with 1024 threads)
+            const int totalv = total / VW, m0v = m0 / VW;
+            const int lgv = ilog2_or_neg(m0v);
+            for (int idx = tid; idx < totalv; idx += 4 * nthr) {
+                T v[4][VW];
+                int ii[4], jj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int id = idx + r * nthr;
+                    if (id < totalv) {
+                        split_idx(id, m0v, lgv, ii[r], jj[r]);
+                        vload<T, VW>(src + ii[r] * VW + (int64_t)jj[r] * a.s1, v[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (idx + r * nthr < totalv) {
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) A[ii[r] * VW + e + jj[r] * ld] = v[r][e];
+                    }
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += 4 * nthr) {
+                T v[4];
+                int ii[4], jj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int id = idx + r * nthr;
+                    if (id < total) {
+                        split_idx(id, m0, lg, ii[r], jj[r]);
+                        v[r] = src[ii[r] + (int64_t)jj[r] * a.s1];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (idx + r * nthr < total) A[ii[r] + jj[r] * ld] = v[r];
+            }
+        }
+    }
+    lds_barrier();
+    for (int lev = 0; lev < a.nlev; ++lev) {
+        const bool last = (lev == a.nlev - 1);
+        const int h0 = m0 >> 1;
+        const int lg0 = ilog2_or_neg(m0), lgh = ilog2_or_neg(h0);
+        if (a.nt == 1) {
+            // single line of length m0 in A
+            for (int k = tid; k < h0; k += nthr) {
+                T s, d;
+                tail_pair<T, FC>(A, 1, k, m0, tp, s, d);
+                y[h0 + k] = d;
+                if (last) y[k] = s;
+                else B[k] = s;
+            }
+            lds_barrier();
+            T *t = A; A = B; B = t;
+            m0 = h0;
+        } else {
+            const int h1 = m1 >> 1;
+            // dim-2 pass: A (m0 x m1) -> B (m0 x m1), [s ; d] along j
+            for (int idx = tid; idx < m0 * h1; idx += 2 * nthr) {
+                int i0, k0, i1 = 0, k1 = 0;
+                const bool two = (idx + nthr) < m0 * h1;
+                split_idx(idx, m0, lg0, i0, k0);
+                if (two) split_idx(idx + nthr, m0, lg0, i1, k1);
+                T s0, d0, s1 = (T)0, d1 = (T)0;
+                tail_pair<T, FC>(A + i0, ld, k0, m1, tp, s0, d0);
+                if (two) tail_pair<T, FC>(A + i1, ld, k1, m1, tp, s1, d1);
+                B[i0 + k0 * ld] = s0;
+                B[i0 + (h1 + k0) * ld] = d0;
+                if (two) { B[i1 + k1 * ld] = s1; B[i1 + (h1 + k1) * ld] = d1; }
+            }
+            lds_barrier();
+            // dim-1 pass: B -> details to y, LL to A (h0 x h1) or y
+            for (int idx = tid; idx < h0 * m1; idx += 2 * nthr) {
+                int k0, j0, k1 = 0, j1 = 0;
+                const bool two = (idx + nthr) < h0 * m1;
+                split_idx(idx, h0, lgh, k0, j0);
+                if (two) split_idx(idx + nthr, h0, lgh, k1, j1);
+                T s0, d0, s1 = (T)0, d1 = (T)0;
+                tail_pair<T, FC>(B + j0 * ld, 1, k0, m0, tp, s0, d0);
+                if (two) tail_pair<T, FC>(B + j1 * ld, 1, k1, m0, tp, s1, d1);
+                y[(int64_t)j0 * a.ldy + h0 + k0] = d0;
+                if (j0 < h1 && !last) A[k0 + j0 * ld] = s0;
+                else y[(int64_t)j0 * a.ldy + k0] = s0;
+                if (two) {
+                    y[(int64_t)j1 * a.ldy + h0 + k1] = d1;
+                    if (j1 < h1 && !last) A[k1 + j1 * ld] = s1;
+                    else y[(int64_t)j1 * a.ldy + k1] = s1;
+                }
+            }
+            lds_barrier();
+            m0 = h0;
+            m1 = h1;
+        }
+    }
+}
+
+// ==========================================================================================
+// host side
+static int env_int(const char *name, int dflt)
+{
+    const char *s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+
+template <typename T>
+constexpr int tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }     // block elements
+template <typename T>
+constexpr int tail_lds_elems() { return tail_cap<T>() + 256; }          // + odd-pad columns
+
+template <typename T>
+static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,
+                              int64_t src_item, int64_t y_item, int nitems, int m0, int m1, int nt, int nlev)
+{
+    TailArgs<T> a;
+    a.src = src; a.s1 = s1; a.y = y; a.ldy = ldy; a.src_item = src_item; a.y_item = y_item;
+    a.m0 = m0; a.m1 = m1; a.nt = nt; a.nlev = nlev; a.cap = tail_lds_elems<T>();
+    const size_t shmem = 2 * (size_t)a.cap * sizeof(T);
+    int64_t work = (int64_t)m0 * m1 / 2;
+    int threads = work >= 4096 ? 1024 : (work >= 512 ? 256 : 64);
+#define WL_TAIL_LAUNCH(FC_)                                                                                   \
+    do {                                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_fwd<T, FC_>),               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);           \
+        if (e != hipSuccess) return e;                                                                        \
+        hipLaunchKernelGGL((k_tail_fwd<T, FC_>), dim3((unsigned)nitems), dim3(threads), shmem, st, a, taps);  \
+    } while (0)
+    switch (taps.F) {
+    case 2: WL_TAIL_LAUNCH(2); break;
+    case 4: WL_TAIL_LAUNCH(4); break;
+    case 6: WL_TAIL_LAUNCH(6); break;
+    case 8: WL_TAIL_LAUNCH(8); break;
+    default: WL_TAIL_LAUNCH(0); break;
+    }
+#undef WL_TAIL_LAUNCH
+    return hipGetLastError();
+}
+
+template <typename T, int F>
+static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
+                               T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    constexpr int RPL = 16 / sizeof(T);
+    constexpr int VR = 64 * RPL - 16;
+    Fwd2DArgs<T, F> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
+    a.nstrips = (int)((ms + VR - 1) / VR);
+    int TJ = env_int("WL_TJ", 128);
+    // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
+    // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16
+    auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
+    while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * 8) TJ >>= 1;
+    while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * 2) TJ >>= 1;
+    a.TJ = TJ;
+    a.nchunks = (int)((ns + TJ - 1) / TJ);
+    a.tp = shrink<T, F>(taps);
+    const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
+    if (env_int("WL_PROBE", 0) == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64), 0, st, a);
+    else if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int F>
+static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t src_ls,
+                               T *sdst, int64_t s_ls, T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count)
+{
+    Fwd1DArgs<T, F> a;
+    a.src = src; a.src_ls = src_ls; a.sdst = sdst; a.s_ls = s_ls; a.ddst = ddst; a.d_ls = d_ls; a.n = n;
+    a.ntiles = ((n >> 1) + 247) / 248;
+    a.tp = shrink<T, F>(taps);
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    if (lvl1) hipLaunchKernelGGL((k_fwd1d_stream<T, F, 1>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd1d_stream<T, F, 0>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+#define WL_DISPATCH_F(F_, ...)                               \
+    switch (F_) {                                            \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break;    \
+    case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
+    case 10: { constexpr int FF = 10; __VA_ARGS__; } break;  \
+    default: break;                                          \
+    }
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+                      T *y, const T *x, const Taps<T> &taps, int L, const char **kernel_name, int *hip_err)
+{
+#define WL_TRY(expr)                                                  \
+    do {                                                              \
+        hipError_t e__ = (expr);                                      \
+        if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } \
+    } while (0)
+    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ws, N);
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    const bool fastF = (path == 0) && (F % 2 == 0) && (F <= 10);
+    const bool two_d = (b.nd == 2 && b.nt == 2);
+    const bool lines = (b.nt == 1 && b.nd <= 2);          // 1-D vector or batched columns
+    const int64_t nlines = lines ? b.dims[1] : 1;
+    const char *dominant = nullptr;
+
+    const T *cur = x;
+    Strides3 cur_st = b.full;
+    int pp = 0;
+    for (int l = 1; l <= L; ++l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        const bool last = (l == L);
+        T *llbuf = pp ? w.B : w.A;
+        int64_t hn[3] = {lo.n[0], lo.n[1], lo.n[2]};
+        Strides3 ll_st = dense_strides(hn);
+        Strides3 box_st = dense_strides(n);
+
+        // ---- LDS-resident tail: finishes every remaining level in one launch ----
+        if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
+            const int64_t blk = two_d ? n[0] * n[1] : n[0];
+            if (blk <= tail_cap<T>() && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
+                if (two_d)
+                    WL_TRY(launch_tail<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
+                else   // one workgroup per line
+                    WL_TRY(launch_tail<T>(st, taps, cur, 0, y, 0, cur_st.s[1], b.full.s[1], (int)nlines, (int)n[0], 1, 1, L - l + 1));
+                if (!dominant) dominant = "k_tail_fwd";
+                break;
+            }
+        }
+        bool done = false;
+        // ---- streaming 2-D level ----
+        if (fastF && two_d && n[0] >= 64 * VEC && (n[0] % 8) == 0 && n[1] >= 16 && (n[1] % 16) == 0 &&
+            cur_st.s[0] == 1 && (cur_st.s[1] % VEC) == 0 && aligned16(cur) &&
+            (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+            WL_DISPATCH_F(F, WL_TRY((launch_fwd2d<T, FF>(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1],
+                                                         last ? (T *)nullptr : llbuf, ll_st.s[1], n[0], n[1], cu_count)));
+                          done = true);
+            if (done && !dominant) dominant = "k_fwd2d_stream";
+        }
+        // ---- streaming 1-D level (vector, or every column of a matrix) ----
+        if (!done && fastF && lines && n[0] >= 512 && (n[0] % 8) == 0 && cur_st.s[0] == 1 && aligned16(cur) &&
+            aligned16(y) && aligned16(llbuf) && (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0)) &&
+            nlines <= 65535) {
+            T *sd = last ? y : llbuf;
+            int64_t sls = last ? b.full.s[1] : ll_st.s[1];
+            WL_DISPATCH_F(F, WL_TRY((launch_fwd1d<T, FF>(st, taps, l == 1, cur, cur_st.s[1], sd, sls, y + (n[0] >> 1),
+                                                         b.full.s[1], n[0], nlines, cu_count)));
+                          done = true);
+            if (done && !dominant) dominant = "k_fwd1d_stream";
+        }
+        // ---- generic level (any rank / size / filter) ----
+        if (!done) {
+            const T *in = cur;
+            Strides3 in_st = cur_st;
+            int tog = 0;
+            for (int a = b.nt - 1; a >= 0; --a) {
+                if (a != 0) {
+                    T *out = tog ? w.T1 : w.T0;
+                    WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
+                    in = out; in_st = box_st; tog ^= 1;
+                } else {
+                    WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+                }
+            }
+            if (!dominant) dominant = "k_generic_fwd_filter";
+        }
+        cur = llbuf; cur_st = ll_st; pp ^= 1;
+    }
+    if (kernel_name) *kernel_name = dominant ? dominant : "none";
+    return WL_OK;
+#undef WL_TRY
+}
+
+template int filter_fwd_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
+                                      const Taps<float> &, int, const char **, int *);
+template int filter_fwd_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,
+                                       const Taps<double> &, int, const char **, int *);
+
+}  // namespace wl

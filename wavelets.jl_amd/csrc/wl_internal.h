@@ -79,6 +79,49 @@ hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, 
 template <typename T>
 hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, Strides3 dst_st, Extent3 n);
 
+// ---- workspace carve-up shared by the level loops (elements of T; N = box elements) ----
+//   T0, T1 : N each   inter-pass buffers (T1 only for 3-D)
+//   W      : N        lifting work buffer
+//   A, B   : N/2 each approximation ping-pong (level l writes the one level l+1 reads)
+inline size_t ws_elems(int64_t N) { return (size_t)(4 * N + 64); }
+template <typename T>
+struct Work { T *T0, *T1, *W, *A, *B; };
+template <typename T>
+inline Work<T> carve(void *ws, int64_t N)
+{
+    Work<T> w;
+    T *p = (T *)ws;
+    w.T0 = p; p += N;
+    w.T1 = p; p += N;
+    w.W = p; p += N;
+    w.A = p; p += N / 2 + 8;
+    w.B = p;
+    return w;
+}
+inline Strides3 dense_strides(const int64_t n[3])
+{
+    Strides3 s;
+    s.s[0] = 1; s.s[1] = n[0]; s.s[2] = n[0] * n[1];
+    return s;
+}
+// A "box transform" covers dwt (all nd axes transformed) and dwtc (axis 0 of a len x nsignals box).
+struct BoxSpec {
+    int nd;                 // rank of the array (1..3)
+    int nt;                 // transformed axes are 0..nt-1
+    int64_t dims[3];        // full extents (unused dims = 1)
+    Strides3 full;          // strides of x / y
+};
+inline void level_box(const BoxSpec &b, int l /*1-based*/, int64_t n[3])
+{
+    for (int d = 0; d < 3; ++d) n[d] = (d < b.nt) ? (b.dims[d] >> (l - 1)) : b.dims[d];
+}
+inline Extent3 low_corner(const BoxSpec &b, const int64_t n[3])
+{
+    Extent3 lo;
+    for (int d = 0; d < 3; ++d) lo.n[d] = (d < b.nt) ? (n[d] >> 1) : n[d];
+    return lo;
+}
+
 // ---- un-fused arithmetic helpers ----
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }

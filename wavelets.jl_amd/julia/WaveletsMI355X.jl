@@ -1,0 +1,104 @@
+# WaveletsMI355X.jl -- Julia glue for libwavelets_mi355x.so (include/wavelets_mi355x.h).
+#
+# NOT executed in this repository's CI: the build image has no Julia.  It is the binding a
+# Wavelets.jl maintainer adds (as a package extension next to ext/WaveletsGPUExt, wired through
+# [weakdeps]/[extensions] of Project.toml with AMDGPU as the trigger).  It only adds methods to the
+# reference's internal seam -- `Transforms._dwt!` / `_wpt!` (src/Transforms/transforms_main.jl:105-176
+# end there) -- for `ROCArray`s, so `dwt / idwt / dwt! / idwt! / wpt / iwpt` and every caller of them
+# (denoise, bestbasistree, ...) pick the MI355X backend by array-type dispatch.  A `ROCVector` method
+# is more specific than the extension's `AbstractGPUVector` method, so it wins without touching it.
+module WaveletsMI355X
+
+using Wavelets
+using Wavelets: WT, Util
+using Wavelets.Transforms: Transforms
+using AMDGPU: ROCArray, ROCVector, ROCMatrix, AMDGPU
+
+const LIB = get(ENV, "WAVELETS_MI355X_LIB", "libwavelets_mi355x.so")
+const DT = Dict(Float32 => Cint(0), Float64 => Cint(1))
+const CTX = Dict{Int,Ptr{Cvoid}}()          # one context per device (per task/stream in real use)
+
+function ctx()
+    dev = AMDGPU.device_id(AMDGPU.device()) - 1
+    get!(CTX, dev) do
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:wl_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), dev, r))
+        r[]
+    end
+end
+stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))     # hipStream_t of the current task
+
+# status -> the exception the reference throws (transforms_filter.jl:25-34, transforms_lifting.jl:131-139)
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:wl_strerror, LIB), Cstring, (Cint,), rc))
+    rc == -4 && throw(DimensionMismatch(msg))
+    rc in (-1, -2, -3, -5, -6, -7, -9, -10) && throw(ArgumentError(msg))
+    error("libwavelets_mi355x: $msg (status $rc)")
+end
+
+dims3(x) = Int64[size(x)..., ntuple(_ -> 1, 3 - ndims(x))...]
+
+# ---- filter bank: replaces _dwt!(y, x, filter::OrthoFilter, L, fw), transforms_filter.jl:13,113,192
+function Transforms._dwt!(y::ROCArray{T,N}, x::ROCArray{T,N}, filter::OrthoFilter, L::Integer,
+                          fw::Bool) where {T<:Union{Float32,Float64},N}
+    size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
+    q = filter.qmf                                  # Float64 taps; converted to T inside, like makereverseqmfpair
+    check(ccall((:wl_dwt_filter, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), q, length(q), L, fw, stream()))
+    return y
+end
+
+# ---- lifting: replaces _dwt!(y, scheme::GLS, L, fw), transforms_lifting.jl:30,128,200
+function flatten(s::GLS)
+    isup = Int32[st.steptype isa WT.UpdateStep for st in s.step]
+    nc = Int32[length(st.param.coef) for st in s.step]
+    sh = Int32[st.param.shift for st in s.step]
+    cf = Float64[c for st in s.step for c in st.param.coef]
+    return isup, nc, sh, cf
+end
+function Transforms._dwt!(y::ROCArray{T,N}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64},N}
+    isup, nc, sh, cf = flatten(scheme)
+    check(ccall((:wl_dwt_lifting, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                 Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), N, dims3(y), length(isup), isup, nc, sh, cf,
+                scheme.norm1, scheme.norm2, L, fw, stream()))
+    return y
+end
+
+# ---- wavelet packets: replaces _wpt!, transforms_filter.jl:301, transforms_lifting.jl:283
+function Transforms._wpt!(y::ROCVector{T}, x::ROCVector{T}, filter::OrthoFilter, tree::BitVector,
+                          fw::Bool) where {T<:Union{Float32,Float64}}
+    size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
+    t = UInt8.(tree)
+    check(ccall((:wl_wpt_filter, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{UInt8}, Int64, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), pointer(x), length(x), filter.qmf, length(filter.qmf), t, length(t), fw, stream()))
+    return y
+end
+function Transforms._wpt!(y::ROCVector{T}, scheme::GLS, tree::BitVector, fw::Bool) where {T<:Union{Float32,Float64}}
+    isup, nc, sh, cf = flatten(scheme)
+    t = UInt8.(tree)
+    check(ccall((:wl_wpt_lifting, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                 Cdouble, Cdouble, Ptr{UInt8}, Int64, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), length(y), length(isup), isup, nc, sh, cf, scheme.norm1, scheme.norm2,
+                t, length(t), fw, stream()))
+    return y
+end
+
+# ---- dwtc / idwtc: named but never defined by the reference (transforms_main.jl:179-181)
+for (f, fw) in ((:dwtc, true), (:idwtc, false))
+    @eval function $f(x::ROCMatrix{T}, filter::OrthoFilter, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T}
+        y = similar(x)
+        check(ccall((:wl_dwtc_filter, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), pointer(x), size(x, 1), size(x, 2), size(x, 1),
+                    filter.qmf, length(filter.qmf), L, $fw, stream()))
+        return y
+    end
+end
+
+end # module

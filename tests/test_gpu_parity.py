@@ -113,6 +113,43 @@ def test_lifting_fwd_inv_bitexact(gpu, W, oracle, dtype, shape):
             assert np.array_equal(host(W, t), xr)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_lines_fast_paths(gpu, W, oracle, dtype):
+    """Fused lifting kernels (stream levels + LDS tail), forward / inverse / in place / batched, and
+    the generic family forced through wl_ctx_set_path(1): all bit-identical to the oracle."""
+    for n, Ls in (((1 << 16), (16, 1, 3)), (3 << 15, (15, 2)), ((1 << 18), (18, 5))):
+        x = rng_array((n,), dtype, n % 1000)
+        for sname in ("cdf97", "db2", "haar"):
+            sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+            for L in Ls:
+                ye = oracle.dwt_lifting(x, sch, L)
+                y = host(W, W.dwt(dev(W, x), sch, L))
+                assert "generic" not in W.last_kernel(), W.last_kernel()
+                assert np.array_equal(y, ye), (n, sname, L, "fwd", W.last_kernel())
+                t = dev(W, x)
+                W.dwt_(t, sch, L)                                   # in place
+                assert np.array_equal(host(W, t), ye), (n, sname, L, "fwd in place")
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (n, sname, L, "inv")
+                t = dev(W, ye)
+                W.idwt_(t, sch, L)
+                assert np.array_equal(host(W, t), xe), (n, sname, L, "inv in place")
+                try:
+                    W.set_kernel_path(1)
+                    yg = host(W, W.dwt(dev(W, x), sch, L))
+                    assert "generic" in W.last_kernel()
+                finally:
+                    W.set_kernel_path(0)
+                assert np.array_equal(yg, ye)
+    # batched columns: 24 signals of 2^15 samples
+    xb = rng_array((1 << 15, 24), dtype, 77)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    for L in (15, 2):
+        ye = oracle.dwtc_lifting(xb, sch, L)
+        assert np.array_equal(host(W, W.dwtc(dev(W, xb), sch, L)), ye)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ye), sch, L)), oracle.dwtc_lifting(ye, sch, L, fw=False))
+
+
 def test_lifting_equals_filter_on_gpu(gpu, W):
     """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
     for nd in (1, 2, 3):

@@ -13,4 +13,12 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                       T *y, const T *x, const Taps<T> &taps, int L,
                       const char **kernel_name, int *hip_err);
 
+// Lifting transform (forward or inverse) of `nlines` independent lines of length n (line stride ld):
+// 1-D vectors and batched columns.  Sets *handled = 1 when everything was enqueued by the fused
+// kernels of wl_lift.hip; otherwise enqueues nothing.
+template <typename T>
+int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
+                       T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
+                       int *handled, const char **kernel_name, int *hip_err);
+
 }  // namespace wl

@@ -1,0 +1,464 @@
+// wl_lift.hip -- lifting DWT/IDWT fast paths for lines (1-D vectors, batched columns).
+//
+//   k_lift1d_stream  one lifting level of a line, forward or inverse, ALL steps + split/merge +
+//                    normalisation fused (the reference makes >= 6 passes over the level:
+//                    split!, one pass per step, normalize!; transforms_lifting.jl:57-64).
+//                    Each lane holds 4 (s, d) pairs = 8 consecutive samples (two 16-byte loads);
+//                    a step's operands outside the lane come from the neighbouring lane by DPP
+//                    AFTER that lane's own update, so nothing is recomputed; the two edge lanes of
+//                    a wave absorb the dependency cone (reach <= 4 pairs), lanes 1..62 are stored.
+//                    One read + one write of the level: 8 B/sample (f32).
+//   k_tail_lift      every remaining level of a line <= 16 Ki f32 / 8 Ki f64 samples inside one
+//                    workgroup with the line in LDS (any scheme, true periodic indexing).
+//
+// Rounding follows the reference exactly: an element whose operands do not wrap is updated as
+// x += (c1*a + c2*b [+ c3*c]) (lift_inbounds!, transforms_lifting.jl:455-483), a wrapped one as
+// x += c1*a; x += c2*b; ... (lift_perboundary!, :437-451); no FMA contraction.
+#include "wl_fast.h"
+
+namespace wl {
+
+// ---- scheme shapes known at compile time (coefficients stay run-time data) -----------------------
+// direction-adjusted order (as produced by make_scheme): step i = {is_update, nc, shift}
+struct StepShape { int upd, nc, sh; };
+template <int ID> struct Shape;
+// cdf9/7 forward and inverse have the same shape sequence read in opposite order
+template <> struct Shape<0> { static constexpr int NS = 4; static constexpr StepShape S[4] = {{1, 2, 0}, {0, 2, 1}, {1, 2, 0}, {0, 2, 1}}; };   // cdf9/7 fw
+template <> struct Shape<1> { static constexpr int NS = 4; static constexpr StepShape S[4] = {{0, 2, 1}, {1, 2, 0}, {0, 2, 1}, {1, 2, 0}}; };   // cdf9/7 inv
+template <> struct Shape<2> { static constexpr int NS = 3; static constexpr StepShape S[3] = {{0, 1, 0}, {1, 2, 1}, {0, 1, -1}}; };             // db2 fw
+template <> struct Shape<3> { static constexpr int NS = 3; static constexpr StepShape S[3] = {{0, 1, -1}, {1, 2, 1}, {0, 1, 0}}; };             // db2 inv
+template <> struct Shape<4> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{0, 1, 0}, {1, 1, 0}}; };                          // haar/db1 fw
+template <> struct Shape<5> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{1, 1, 0}, {0, 1, 0}}; };                          // haar/db1 inv
+constexpr int kNumShapes = 6;
+
+template <int ID>
+static bool shape_matches(int nsteps, const int *upd, const int *nc, const int *sh)
+{
+    if (nsteps != Shape<ID>::NS) return false;
+    for (int i = 0; i < nsteps; ++i)
+        if (upd[i] != Shape<ID>::S[i].upd || nc[i] != Shape<ID>::S[i].nc || sh[i] != Shape<ID>::S[i].sh) return false;
+    return true;
+}
+
+__device__ __forceinline__ int l_dpp_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int l_dpp_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float l_next(float v) { return __int_as_float(l_dpp_next(__float_as_int(v))); }
+__device__ __forceinline__ float l_prev(float v) { return __int_as_float(l_dpp_prev(__float_as_int(v))); }
+__device__ __forceinline__ double l_next(double v) { return __hiloint2double(l_dpp_next(__double2hiint(v)), l_dpp_next(__double2loint(v))); }
+__device__ __forceinline__ double l_prev(double v) { return __hiloint2double(l_dpp_prev(__double2hiint(v)), l_dpp_prev(__double2loint(v))); }
+
+template <typename T>
+struct Lift1DArgs {
+    // forward: src = line of n samples; sdst/ddst = approximation / detail destinations (n/2 each)
+    // inverse: ssrc/dsrc = approximation / detail sources (n/2 each); dst = line of n samples
+    const T *a; int64_t a_ls;       // fw: src            inv: ssrc
+    const T *b; int64_t b_ls;       // fw: unused         inv: dsrc
+    T *o0; int64_t o0_ls;           // fw: sdst           inv: dst
+    T *o1; int64_t o1_ls;           // fw: ddst           inv: unused
+    int64_t n;                      // line length (multiple of 8, >= 512)
+    int64_t ntiles;
+    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T>
+__device__ __forceinline__ void ld8(const T *p, T (&v)[8])
+{
+    constexpr int C = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < 8 / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stN(T *p, const T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
+template <typename T, int ID, int FW>
+__global__ void __launch_bounds__(256) k_lift1d_stream(Lift1DArgs<T> a)
+{
+    constexpr int VP = 62 * 4;
+    typedef Shape<ID> SH;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t n = a.n, half = n >> 1;
+    const int64_t line = blockIdx.y;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k0 = tile * VP + (int64_t)(lane - 1) * 4;      // first pair of this lane (may wrap)
+        int64_t kw = k0;
+        if (kw < 0) kw += half;
+        if (kw >= half) kw -= half;
+        T s[4], d[4];
+        if (FW) {
+            T v[8];
+            ld8<T>(a.a + line * a.a_ls + 2 * kw, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] = v[2 * j]; d[j] = v[2 * j + 1]; }      // Util.split!
+        } else {
+            T sv[4], dv[4];
+            constexpr int C = 16 / sizeof(T);
+            typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+            for (int c = 0; c < 4 / C; ++c) {
+                V t0 = *reinterpret_cast<const V *>(a.a + line * a.a_ls + kw + c * C);
+                V t1 = *reinterpret_cast<const V *>(a.b + line * a.b_ls + kw + c * C);
+#pragma unroll
+                for (int i = 0; i < C; ++i) { sv[c * C + i] = t0[i]; dv[c * C + i] = t1[i]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] = a.norm1 * sv[j]; d[j] = a.norm2 * dv[j]; }   // normalize! (inverse first)
+        }
+#pragma unroll
+        for (int st = 0; st < SH::NS; ++st) {
+            const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+            // operands: the other half at pair offsets (kk - sh), kk = 0..nc-1
+            T *tgt = upd ? d : s;
+            const T *op = upd ? s : d;
+            // neighbour lanes' current operand values (after their own previous updates)
+            T opn[4], opp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { opn[j] = (T)0; opp[j] = (T)0; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // needed iff some jj + kk - sh lands on this element of the neighbour
+                bool need_n = false, need_p = false;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+                        if (kk < nc) {
+                            int off = jj + kk - sh;
+                            if (off - 4 == j) need_n = true;
+                            if (off + 4 == j) need_p = true;
+                        }
+                if (need_n) opn[j] = l_next(op[j]);
+                if (need_p) opp[j] = l_prev(op[j]);
+            }
+            T res[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                T o[3];
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    o[kk] = (T)0;
+                    if (kk < nc) {
+                        const int off = jj + kk - sh;
+                        o[kk] = (off < 0) ? opp[off + 4] : (off > 3 ? opn[off - 4] : op[off]);
+                    }
+                }
+                // in bounds <=> no operand wraps around the line: 0 <= j - sh and j + nc - 1 - sh <= half - 1
+                const int64_t jg = kw + jj - sh;
+                const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+                const T x = tgt[jj];
+                T acc = a.c[st][0] * o[0];
+                if (nc > 1) acc = acc + a.c[st][1] * o[1];
+                if (nc > 2) acc = acc + a.c[st][2] * o[2];
+                const T xin = x + acc;
+                T xb = x + a.c[st][0] * o[0];
+                if (nc > 1) xb = xb + a.c[st][1] * o[1];
+                if (nc > 2) xb = xb + a.c[st][2] * o[2];
+                res[jj] = inb ? xin : xb;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) tgt[jj] = res[jj];
+        }
+        const bool valid = lane >= 1 && lane <= 62 && k0 < half;
+        if (FW) {
+            T so[4], dO[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { so[j] = s[j] * a.norm1; dO[j] = d[j] * a.norm2; }     // normalize!
+            if (valid) {
+                stN<T, 4>(a.o0 + line * a.o0_ls + k0, so);
+                stN<T, 4>(a.o1 + line * a.o1_ls + k0, dO);
+            }
+        } else {
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = s[j]; v[2 * j + 1] = d[j]; }               // Util.merge!
+            if (valid) stN<T, 8>(a.o0 + line * a.o0_ls + 2 * k0, v);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// LDS tail: all remaining levels of one line per workgroup (any scheme)
+template <typename T>
+struct LiftTailArgs {
+    const T *src; int64_t src_item;     // fw: the line to transform (n0 samples)
+    T *y; int64_t y_item;               // output line; fw: details + final approximation; inv: samples
+    const T *ll; int64_t ll_item;       // inv only: approximation source of the deepest level (may equal y's LL)
+    int n0;                             // fw: input length;  inv: OUTPUT length of the last (shallowest) level done here
+    int nlev;
+    int cap;
+};
+
+template <typename T>
+__device__ __forceinline__ void tail_lift_steps(T *w, int half, const LiftScheme<T> &sc, int tid, int nthr)
+{
+    for (int st = 0; st < sc.nsteps; ++st) {
+        const LiftStep<T> &sp = sc.step[st];
+        T *tgt = w + (sp.is_update ? half : 0);
+        const T *op = w + (sp.is_update ? 0 : half);
+        for (int j = tid; j < half; j += nthr) {
+            const int j0 = j - sp.shift;
+            const bool inb = (j0 >= 0) && (j0 + sp.nc - 1 <= half - 1);
+            T x = tgt[j];
+            if (inb) {
+                T acc = sp.c[0] * op[j0];
+                if (sp.nc > 1) acc = acc + sp.c[1] * op[j0 + 1];
+                if (sp.nc > 2) acc = acc + sp.c[2] * op[j0 + 2];
+                x = x + acc;
+            } else {
+                for (int k = 0; k < sp.nc; ++k) {
+                    int i = j0 + k;
+                    while (i < 0) i += half;
+                    while (i >= half) i -= half;
+                    x = x + sp.c[k] * op[i];
+                }
+            }
+            tgt[j] = x;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+template <typename T, int FW>
+__global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftScheme<T> sc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *A = reinterpret_cast<T *>(smem_raw);       // current approximation (natural order)
+    T *W = A + a.cap;                             // [s ; d] work line
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    T *y = a.y + (int64_t)blockIdx.x * a.y_item;
+    if (FW) {
+        const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
+        int n = a.n0;
+        for (int i = tid; i < n; i += nthr) A[i] = src[i];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int half = n >> 1;
+            for (int j = tid; j < half; j += nthr) { W[j] = A[2 * j]; W[half + j] = A[2 * j + 1]; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            tail_lift_steps<T>(W, half, sc, tid, nthr);
+            const bool last = (lev == a.nlev - 1);
+            for (int j = tid; j < half; j += nthr) {
+                T s = W[j] * sc.norm1, d = W[half + j] * sc.norm2;
+                y[half + j] = d;
+                if (last) y[j] = s;
+                else A[j] = s;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            n = half;
+        }
+    } else {
+        // deepest level first: output lengths n0 >> (nlev-1), ..., n0
+        const T *ll = a.ll + (int64_t)blockIdx.x * a.ll_item;
+        const T *src = a.src + (int64_t)blockIdx.x * a.src_item;     // detail coefficients live in src (x)
+        int n = a.n0 >> (a.nlev - 1);
+        for (int j = tid; j < (n >> 1); j += nthr) A[j] = ll[j];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int half = n >> 1;
+            for (int j = tid; j < half; j += nthr) { W[j] = sc.norm1 * A[j]; W[half + j] = sc.norm2 * src[half + j]; }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            tail_lift_steps<T>(W, half, sc, tid, nthr);
+            const bool last = (lev == a.nlev - 1);
+            for (int j = tid; j < half; j += nthr) {
+                if (last) { y[2 * j] = W[j]; y[2 * j + 1] = W[half + j]; }
+                else { A[2 * j] = W[j]; A[2 * j + 1] = W[half + j]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            n <<= 1;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+constexpr int lift_tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }
+
+template <typename T, int ID, int FW>
+static void launch_stream_id(hipStream_t st, const Lift1DArgs<T> &a, int64_t nlines, int cu_count)
+{
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((k_lift1d_stream<T, ID, FW>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+}
+
+template <typename T>
+static int match_shape(const LiftScheme<T> &sc)
+{
+    int upd[WL_MAX_STEPS], nc[WL_MAX_STEPS], sh[WL_MAX_STEPS];
+    for (int i = 0; i < sc.nsteps; ++i) { upd[i] = sc.step[i].is_update; nc[i] = sc.step[i].nc; sh[i] = sc.step[i].shift; }
+    if (shape_matches<0>(sc.nsteps, upd, nc, sh)) return 0;
+    if (shape_matches<1>(sc.nsteps, upd, nc, sh)) return 1;
+    if (shape_matches<2>(sc.nsteps, upd, nc, sh)) return 2;
+    if (shape_matches<3>(sc.nsteps, upd, nc, sh)) return 3;
+    if (shape_matches<4>(sc.nsteps, upd, nc, sh)) return 4;
+    if (shape_matches<5>(sc.nsteps, upd, nc, sh)) return 5;
+    return -1;
+}
+
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Forward or inverse lifting transform of `nlines` lines (1-D vector: nlines = 1; batched columns).
+// Returns 1 in *handled when the whole transform was enqueued by the fast kernels.
+template <typename T>
+int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
+                       T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
+                       int *handled, const char **kernel_name, int *hip_err)
+{
+    *handled = 0;
+    constexpr int VEC = 16 / sizeof(T);
+    const int id = match_shape<T>(sc);
+    if (L < 1 || !al16(x) || !al16(y) || nlines > 65535) return WL_OK;
+    if (nlines > 1 && (ld % VEC) != 0) return WL_OK;
+    const int cap = lift_tail_cap<T>();
+    // every level must be either stream-able (known shape, n_l >= 512, n_l % 8 == 0) or inside the tail
+    int l_tail = L + 1;                       // first level (1-based) handled by the tail (fw) ...
+    for (int l = 1; l <= L; ++l) {
+        const int64_t nl = n >> (l - 1);
+        if (nl <= cap) { l_tail = l; break; }
+        if (id < 0 || nl < 512 || (nl % 8) != 0) return WL_OK;
+    }
+    const int64_t N = n * nlines;
+    Work<T> w = carve<T>(ws, N);
+    const size_t shmem = 2 * (size_t)cap * sizeof(T);
+    const char *dom = nullptr;
+#define WL_LAUNCH_ID(FWV)                                                                    \
+    switch (id) {                                                                            \
+    case 0: launch_stream_id<T, 0, FWV>(st, a, nlines, cu_count); break;                     \
+    case 1: launch_stream_id<T, 1, FWV>(st, a, nlines, cu_count); break;                     \
+    case 2: launch_stream_id<T, 2, FWV>(st, a, nlines, cu_count); break;                     \
+    case 3: launch_stream_id<T, 3, FWV>(st, a, nlines, cu_count); break;                     \
+    case 4: launch_stream_id<T, 4, FWV>(st, a, nlines, cu_count); break;                     \
+    default: launch_stream_id<T, 5, FWV>(st, a, nlines, cu_count); break;                    \
+    }
+#define WL_CHECK_LAUNCH()                                                                    \
+    do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } } while (0)
+
+    Lift1DArgs<T> a;
+    for (int i = 0; i < WL_MAX_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+
+    if (fw) {
+        const bool inplace = (y == x);
+        const T *cur = x;
+        int64_t cur_ls = ld;
+        int pp = 0;
+        for (int l = 1; l < l_tail && l <= L; ++l) {
+            const int64_t nl = n >> (l - 1), hl = nl >> 1;
+            const bool last = (l == L);
+            T *llbuf = pp ? w.B : w.A;
+            a.a = cur; a.a_ls = cur_ls; a.b = nullptr; a.b_ls = 0;
+            // in place, level 1 reads all of y while other waves would already write s / d into it:
+            // stage both halves in the workspace and copy them back afterwards
+            const bool stage = inplace && (l == 1);
+            a.o0 = (last && !stage) ? y : llbuf; a.o0_ls = (last && !stage) ? ld : hl;
+            a.o1 = stage ? w.W : (y + hl); a.o1_ls = stage ? hl : ld;
+            a.n = nl; a.ntiles = (hl + 247) / 248;
+            WL_LAUNCH_ID(1);
+            WL_CHECK_LAUNCH();
+            if (stage) {
+                Extent3 e = {{hl, nlines, 1}};
+                Strides3 s0 = {{1, hl, hl * nlines}}, s1 = {{1, ld, ld * nlines}};
+                hipError_t e2 = generic_copy_box<T>(st, w.W, s0, y + hl, s1, e);
+                if (e2 == hipSuccess && last) e2 = generic_copy_box<T>(st, llbuf, s0, y, s1, e);
+                if (e2 != hipSuccess) { if (hip_err) *hip_err = (int)e2; return WL_EHIP; }
+            }
+            if (!dom) dom = "k_lift1d_stream";
+            cur = llbuf; cur_ls = hl; pp ^= 1;
+        }
+        if (l_tail <= L) {
+            LiftTailArgs<T> t;
+            const int64_t nl = n >> (l_tail - 1);
+            t.src = cur; t.src_item = cur_ls; t.y = y; t.y_item = ld; t.ll = nullptr; t.ll_item = 0;
+            t.n0 = (int)nl; t.nlev = L - l_tail + 1; t.cap = cap;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }
+            int threads = nl >= 4096 ? 1024 : (nl >= 512 ? 256 : 64);
+            hipLaunchKernelGGL((k_tail_lift<T, 1>), dim3((unsigned)nlines), dim3(threads), shmem, st, t, sc);
+            WL_CHECK_LAUNCH();
+            if (!dom) dom = "k_tail_lift";
+        }
+    } else {
+        // inverse: levels L..1; the tail does the deepest levels (outputs up to `cap` samples)
+        const T *llsrc = x;                  // approximation source of the current level
+        int64_t ll_ls = ld;
+        int l = L;
+        int pp = 0;
+        // deepest levels whose OUTPUT fits the tail: output length of level l is n >> (l-1)
+        int l_hi = L;                        // tail covers levels L .. l_lo
+        int l_lo = L + 1;
+        for (int q = L; q >= 1; --q) { if ((n >> (q - 1)) <= cap) l_lo = q; else break; }
+        if (l_lo <= L) {
+            LiftTailArgs<T> t;
+            const int64_t nout = n >> (l_lo - 1);
+            const bool to_y = (l_lo == 1);
+            T *out = to_y ? y : (pp ? w.B : w.A);
+            t.src = x; t.src_item = ld; t.ll = x; t.ll_item = ld;
+            t.y = out; t.y_item = to_y ? ld : nout;
+            t.n0 = (int)nout; t.nlev = l_hi - l_lo + 1; t.cap = cap;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }
+            int threads = nout >= 4096 ? 1024 : (nout >= 512 ? 256 : 64);
+            hipLaunchKernelGGL((k_tail_lift<T, 0>), dim3((unsigned)nlines), dim3(threads), shmem, st, t, sc);
+            WL_CHECK_LAUNCH();
+            if (!dom) dom = "k_tail_lift";
+            llsrc = out; ll_ls = t.y_item; pp ^= 1;
+            l = l_lo - 1;
+        }
+        for (; l >= 1; --l) {
+            const int64_t nl = n >> (l - 1), hl = nl >> 1;
+            const bool to_y = (l == 1);
+            T *out = to_y ? y : (pp ? w.B : w.A);
+            a.a = llsrc; a.a_ls = ll_ls; a.b = x + hl; a.b_ls = ld;
+            // in place (y == x), level 1 writes all of y while detail d1 = y[n/2..n) is still being read
+            // by other waves: stage the output in the work buffer and copy back
+            const bool stage = to_y && (y == x);
+            a.o0 = stage ? w.W : out; a.o0_ls = stage ? nl : (to_y ? ld : nl);
+            a.o1 = nullptr; a.o1_ls = 0;
+            a.n = nl; a.ntiles = (hl + 247) / 248;
+            WL_LAUNCH_ID(0);
+            WL_CHECK_LAUNCH();
+            if (stage) {
+                Extent3 e = {{nl, nlines, 1}};
+                Strides3 s0 = {{1, nl, nl * nlines}}, s1 = {{1, ld, ld * nlines}};
+                hipError_t e2 = generic_copy_box<T>(st, w.W, s0, y, s1, e);
+                if (e2 != hipSuccess) { if (hip_err) *hip_err = (int)e2; return WL_EHIP; }
+            }
+            dom = "k_lift1d_stream";
+            llsrc = out; ll_ls = nl; pp ^= 1;
+        }
+    }
+#undef WL_LAUNCH_ID
+#undef WL_CHECK_LAUNCH
+    *handled = 1;
+    if (kernel_name) *kernel_name = dom ? dom : "none";
+    return WL_OK;
+}
+
+template int lifting_lines_fast<float>(void *, int, hipStream_t, int64_t, int64_t, int64_t, float *, const float *,
+                                       const LiftScheme<float> &, int, int, int *, const char **, int *);
+template int lifting_lines_fast<double>(void *, int, hipStream_t, int64_t, int64_t, int64_t, double *, const double *,
+                                        const LiftScheme<double> &, int, int, int *, const char **, int *);
+
+}  // namespace wl

@@ -70,18 +70,23 @@ def test_filter_fwd_inv_bitexact(gpu, W, oracle, dtype, shape):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fast_and_generic_paths_agree(gpu, W, oracle, dtype):
     """wl_ctx_set_path(1) forces the generic kernels; both families must give identical bits."""
-    for shape, L in (((1 << 18,), 18), ((1 << 18,), 3), ((1024, 1024), 10), ((512, 2048), 4), ((2048, 256), 8),
+    for shape, L in (((1 << 18,), 18), ((1 << 18,), 3), ((69632,), 12), ((69632,), 2), ((98304,), 15), ((1 << 20,), 5),
+                     ((69632, 3), 0), ((1024, 1024), 10), ((512, 2048), 4), ((2048, 256), 8),
                      ((64, 64, 64), 6)):
         x = rng_array(shape, dtype, 99)
         for fname in ("db4", "db2", "haar", "db3", "sym4"):
             wt = W.wavelet(getattr(W.WT, fname))
+            if L == 0:      # batched columns (dwtc), full depth of the column length
+                fn = lambda t: W.dwtc(t, wt)
+            else:
+                fn = lambda t: W.dwt(t, wt, L)
             try:
                 W.set_kernel_path(1)
-                yg = host(W, W.dwt(dev(W, x), wt, L))
+                yg = host(W, fn(dev(W, x)))
                 kg = W.last_kernel()
             finally:
                 W.set_kernel_path(0)
-            yf = host(W, W.dwt(dev(W, x), wt, L))
+            yf = host(W, fn(dev(W, x)))
             assert "generic" in kg
             assert np.array_equal(yg, yf), (shape, L, fname, W.last_kernel(), np.abs(yg - yf).max())
 

@@ -97,6 +97,13 @@ __device__ __forceinline__ void vstore16(T *p, const T (&v)[N])
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
+// release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); kernels that
+// stream results to HBM between barriers and never read them back do not need that.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and one that also drains this wave's global loads (after staging HBM data into LDS)
+__device__ __forceinline__ void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr __host__ __device__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // Whole-wave lane shifts on the VALU (DPP wave_shl:1 / wave_shr:1 -- gfx9-family controls, valid
@@ -439,6 +446,126 @@ __global__ void __launch_bounds__(256) k_fwd1d_stream(Fwd1DArgs<T, F> a)
     }
 }
 
+
+// ==========================================================================================
+// 1-D multi-level tile kernel: NL (<= 6) consecutive levels of a line in ONE pass over HBM.
+// A workgroup owns TS input samples, loads them plus a halo of H0 = (F-2)(2^NL - 1) samples on
+// each side into LDS (periodic wrap resolved while staging), then runs the levels LDS -> LDS:
+// at level t the local array covers the owned range widened by H_t = (F-2)(2^(NL-t) - 1), so pair i
+// of level t reads the fixed window [2i, 2i + 2F - 2) of level t-1 -- no index arithmetic, no wrap,
+// and two adjacent pairs are four aligned ds_read_b128.  Details of the owned range stream to their
+// final place in y, the last approximation goes to the next stage.  Traffic: read n + write n for NL
+// levels (the level-by-level scheme moves (4 - 2^(2-NL)) n); halo re-reads are 2*H0/TS (~2 %).
+template <typename T, int F>
+struct Multi1DArgs {
+    const T *src; int64_t src_ls;
+    T *y; int64_t y_ls;             // detail level t (1..NL) goes to y[(n >> t) + k]
+    T *sdst; int64_t s_ls;          // approximation after NL levels
+    int64_t n;                      // line length entering this stage
+    int NL, TS;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F, int LVL1>
+__global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int VEC = 16 / sizeof(T);
+    const int tid = threadIdx.x;
+    const int64_t n = a.n;
+    const int NL = a.NL;
+    int H[8];
+    H[NL] = 0;
+    for (int t = NL; t >= 1; --t) H[t - 1] = 2 * H[t] + (F - 2);
+    const int64_t own0 = (int64_t)blockIdx.x * a.TS;
+    const int own_len = (int)((own0 + a.TS <= n) ? a.TS : (n - own0));
+    const int lenA = own_len + 2 * H[0];
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + ((a.TS + 2 * H[0] + 7) & ~7);
+    const T *src = a.src + (int64_t)blockIdx.y * a.src_ls;
+    T *y = a.y + (int64_t)blockIdx.y * a.y_ls;
+
+    // stage: A[j] = x[(own0 - H0 + j) mod n], 16-byte chunks at aligned global positions
+    {
+        const int64_t start = own0 - H[0];
+        const int r = (int)(((start % VEC) + VEC) % VEC);
+        const int64_t astart = start - r;
+        const int nch = (lenA + r + VEC - 1) / VEC;
+        // all of a thread's chunk loads are issued before the first LDS write (up to 10 in flight)
+        constexpr int UL = 10;
+        for (int c0 = tid; c0 < nch; c0 += UL * 256) {
+            T v[UL][VEC];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int c = c0 + u * 256;
+                if (c < nch) {
+                    int64_t gidx = astart + (int64_t)c * VEC;
+                    if (gidx < 0) gidx += n;
+                    if (gidx >= n) gidx -= n;
+                    vload<T, VEC>(src + gidx, v[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int c = c0 + u * 256;
+                if (c < nch) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int j = c * VEC + e - r;
+                        if (j >= 0 && j < lenA) bufA[j] = v[u][e];
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier_vm();
+    T *Ain = bufA, *Aout = bufB;
+    for (int t = 1; t <= NL; ++t) {
+        const int ownt = own_len >> t;
+        const int Lout = ownt + 2 * H[t];
+        const int64_t k0 = own0 >> t;                 // global index of the first owned pair
+        T *dd = y + (n >> t);
+        const bool lastlev = (t == NL);
+        T *sg = a.sdst + (int64_t)blockIdx.y * a.s_ls;
+        for (int i = 2 * tid; i < Lout; i += 2 * 256) {
+            T xv[2 * F];
+            vload16<T, 2 * F>(Ain + 2 * i, xv);       // window of pairs i and i+1 (2i is a multiple of 4)
+            T so[2], dO[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                T sv = a.tp.h[0] * xv[2 * q + F - 2];
+#pragma unroll
+                for (int m = 1; m < F; ++m) sv = sv + a.tp.h[m] * xv[2 * q + F - 2 + m];
+                T dv = a.tp.g[F - 1] * xv[2 * q];
+#pragma unroll
+                for (int m = F - 2; m >= 0; --m) dv = dv + a.tp.g[m] * xv[2 * q + F - 1 - m];
+                so[q] = sv;
+                dO[q] = dv;
+            }
+            const bool two = (i + 1) < Lout;
+            const int io = i - H[t];                  // owned iff 0 <= io < ownt
+            if (!lastlev) {
+                Aout[i] = so[0];
+                if (two) Aout[i + 1] = so[1];
+            }
+            if (io >= 0 && io < ownt) {
+                if (two && io + 1 < ownt) {
+                    vstore<T, 2>(dd + k0 + io, dO);
+                    if (lastlev) vstore<T, 2>(sg + k0 + io, so);
+                } else {
+                    dd[k0 + io] = dO[0];
+                    if (lastlev) sg[k0 + io] = so[0];
+                }
+            } else if (two && io + 1 >= 0 && io + 1 < ownt) {
+                dd[k0 + io + 1] = dO[1];
+                if (lastlev) sg[k0 + io + 1] = so[1];
+            }
+        }
+        lds_barrier();
+        T *tmp = Ain; Ain = Aout; Aout = tmp;
+    }
+}
+
 // ==========================================================================================
 // tail: all remaining levels of a small block inside one workgroup, block resident in LDS
 template <typename T>
@@ -452,14 +579,6 @@ struct TailArgs {
     int cap;                        // elements per LDS buffer
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
-// release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); the tail kernel
-// streams its detail coefficients to HBM between barriers and nothing in the kernel reads them back,
-// so waiting for them (~1-2 us per barrier, 14 barriers) was most of its run time.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 __device__ __forceinline__ int wrap_idx(int i, int n)
 {
     // periodic index without integer division: one trip for n >= F, a few for tiny lines
@@ -657,7 +776,9 @@ static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src,
 {
     TailArgs<T> a;
     a.src = src; a.s1 = s1; a.y = y; a.ldy = ldy; a.src_item = src_item; a.y_item = y_item;
-    a.m0 = m0; a.m1 = m1; a.nt = nt; a.nlev = nlev; a.cap = tail_lds_elems<T>();
+    // right-sized LDS (two buffers of the padded block) so that several small blocks share a CU
+    a.m0 = m0; a.m1 = m1; a.nt = nt; a.nlev = nlev;
+    a.cap = (int)((((int64_t)(m1 > 1 ? (m0 | 1) : m0) * m1) + 15) & ~15);
     const size_t shmem = 2 * (size_t)a.cap * sizeof(T);
     int64_t work = (int64_t)m0 * m1 / 2;
     int threads = work >= 4096 ? 1024 : (work >= 512 ? 256 : 64);
@@ -720,6 +841,27 @@ static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     return hipGetLastError();
 }
 
+
+template <typename T, int F>
+static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t src_ls,
+                                     T *y, int64_t y_ls, T *sdst, int64_t s_ls, int64_t n, int64_t nlines, int NL)
+{
+    Multi1DArgs<T, F> a;
+    a.src = src; a.src_ls = src_ls; a.y = y; a.y_ls = y_ls; a.sdst = sdst; a.s_ls = s_ls; a.n = n; a.NL = NL;
+    // tile = 32 KiB of input for long lines; shorter tiles (down to 4 KiB) when there would otherwise be
+    // fewer workgroups than CUs -- a workgroup's latency chain (stage, NL levels, barriers) is ~constant
+    a.TS = env_int("WL_TS", (int)(16384 / sizeof(T)));
+    while (a.TS > (int)(4096 / sizeof(T)) && ((n + a.TS - 1) / a.TS) * nlines < 512) a.TS >>= 1;
+    a.tp = shrink<T, F>(taps);
+    const int H0 = (F - 2) * ((1 << NL) - 1), H1 = (F - 2) * ((1 << (NL - 1)) - 1);
+    const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + (size_t)(a.TS / 2 + 2 * H1 + 8);
+    const size_t shmem = elems * sizeof(T);
+    const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
+    if (lvl1) hipLaunchKernelGGL((k_fwd1d_multi<T, F, 1>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
+    else hipLaunchKernelGGL((k_fwd1d_multi<T, F, 0>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
 #define WL_DISPATCH_F(F_, ...)                               \
     switch (F_) {                                            \
     case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
@@ -754,7 +896,9 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
     const T *cur = x;
     Strides3 cur_st = b.full;
     int pp = 0;
-    for (int l = 1; l <= L; ++l) {
+    int lstep = 1;
+    for (int l = 1; l <= L; l += lstep) {
+        lstep = 1;
         int64_t n[3];
         level_box(b, l, n);
         Extent3 ext = {{n[0], n[1], n[2]}};
@@ -778,6 +922,29 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             }
         }
         bool done = false;
+        // ---- 1-D multi-level tile kernel: up to 4 levels per pass over HBM ----
+        if (fastF && lines && env_int("WL_NO_MULTI", 0) == 0 && n[0] > tail_cap<T>() && (n[0] % (8 * VEC)) == 0 &&
+            cur_st.s[0] == 1 && aligned16(cur) && aligned16(y) && nlines <= 65535 &&
+            (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0))) {
+            int NL = L - l + 1;
+            const int nlmax = env_int("WL_NLMAX", 4);
+            if (NL > nlmax) NL = nlmax;
+            while (NL > 1 && (n[0] % ((int64_t)(1 << NL) * 4 * VEC)) != 0) --NL;   // alignment of every level's stores
+            const bool lastm = (l + NL - 1 == L);
+            // after NL levels the approximation has n >> NL samples per line
+            T *sd = lastm ? y : llbuf;
+            const int64_t sls = lastm ? b.full.s[1] : (n[0] >> NL);
+            WL_DISPATCH_F(F, WL_TRY((launch_fwd1d_multi<T, FF>(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], sd, sls,
+                                                               n[0], nlines, NL)));
+                          done = true);
+            if (done) {
+                if (!dominant) dominant = "k_fwd1d_multi";
+                lstep = NL;
+                int64_t hn2[3] = {n[0] >> NL, n[1], n[2]};
+                cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                continue;
+            }
+        }
         // ---- streaming 2-D level ----
         if (fastF && two_d && n[0] >= 64 * VEC && (n[0] % 8) == 0 && n[1] >= 16 && (n[1] % 16) == 0 &&
             cur_st.s[0] == 1 && (cur_st.s[1] % VEC) == 0 && aligned16(cur) &&

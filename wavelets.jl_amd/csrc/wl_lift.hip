@@ -338,7 +338,6 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     }
     const int64_t N = n * nlines;
     Work<T> w = carve<T>(ws, N);
-    const size_t shmem = 2 * (size_t)cap * sizeof(T);
     const char *dom = nullptr;
 #define WL_LAUNCH_ID(FWV)                                                                    \
     switch (id) {                                                                            \
@@ -389,7 +388,8 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             LiftTailArgs<T> t;
             const int64_t nl = n >> (l_tail - 1);
             t.src = cur; t.src_item = cur_ls; t.y = y; t.y_item = ld; t.ll = nullptr; t.ll_item = 0;
-            t.n0 = (int)nl; t.nlev = L - l_tail + 1; t.cap = cap;
+            t.n0 = (int)nl; t.nlev = L - l_tail + 1; t.cap = (int)((nl + 15) & ~15);
+            const size_t shmem = 2 * (size_t)t.cap * sizeof(T);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }
@@ -415,7 +415,8 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             T *out = to_y ? y : (pp ? w.B : w.A);
             t.src = x; t.src_item = ld; t.ll = x; t.ll_item = ld;
             t.y = out; t.y_item = to_y ? ld : nout;
-            t.n0 = (int)nout; t.nlev = l_hi - l_lo + 1; t.cap = cap;
+            t.n0 = (int)nout; t.nlev = l_hi - l_lo + 1; t.cap = (int)((nout + 15) & ~15);
+            const size_t shmem = 2 * (size_t)t.cap * sizeof(T);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }

@@ -69,6 +69,29 @@ __device__ __forceinline__ void vstore(T *p, const T (&v)[N])
         *reinterpret_cast<V *>(p) = t;
     }
 }
+template <typename T, int N>
+__device__ __forceinline__ void vload_nt(const T *p, T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    V t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+    if constexpr (N == 1) v[0] = t;
+    else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void vstore_nt(T *p, const T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    if constexpr (N == 1) __builtin_nontemporal_store(v[0], p);
+    else {
+        V t;
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = v[i];
+        __builtin_nontemporal_store(t, reinterpret_cast<V *>(p));
+    }
+}
 // 16-byte-granular load/store of N elements (N*sizeof(T) may exceed 16 bytes)
 template <typename T, int N>
 __device__ __forceinline__ void vload16(const T *p, T (&v)[N])
@@ -256,6 +279,7 @@ struct Fwd2DArgs {
     T *ll; int64_t ldll;            // approximation buffer for the next level (or nullptr)
     int64_t ms, ns;
     int TJ;                         // input columns per chunk (even)
+    int nt;                         // bit 0: nontemporal loads, bit 1: nontemporal stores
     int nstrips, nchunks;
     TapsF<T, F> tp;
 };
@@ -267,13 +291,17 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     constexpr int VR = 64 * RPL - 16;      // rows of output responsibility per wave
     constexpr int NO = RPL / 2;            // output rows per lane per subband
     constexpr int SH = (F - 2) / 2;        // detail-column shift
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 
-    // XCD-aware bijective remap: consecutive logical ids (strip fastest) share an XCD's L2,
-    // so the 16-row overlap of neighbouring strips is an L2 hit.
+    // XCD-aware bijective remap: consecutive logical ids (strip fastest) share an XCD's L2 -- and the
+    // WPB waves of a workgroup (adjacent strips of one chunk) a CU's L1 -- so the 16-row overlap of
+    // neighbouring strips is a cache hit.
+    const uint32_t wpb = blockDim.x >> 6;
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const uint32_t lwg = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const uint32_t logical = lwg * wpb + (threadIdx.x >> 6);
+    if (logical >= (uint32_t)(a.nstrips * a.nchunks)) return;
     const int strip = (int)(logical % (uint32_t)a.nstrips);
     const int chunk = (int)(logical / (uint32_t)a.nstrips);
 
@@ -301,7 +329,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     for (int c = 0; c < R - 2; ++c) {
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
-        vload<T, RPL>(base + jc * a.lds, ring[c]);
+        if (a.nt & 1) vload_nt<T, RPL>(base + jc * a.lds, ring[c]); else vload<T, RPL>(base + jc * a.lds, ring[c]);
     }
 
     T *const yl = a.y + ko;
@@ -316,7 +344,8 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
             for (int e = 0; e < 2; ++e) {
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
-                vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+                if (a.nt & 1) vload_nt<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+                else vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
             }
         }
         // dim-2 pass in registers on row pairs (adjacent registers of the 16-byte loads):
@@ -382,8 +411,8 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
                 // even: LL / ds of column k at row ko;   odd: sd / dd of column kd at row ko-2
                 T *pP = odd ? (yl - NO + (nxj + kd) * a.ldy) : (llp + k * ldl);
                 T *pQ = odd ? (yl - NO + (nxj + kd) * a.ldy + hm) : (yl + k * a.ldy + hm);
-                vstore<T, 4>(pP, vP);
-                vstore<T, 4>(pQ, vQ);
+                if (a.nt & 2) { vstore_nt<T, 4>(pP, vP); vstore_nt<T, 4>(pQ, vQ); }
+                else { vstore<T, 4>(pP, vP); vstore<T, 4>(pQ, vQ); }
             }
         } else {
             if (valid) {
@@ -563,6 +592,129 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
         }
         lds_barrier();
         T *tmp = Ain; Ain = Aout; Aout = tmp;
+    }
+}
+
+
+// ==========================================================================================
+// 2-D multi-level tile kernel for the small, cache-resident levels: NL (1 or 2) consecutive 2-D
+// levels per launch.  A workgroup owns an OT x OT piece of the input block, stages it with a halo
+// of H0 = (F-2)(2^NL - 1) on every side into LDS (periodic wrap resolved while staging) and runs
+// dim-2 pass / dim-1 pass / next level entirely LDS -> LDS with fixed windows (same indexing as
+// k_fwd1d_multi, per dimension).  Halo work is recomputed instead of exchanged, so workgroups are
+// independent; the redundant reads hit L2 (these levels are <= 16 MiB).  Replaces the per-level
+// launches whose cost was a ~7 us latency chain each, and shrinks what is left for k_tail_fwd.
+template <typename T, int F>
+struct Multi2DArgs {
+    const T *src; int64_t lds;      // input block M x N
+    T *y; int64_t ldy;
+    T *ll; int64_t ldll;            // approximation after NL levels (dense buffer or y itself)
+    int M, N;
+    int NL, OT;
+    int ld0;                        // LDS leading dimension of the staged tile (multiple of 4)
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F>
+__device__ __forceinline__ void window_pair(const T (&xv)[2 * F - 2], const TapsF<T, F> &tp, T &sv, T &dv)
+{
+    sv = tp.h[0] * xv[F - 2];
+#pragma unroll
+    for (int m = 1; m < F; ++m) sv = sv + tp.h[m] * xv[F - 2 + m];
+    dv = tp.g[F - 1] * xv[0];
+#pragma unroll
+    for (int m = F - 2; m >= 0; --m) dv = dv + tp.g[m] * xv[F - 1 - m];
+}
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256) k_fwd2d_multi(Multi2DArgs<T, F> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int NL = a.NL;
+    int H[4];
+    H[NL] = 0;
+    for (int t = NL; t >= 1; --t) H[t - 1] = 2 * H[t] + (F - 2);
+    const int r0 = blockIdx.x * a.OT, c0 = blockIdx.y * a.OT;     // owned origin (input coordinates)
+    const int S0 = a.OT + 2 * H[0];
+    const int ld = a.ld0;
+    T *A = reinterpret_cast<T *>(smem_raw);                        // S x S (current level input), ld
+    T *Rs = A + (size_t)ld * S0;                                   // S x Lout, ld
+    T *Rd = Rs + (size_t)ld * ((S0 - (F - 2)) / 2 + 1);
+
+    // stage A[i + j*ld] = X[(r0 - H0 + i) mod M, (c0 - H0 + j) mod N]
+    {
+        const int total = S0 * S0;
+        constexpr int UL = 8;
+        for (int e0 = tid; e0 < total; e0 += UL * 256) {
+            T v[UL];
+            int li[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int e = e0 + u * 256;
+                if (e < total) {
+                    const int j = e / S0, i = e - j * S0;
+                    int gr = r0 - H[0] + i, gc = c0 - H[0] + j;
+                    if (gr < 0) gr += a.M;
+                    if (gr >= a.M) gr -= a.M;
+                    if (gc < 0) gc += a.N;
+                    if (gc >= a.N) gc -= a.N;
+                    v[u] = a.src[gr + (int64_t)gc * a.lds];
+                    li[u] = i + j * ld;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (e0 + u * 256 < total) A[li[u]] = v[u];
+        }
+    }
+    lds_barrier_vm();
+    int S = S0;
+    for (int t = 1; t <= NL; ++t) {
+        const int own = a.OT >> t;
+        const int Lout = own + 2 * H[t];
+        // dim-2 pass: rows i in [0,S), column pairs c in [0,Lout): window A[i, 2c .. 2c+2F-3]
+        for (int e = tid; e < S * Lout; e += 256) {
+            const int c = e / S, i = e - c * S;
+            T xv[2 * F - 2];
+#pragma unroll
+            for (int q = 0; q < 2 * F - 2; ++q) xv[q] = A[i + (2 * c + q) * ld];
+            T sv, dv;
+            window_pair<T, F>(xv, a.tp, sv, dv);
+            Rs[i + c * ld] = sv;
+            Rd[i + c * ld] = dv;
+        }
+        lds_barrier();
+        // dim-1 pass: columns c in [0,Lout) of Rs and Rd, row pairs r in [0,Lout)
+        const int Mt = a.M >> t, Nt = a.N >> t;                    // quadrant extents of this level
+        const int gr0 = (r0 >> t) - H[t], gc0 = (c0 >> t) - H[t];
+        const bool lastlev = (t == NL);
+        for (int e = tid; e < 2 * Lout * Lout; e += 256) {
+            const int which = e / (Lout * Lout);                   // 0: from Rs (s_j), 1: from Rd (d_j)
+            const int e2 = e - which * Lout * Lout;
+            const int c = e2 / Lout, r = e2 - c * Lout;
+            const T *Rp = which ? Rd : Rs;
+            T xv[2 * F - 2];
+#pragma unroll
+            for (int q = 0; q < 2 * F - 2; ++q) xv[q] = Rp[2 * r + q + c * ld];
+            T sv, dv;
+            window_pair<T, F>(xv, a.tp, sv, dv);
+            const int ro = r - H[t], co = c - H[t];
+            const bool owned = ro >= 0 && ro < own && co >= 0 && co < own;
+            const int64_t grow = gr0 + r, gcol = gc0 + c;          // global coordinates inside the quadrant
+            if (which == 0) {
+                if (!lastlev) A[r + c * ld] = sv;                  // LL of this level -> next level input
+                if (owned) {
+                    if (lastlev) a.ll[grow + gcol * a.ldll] = sv;
+                    a.y[(Mt + grow) + gcol * a.ldy] = dv;          // d_i(s_j)
+                }
+            } else if (owned) {
+                a.y[grow + (Nt + gcol) * a.ldy] = sv;              // s_i(d_j)
+                a.y[(Mt + grow) + (Nt + gcol) * a.ldy] = dv;      // d_i(d_j)
+            }
+        }
+        lds_barrier();
+        S = Lout;
     }
 }
 
@@ -800,15 +952,15 @@ static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src,
     return hipGetLastError();
 }
 
-template <typename T, int F>
-static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
-                               T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+template <typename T, int F, int RPL>
+static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
+                                 T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
 {
-    constexpr int RPL = 16 / sizeof(T);
     constexpr int VR = 64 * RPL - 16;
     Fwd2DArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
     a.nstrips = (int)((ms + VR - 1) / VR);
+    a.nt = env_int("WL_NT", 0);
     int TJ = env_int("WL_TJ", 128);
     // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
     // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16
@@ -818,11 +970,24 @@ static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.tp = shrink<T, F>(taps);
-    const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
-    if (env_int("WL_PROBE", 0) == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64), 0, st, a);
-    else if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64), 0, st, a);
+    const unsigned wpb = 1;      // waves per workgroup (4-wave workgroups measured no faster)
+    const unsigned nwg = ((unsigned)(a.nstrips * a.nchunks) + wpb - 1) / wpb;
+    if (env_int("WL_PROBE", 0) == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    else if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     return hipGetLastError();
+}
+
+template <typename T, int F>
+static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
+                               T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    constexpr int RPL = 16 / sizeof(T);
+    if constexpr (sizeof(T) == 4 && F <= 8) {
+        if (env_int("WL_RPL", 4) == 8 && ms >= 1024 && (ms % 16) == 0)
+            return launch_fwd2d_r<T, F, 8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    }
+    return launch_fwd2d_r<T, F, RPL>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
 }
 
 template <typename T, int F>
@@ -859,6 +1024,32 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
     if (lvl1) hipLaunchKernelGGL((k_fwd1d_multi<T, F, 1>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
     else hipLaunchKernelGGL((k_fwd1d_multi<T, F, 0>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
+
+template <typename T, int F>
+static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const T *src, int64_t lds, T *y, int64_t ldy,
+                                     T *ll, int64_t ldll, int M, int N, int NL)
+{
+    Multi2DArgs<T, F> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.M = M; a.N = N; a.NL = NL;
+    // owned tile: 64 x 64 inputs, smaller while there would be fewer than ~64 workgroups
+    int OT = 64;
+    const int mn = M < N ? M : N;
+    while (OT > 16 && ((int64_t)(M / OT) * (N / OT) < 64 || OT > mn)) OT >>= 1;
+    a.OT = OT;
+    const int H0 = (F - 2) * ((1 << NL) - 1);
+    const int S0 = OT + 2 * H0;
+    a.ld0 = (S0 + 3) & ~3;
+    a.tp = shrink<T, F>(taps);
+    const int L1 = (S0 - (F - 2)) / 2 + 1;
+    const size_t elems = (size_t)a.ld0 * S0 + 2 * (size_t)a.ld0 * L1 + 16;
+    const size_t shmem = elems * sizeof(T);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_multi<T, F>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fwd2d_multi<T, F>), dim3((unsigned)(M / OT), (unsigned)(N / OT)), dim3(256), shmem, st, a);
     return hipGetLastError();
 }
 
@@ -909,6 +1100,26 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         Strides3 ll_st = dense_strides(hn);
         Strides3 box_st = dense_strides(n);
 
+        // ---- 2-D multi-level tiles for the cache-resident levels (two levels per launch) ----
+        if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 128) &&
+            n[1] <= env_int("WL_M2D_MAX", 128) && n[0] >= 64 && n[1] >= 64 && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
+            cur_st.s[0] == 1) {
+            int NL = (L - l + 1) >= 2 ? 2 : 1;
+            const bool lastm = (l + NL - 1 == L);
+            T *lld = lastm ? y : llbuf;
+            const int64_t ldd = lastm ? b.full.s[1] : (n[0] >> NL);
+            bool ok = false;
+            WL_DISPATCH_F(F, WL_TRY((launch_fwd2d_multi<T, FF>(st, taps, cur, cur_st.s[1], y, b.full.s[1], lld, ldd,
+                                                               (int)n[0], (int)n[1], NL)));
+                          ok = true);
+            if (ok) {
+                if (!dominant) dominant = "k_fwd2d_multi";
+                lstep = NL;
+                int64_t hn2[3] = {n[0] >> NL, n[1] >> NL, n[2]};
+                cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                continue;
+            }
+        }
         // ---- LDS-resident tail: finishes every remaining level in one launch ----
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];

@@ -46,7 +46,7 @@ def test_golden_nonsquare_on_gpu(gpu, W, oracle):
 
 # ---- filter bank, all ranks / sizes / levels -----------------------------------------------------
 SHAPES = [(2,), (8,), (40,), (96,), (1024,), (4096,), (1 << 16,),
-          (2, 2), (8, 8), (4, 8), (24, 40), (64, 64), (96, 32), (256, 128), (512, 512), (128, 1024),
+          (2, 2), (8, 8), (4, 8), (24, 40), (64, 64), (96, 32), (256, 128), (512, 512), (128, 1024), (1024, 512),
           (2, 2, 2), (8, 8, 8), (16, 8, 32), (32, 32, 32), (24, 8, 40)]
 FILTERS = ["haar", "db2", "db4", "db3", "sym8", "coif6", "batt2"]
 

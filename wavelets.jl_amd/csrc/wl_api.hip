@@ -93,44 +93,6 @@ int make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, cons
 }
 
 // ---- generic filter level loops ----------------------------------------------------------
-template <typename T>
-int generic_filter_inv(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
-                       const Taps<T> &taps, int L)
-{
-    int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
-    Work<T> w = carve<T>(ctx->ws, N);
-    // reconstruction ping-pong: level l output box has N/2^(nt*(l-1)) elements; for l >= 2
-    // that is <= N/2, so A/B (N/2 each) suffice.
-    int pp = 0;
-    const T *llsrc = nullptr;
-    Strides3 llsrc_st = {{0, 0, 0}};
-    for (int l = L; l >= 1; --l) {
-        int64_t n[3];
-        level_box(b, l, n);
-        Extent3 ext = {{n[0], n[1], n[2]}};
-        Extent3 lo = low_corner(b, n);
-        Strides3 box_st = dense_strides(n);
-        const T *in = x;
-        Strides3 in_st = b.full;
-        int tog = 0;
-        T *res = nullptr;
-        for (int a = 0; a < b.nt; ++a) {
-            const bool firstp = (a == 0), lastp = (a == b.nt - 1);
-            T *out; Strides3 out_st;
-            if (lastp) {
-                if (l == 1) { out = y; out_st = b.full; }
-                else { out = pp ? w.B : w.A; out_st = box_st; }
-                res = out;
-            } else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
-            WL_HIP(ctx, generic_inv_filter_pass<T>(st, taps, in, in_st, firstp ? llsrc : (const T *)nullptr, llsrc_st,
-                                                   out, out_st, ext, a, lo));
-            in = out; in_st = out_st;
-        }
-        llsrc = res; llsrc_st = box_st; pp ^= 1;
-    }
-    return WL_OK;
-}
-
 // ---- generic lifting level loops -----------------------------------------------------------
 template <typename T>
 int generic_lifting_fwd(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x,
@@ -246,8 +208,8 @@ int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T
     if (fw)
         return filter_fwd_levels<T>(ctx->ws, ctx->cu_count, ctx->path, st, b, y, x, taps, L,
                                     &ctx->last_kernel, &ctx->last_hip);
-    ctx->last_kernel = "k_generic_inv_filter";
-    return generic_filter_inv<T>(ctx, st, b, y, x, taps, L);
+    return filter_inv_levels<T>(ctx->ws, ctx->cu_count, ctx->path, st, b, y, x, taps, L,
+                                &ctx->last_kernel, &ctx->last_hip);
 }
 
 template <typename T>

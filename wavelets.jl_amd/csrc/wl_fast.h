@@ -13,6 +13,12 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                       T *y, const T *x, const Taps<T> &taps, int L,
                       const char **kernel_name, int *hip_err);
 
+// Inverse filter-bank transform: all L levels (streaming kernels for large levels, generic otherwise).
+template <typename T>
+int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+                      T *y, const T *x, const Taps<T> &taps, int L,
+                      const char **kernel_name, int *hip_err);
+
 // Lifting transform (forward or inverse) of `nlines` independent lines of length n (line stride ld):
 // 1-D vectors and batched columns.  Sets *handled = 1 when everything was enqueued by the fused
 // kernels of wl_lift.hip; otherwise enqueues nothing.

@@ -1,0 +1,349 @@
+// wl_inv.hip -- inverse filter-bank DWT: level loop and streaming kernels.
+//
+//   k_inv1d_stream     one inverse level of a line (also one line per blockIdx.y: batched columns, or
+//                      every column of a 2-D block = the dim-1 pass of a 2-D inverse level).  Each lane
+//                      holds 4 approximation + 4 detail coefficients (two 16-byte loads), takes the
+//                      (F-2)/2 neighbouring coefficients from the adjacent lanes by DPP and stores 8
+//                      reconstructed samples (two 16-byte stores).
+//   k_inv_dim2_stream  the dim-2 pass of a 2-D inverse level: a wave owns 256 rows (4 per lane, 16-byte
+//                      loads/stores coalesced along dim 1) and marches along dim 2 with two 8-slot
+//                      register rings (approximation columns p-(F-2)/2..p, detail columns p..p+(F-2)/2);
+//                      no cross-lane traffic at all.
+// Levels too small for the streaming kernels use the generic kernels (wl_generic.hip).
+// Arithmetic = the closed form of filtup! (wl_internal.h): x[o] = S + D with
+//   S = sum over m descending, (o-m) even, of h[m]*s[(o-m)/2];  D = sum over m ascending, (o+m-1) even, of g[m]*d[(o+m-1)/2]
+#include "wl_fast.h"
+
+#include <cstdlib>
+
+namespace wl {
+
+template <typename T, int F>
+struct TapsI { T h[F]; T g[F]; };
+template <typename T, int F>
+static TapsI<T, F> shrink_i(const Taps<T> &t)
+{
+    TapsI<T, F> r;
+    for (int i = 0; i < F; ++i) { r.h[i] = t.h[i]; r.g[i] = t.g[i]; }
+    return r;
+}
+
+__device__ __forceinline__ int i_dpp_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int i_dpp_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float i_next(float v) { return __int_as_float(i_dpp_next(__float_as_int(v))); }
+__device__ __forceinline__ float i_prev(float v) { return __int_as_float(i_dpp_prev(__float_as_int(v))); }
+__device__ __forceinline__ double i_next(double v) { return __hiloint2double(i_dpp_next(__double2hiint(v)), i_dpp_next(__double2loint(v))); }
+__device__ __forceinline__ double i_prev(double v) { return __hiloint2double(i_dpp_prev(__double2hiint(v)), i_dpp_prev(__double2loint(v))); }
+
+template <typename T, int N>
+__device__ __forceinline__ void ldv(const T *p, T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stv(T *p, const T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
+// reconstruct the output pair (x[2p], x[2p+1]) from sw[0..SH] = s[p-SH..p] and dw[0..SH] = d[p..p+SH]
+template <typename T, int F>
+__device__ __forceinline__ void inv_pair(const T *sw, const T *dw, const TapsI<T, F> &tp, T &xe, T &xo)
+{
+    constexpr int SH = (F - 2) / 2;
+    // even output o = 2p: S over even m descending (F-2, ..., 0) -> s[p - m/2]; D over odd m ascending -> d[p + (m-1)/2]
+    T Se = tp.h[F - 2] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
+    T De = tp.g[1] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    xe = Se + De;
+    // odd output o = 2p+1: S over odd m descending (F-1, ..., 1) -> s[p - (m-1)/2]; D over even m ascending -> d[p + m/2]
+    T So = tp.h[F - 1] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
+    T Do = tp.g[0] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    xo = So + Do;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int F>
+struct Inv1DArgs {
+    const T *ssrc; int64_t s_ls;
+    const T *dsrc; int64_t d_ls;
+    T *dst; int64_t o_ls;
+    int64_t n;                      // output line length (multiple of 8, >= 512)
+    int64_t ntiles;
+    TapsI<T, F> tp;
+};
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256) k_inv1d_stream(Inv1DArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, VP = 62 * 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t nx = a.n >> 1;
+    const T *ssrc = a.ssrc + (int64_t)blockIdx.y * a.s_ls;
+    const T *dsrc = a.dsrc + (int64_t)blockIdx.y * a.d_ls;
+    T *dst = a.dst + (int64_t)blockIdx.y * a.o_ls;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k0 = tile * VP + (int64_t)(lane - 1) * 4;
+        int64_t kw = k0;
+        if (kw < 0) kw += nx;
+        if (kw >= nx) kw -= nx;
+        T s[4], d[4];
+        ldv<T, 4>(ssrc + kw, s);
+        ldv<T, 4>(dsrc + kw, d);
+        // sx[i] = s[p = i - SH] for i = 0 .. 3 + SH;  dx[i] = d[p = i] for i = 0 .. 3 + SH
+        T sx[4 + SH], dx[4 + SH];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sx[SH + i] = s[i]; dx[i] = d[i]; }
+#pragma unroll
+        for (int i = 0; i < SH; ++i) {
+            sx[i] = i_prev(s[4 - SH + i]);        // previous lane's last SH approximations
+            dx[4 + i] = i_next(d[i]);             // next lane's first SH details
+        }
+        T out[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) inv_pair<T, F>(&sx[p], &dx[p], a.tp, out[2 * p], out[2 * p + 1]);
+        if (lane >= 1 && lane <= 62 && k0 < nx) stv<T, 8>(dst + 2 * k0, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int F>
+struct InvD2Args {
+    const T *src; int64_t lds;      // ms x ns block, columns [0,ns/2) = approximation, [ns/2,ns) = detail (along dim 2)
+    T *dst; int64_t ldd;
+    int64_t ms, ns;
+    int TP;                         // output column pairs per chunk (multiple of 8)
+    int nstrips, nchunks;
+    TapsI<T, F> tp;
+};
+
+template <typename T, int F, int RPL>
+__global__ void __launch_bounds__(64) k_inv_dim2_stream(InvD2Args<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, R = 8;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+    const int64_t row = (int64_t)strip * 64 * RPL + (int64_t)lane * RPL;
+    const bool valid = row < a.ms;
+    const int64_t rr = valid ? row : 0;
+    const int64_t nxj = a.ns >> 1;
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < nxj) ? (p0 + a.TP) : nxj;
+    const int S = (int)(pend - p0);              // multiple of 8
+    const T *sbase = a.src + rr;
+    const T *dbase = a.src + rr + nxj * a.lds;
+    // ring slot c % R holds approximation column (p0 - SH + c) and detail column (p0 + c)
+    T rs[R][RPL], rd[R][RPL];
+#pragma unroll
+    for (int c = 0; c < R - 1; ++c) {
+        int64_t js = p0 - SH + c;
+        if (js < 0) js += nxj;
+        if (js >= nxj) js -= nxj;
+        int64_t jd = p0 + c;
+        if (jd >= nxj) jd -= nxj;
+        ldv<T, RPL>(sbase + js * a.lds, rs[c]);
+        ldv<T, RPL>(dbase + jd * a.lds, rd[c]);
+    }
+    T *out = a.dst + rr;
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        if (prefetch) {
+            int64_t js = p0 - SH + t + (R - 1);
+            if (js >= nxj) js -= nxj;
+            int64_t jd = p0 + t + (R - 1);
+            if (jd >= nxj) jd -= nxj;
+            ldv<T, RPL>(sbase + js * a.lds, rs[(u + R - 1) % R]);
+            ldv<T, RPL>(dbase + jd * a.lds, rd[(u + R - 1) % R]);
+        }
+        T xe[RPL], xo[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sw[i] = rs[(u + i) % R][q]; dw[i] = rd[(u + i) % R][q]; }
+            inv_pair<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+        }
+        if (valid) {
+            const int64_t p = p0 + t;
+            stv<T, RPL>(out + (2 * p) * a.ldd, xe);
+            stv<T, RPL>(out + (2 * p + 1) * a.ldd, xo);
+        }
+    };
+    int t0 = 0;
+    for (; t0 < S - R; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) step(t0 + u, u, u <= SH);     // last group: columns beyond the chunk's window are not fetched
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int i_env(const char *name, int dflt)
+{
+    const char *s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+static inline bool i_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, int F>
+static hipError_t launch_inv1d(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls,
+                               T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count)
+{
+    Inv1DArgs<T, F> a;
+    a.ssrc = ssrc; a.s_ls = s_ls; a.dsrc = dsrc; a.d_ls = d_ls; a.dst = dst; a.o_ls = o_ls; a.n = n;
+    a.ntiles = ((n >> 1) + 247) / 248;
+    a.tp = shrink_i<T, F>(taps);
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((k_inv1d_stream<T, F>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int F>
+static hipError_t launch_inv_dim2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t lds, T *dst, int64_t ldd,
+                                  int64_t ms, int64_t ns, int cu_count)
+{
+    constexpr int RPL = 16 / sizeof(T);
+    InvD2Args<T, F> a;
+    a.src = src; a.lds = lds; a.dst = dst; a.ldd = ldd; a.ms = ms; a.ns = ns;
+    a.nstrips = (int)((ms + 64 * RPL - 1) / (64 * RPL));
+    const int64_t nxj = ns >> 1;
+    int TP = 64;
+    while (TP > 8 && (int64_t)a.nstrips * ((nxj + TP - 1) / TP) < (int64_t)cu_count * 8) TP >>= 1;
+    a.TP = TP;
+    a.nchunks = (int)((nxj + TP - 1) / TP);
+    a.tp = shrink_i<T, F>(taps);
+    hipLaunchKernelGGL((k_inv_dim2_stream<T, F, RPL>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+#define WL_DISPATCH_FI(F_, ...)                              \
+    switch (F_) {                                            \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break;    \
+    case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
+    case 10: { constexpr int FF = 10; __VA_ARGS__; } break;  \
+    default: break;                                          \
+    }
+
+template <typename T>
+int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+                      T *y, const T *x, const Taps<T> &taps, int L, const char **kernel_name, int *hip_err)
+{
+#define WL_TRYI(expr)                                                  \
+    do {                                                               \
+        hipError_t e__ = (expr);                                       \
+        if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } \
+    } while (0)
+    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    Work<T> w = carve<T>(ws, N);
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    const bool fastF = (path == 0) && (F % 2 == 0) && (F <= 10) && i_env("WL_NO_INVFAST", 0) == 0;
+    const bool two_d = (b.nd == 2 && b.nt == 2);
+    const bool lines = (b.nt == 1 && b.nd <= 2);
+    const int64_t nlines = lines ? b.dims[1] : 1;
+    const char *dominant = nullptr;
+
+    int pp = 0;
+    const T *llsrc = nullptr;              // reconstruction of the deeper level (dense), nullptr: take it from x
+    Strides3 llsrc_st = {{0, 0, 0}};
+    for (int l = L; l >= 1; --l) {
+        int64_t n[3];
+        level_box(b, l, n);
+        Extent3 ext = {{n[0], n[1], n[2]}};
+        Extent3 lo = low_corner(b, n);
+        Strides3 box_st = dense_strides(n);
+        T *res = (l == 1) ? y : (pp ? w.B : w.A);
+        Strides3 res_st = (l == 1) ? b.full : box_st;
+        bool done = false;
+
+        if (fastF && lines && n[0] >= 512 && (n[0] % 8) == 0 && b.full.s[0] == 1 && i_al16(x) && i_al16(y) &&
+            nlines <= 65535 && (nlines == 1 || (b.full.s[1] % VEC) == 0)) {
+            const T *ss = llsrc ? llsrc : x;
+            const int64_t sls = llsrc ? llsrc_st.s[1] : b.full.s[1];
+            WL_DISPATCH_FI(F, WL_TRYI((launch_inv1d<T, FF>(st, taps, ss, sls, x + (n[0] >> 1), b.full.s[1], res, res_st.s[1],
+                                                           n[0], nlines, cu_count)));
+                           done = true);
+            if (done) dominant = "k_inv1d_stream";
+        }
+        if (!done && fastF && two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 16) == 0 &&
+            b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) && i_al16(y) && n[1] <= 65535) {
+            // dim-1 pass: every column is a line of length n0: s = rows [0,h0), d = rows [h0,n0)
+            const int64_t h0 = n[0] >> 1, h1 = n[1] >> 1;
+            T *tmp = w.T0;                         // n0 x n1 dense
+            bool ok = true;
+            if (llsrc) {
+                // columns [0,h1): approximation from the deeper reconstruction; columns [h1,n1): from x
+                WL_DISPATCH_FI(F, WL_TRYI((launch_inv1d<T, FF>(st, taps, llsrc, llsrc_st.s[1], x + h0, b.full.s[1], tmp, n[0],
+                                                               n[0], h1, cu_count)));
+                               WL_TRYI((launch_inv1d<T, FF>(st, taps, x + h1 * b.full.s[1], b.full.s[1], x + h1 * b.full.s[1] + h0,
+                                                            b.full.s[1], tmp + h1 * n[0], n[0], n[0], h1, cu_count))));
+            } else {
+                WL_DISPATCH_FI(F, WL_TRYI((launch_inv1d<T, FF>(st, taps, x, b.full.s[1], x + h0, b.full.s[1], tmp, n[0], n[0], n[1],
+                                                               cu_count))));
+            }
+            // dim-2 pass
+            WL_DISPATCH_FI(F, WL_TRYI((launch_inv_dim2<T, FF>(st, taps, tmp, n[0], res, res_st.s[1], n[0], n[1], cu_count))));
+            (void)ok;
+            done = true;
+            dominant = "k_inv_dim2_stream";
+        }
+        if (!done) {
+            const T *in = x;
+            Strides3 in_st = b.full;
+            int tog = 0;
+            for (int a = 0; a < b.nt; ++a) {
+                const bool firstp = (a == 0), lastp = (a == b.nt - 1);
+                T *out; Strides3 out_st;
+                if (lastp) { out = res; out_st = res_st; }
+                else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
+                WL_TRYI(generic_inv_filter_pass<T>(st, taps, in, in_st, firstp ? llsrc : (const T *)nullptr, llsrc_st,
+                                                   out, out_st, ext, a, lo));
+                in = out; in_st = out_st;
+            }
+            if (!dominant) dominant = "k_generic_inv_filter";
+        }
+        llsrc = res; llsrc_st = box_st; pp ^= 1;
+    }
+    if (kernel_name) *kernel_name = dominant ? dominant : "none";
+    return WL_OK;
+#undef WL_TRYI
+}
+
+template int filter_inv_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
+                                      const Taps<float> &, int, const char **, int *);
+template int filter_inv_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,
+                                       const Taps<double> &, int, const char **, int *);
+
+}  // namespace wl

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
 
     // u = t % U is a compile-time constant at every call site
     auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
-        if (prefetch) {
+        if (prefetch && LVL1 != 4) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
         }
         // dim-1 pass across lanes: P[q] = {ss, sd}, Q[q] = {ds, dd} for output row ko + q
         T2 P[NO], Q[NO];
-        if constexpr (LVL1 == 2) {
+        if constexpr (LVL1 >= 2) {
             // bandwidth probe (WL_PROBE=1, never used by the product path): same loads and stores,
             // no arithmetic -- measures what this access pattern can reach
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
                 vP[qq] = odd ? rP[qq] : P[qq].x;  vP[NO + qq] = odd ? P[qq].y : rP[qq];
                 vQ[qq] = odd ? rQ[qq] : Q[qq].x;  vQ[NO + qq] = odd ? Q[qq].y : rQ[qq];
             }
-            if (valid) {
+            if (valid && (LVL1 != 3 || vP[0] == (T)123456.789)) {
                 // even: LL / ds of column k at row ko;   odd: sd / dd of column kd at row ko-2
                 T *pP = odd ? (yl - NO + (nxj + kd) * a.ldy) : (llp + k * ldl);
                 T *pQ = odd ? (yl - NO + (nxj + kd) * a.ldy + hm) : (yl + k * a.ldy + hm);
@@ -972,7 +972,10 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     a.tp = shrink<T, F>(taps);
     const unsigned wpb = 1;      // waves per workgroup (4-wave workgroups measured no faster)
     const unsigned nwg = ((unsigned)(a.nstrips * a.nchunks) + wpb - 1) / wpb;
-    if (env_int("WL_PROBE", 0) == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    const int probe = env_int("WL_PROBE", 0);
+    if (probe == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    else if (probe == 2) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 3>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    else if (probe == 3) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 4>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     else if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     return hipGetLastError();

@@ -59,7 +59,7 @@ def unpack_wavelet(v: np.ndarray, name: str = "broadcast"):
 
 def broadcast_wavelet(wt, dist, device):
     """Rank 0's wavelet description to every rank (no-op without a process group)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return wt
     rank = dist.get_rank()
     buf = torch.from_numpy(pack_wavelet(wt) if rank == 0 else np.zeros(_PACK_LEN)).to(device)

@@ -248,7 +248,7 @@ def test_dwtc_bitexact(gpu, W, oracle, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_wpt_bitexact(gpu, W, oracle, dtype):
     rs = np.random.default_rng(4)
-    for n in (8, 32, 40, 256, 4096):
+    for n in (8, 32, 40, 256, 4096, 1 << 16):
         x = rng_array((n,), dtype, n)
         Lmax = W.maxtransformlevels(n)
         trees = [W.maketree(n, L, "full") for L in range(0, Lmax + 1)] + [W.maketree(n, L, "dwt") for L in (1, Lmax)]

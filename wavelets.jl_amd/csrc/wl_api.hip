@@ -484,6 +484,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     }
     const int K = (int)depths.size();
     const T *cur = x;
+    bool fast_used = false;
     for (int i = 0; i < K; ++i) {
         const int d = depths[i];
         const int64_t nj = n >> d, nseg = (int64_t)1 << d;
@@ -507,6 +508,16 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             cur = y;
         } else {
             T *out = ((K - 1 - i) % 2 == 0) ? y : w.T0;
+            // fully split depth: every segment is a line of the streaming kernels
+            bool all_set = true;
+            for (int64_t k = 0; k < nseg && all_set; ++k) all_set = tree[(((int64_t)1 << d) - 1) + k] != 0;
+            if (all_set && ctx->path == 0) {
+                hipError_t he = hipSuccess;
+                bool ok = fw ? fast_lines_fwd_level<T>(st, *taps, cur, nj, out, nj, out + (nj >> 1), nj, nj, nseg, ctx->cu_count, &he)
+                             : fast_lines_inv_level<T>(st, *taps, cur, nj, cur + (nj >> 1), nj, out, nj, nj, nseg, ctx->cu_count, &he);
+                if (he != hipSuccess) return hip_fail(ctx, he);
+                if (ok) { cur = out; fast_used = true; continue; }
+            }
             if (fw)
                 WL_HIP(ctx, generic_fwd_filter_pass<T>(st, *taps, cur, bst, out, bst, (T *)nullptr, bst, ext, 0, lo, mask));
             else
@@ -514,7 +525,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             cur = out;
         }
     }
-    ctx->last_kernel = lifting ? "k_generic_lift_wpt" : "k_generic_filter_wpt";
+    ctx->last_kernel = lifting ? "k_generic_lift_wpt" : (fast_used ? (fw ? "k_fwd1d_stream" : "k_inv1d_stream") : "k_generic_filter_wpt");
     return WL_OK;
 }
 

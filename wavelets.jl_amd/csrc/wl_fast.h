@@ -19,6 +19,14 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                       T *y, const T *x, const Taps<T> &taps, int L,
                       const char **kernel_name, int *hip_err);
 
+// One level of `nlines` independent lines (segment = line) with the streaming kernels; false = not eligible.
+template <typename T>
+bool fast_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls,
+                          T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err);
+template <typename T>
+bool fast_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls,
+                          T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err);
+
 // Lifting transform (forward or inverse) of `nlines` independent lines of length n (line stride ld):
 // 1-D vectors and batched columns.  Sets *handled = 1 when everything was enqueued by the fused
 // kernels of wl_lift.hip; otherwise enqueues nothing.

@@ -1202,6 +1202,28 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
 #undef WL_TRY
 }
 
+// One forward level of `nlines` independent lines with the streaming kernel (used by the packet
+// transform for fully split depths).  Returns false when the shape/filter is not eligible.
+template <typename T>
+bool fast_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls,
+                          T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || nlines > 65535 || !aligned16(src) || !aligned16(sdst) ||
+        !aligned16(ddst) || (src_ls % VEC) != 0 || (s_ls % VEC) != 0 || (d_ls % VEC) != 0)
+        return false;
+    bool done = false;
+    WL_DISPATCH_F(F, *err = launch_fwd1d<T, FF>(st, taps, false, src, src_ls, sdst, s_ls, ddst, d_ls, n, nlines, cu_count);
+                  done = true);
+    return done;
+}
+template bool fast_lines_fwd_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, float *, int64_t, float *,
+                                          int64_t, int64_t, int64_t, int, hipError_t *);
+template bool fast_lines_fwd_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, double *, int64_t,
+                                           double *, int64_t, int64_t, int64_t, int, hipError_t *);
+
 template int filter_fwd_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);
 template int filter_fwd_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,

@@ -341,6 +341,26 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
 #undef WL_TRYI
 }
 
+template <typename T>
+bool fast_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls,
+                          T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || nlines > 65535 || !i_al16(ssrc) || !i_al16(dsrc) ||
+        !i_al16(dst) || (s_ls % VEC) != 0 || (d_ls % VEC) != 0 || (o_ls % VEC) != 0)
+        return false;
+    bool done = false;
+    WL_DISPATCH_FI(F, *err = launch_inv1d<T, FF>(st, taps, ssrc, s_ls, dsrc, d_ls, dst, o_ls, n, nlines, cu_count);
+                   done = true);
+    return done;
+}
+template bool fast_lines_inv_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, const float *, int64_t,
+                                          float *, int64_t, int64_t, int64_t, int, hipError_t *);
+template bool fast_lines_inv_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, const double *, int64_t,
+                                           double *, int64_t, int64_t, int64_t, int, hipError_t *);
+
 template int filter_inv_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);
 template int filter_inv_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,

@@ -244,6 +244,27 @@ def test_dwtc_bitexact(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.idwtc(dev(W, ye), sch, Lmax)), oracle.dwtc_lifting(ye, sch, Lmax, fw=False))
 
 
+def test_many_lines_slab_launches(gpu, W, oracle, monkeypatch):
+    """gridDim.y is capped at 65535, so batches are launched in slabs of lines; WL_SLAB_LINES=5 forces
+    several slabs on a small batch (24 and 7 lines)."""
+    monkeypatch.setenv("WL_SLAB_LINES", "5")
+    wt = W.wavelet(W.WT.db4)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    for n, ns in (((1 << 15), 24), ((1 << 16), 7)):
+        x = rng_array((n, ns), np.float32, n + ns)
+        for L in (15, 2):
+            ye = oracle.dwtc_filter(x, wt.qmf, L)
+            assert np.array_equal(host(W, W.dwtc(dev(W, x), wt, L)), ye)
+            assert np.array_equal(host(W, W.idwtc(dev(W, ye), wt, L)), oracle.dwtc_filter(ye, wt.qmf, L, fw=False))
+            yl = oracle.dwtc_lifting(x, sch, L)
+            assert np.array_equal(host(W, W.dwtc(dev(W, x), sch, L)), yl)
+            assert np.array_equal(host(W, W.idwtc(dev(W, yl), sch, L)), oracle.dwtc_lifting(yl, sch, L, fw=False))
+    # 2-D inverse uses the line kernel for its dim-1 pass
+    x2 = rng_array((1024, 512), np.float32, 5)
+    y2 = oracle.dwt_filter(x2, wt.qmf, 2)
+    assert np.array_equal(host(W, W.idwt(dev(W, y2), wt, 2)), oracle.dwt_filter(y2, wt.qmf, 2, fw=False))
+
+
 # ---- wavelet packets ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_wpt_bitexact(gpu, W, oracle, dtype):

@@ -627,10 +627,12 @@ __device__ __forceinline__ void window_pair(const T (&xv)[2 * F - 2], const Taps
 }
 
 template <typename T, int F>
-__global__ void __launch_bounds__(256) k_fwd2d_multi(Multi2DArgs<T, F> a)
+__global__ void __launch_bounds__(512) k_fwd2d_multi(Multi2DArgs<T, F> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 512;
     const int tid = threadIdx.x;
+    const int ti = tid & 63, tj = tid >> 6;        // 64 threads along dim 1, 8 along dim 2
     const int NL = a.NL;
     int H[4];
     H[NL] = 0;
@@ -642,30 +644,34 @@ __global__ void __launch_bounds__(256) k_fwd2d_multi(Multi2DArgs<T, F> a)
     T *Rs = A + (size_t)ld * S0;                                   // S x Lout, ld
     T *Rd = Rs + (size_t)ld * ((S0 - (F - 2)) / 2 + 1);
 
-    // stage A[i + j*ld] = X[(r0 - H0 + i) mod M, (c0 - H0 + j) mod N]
+    // stage A[i + j*ld] = X[(r0 - H0 + i) mod M, (c0 - H0 + j) mod N]; 8-byte loads along dim 1
+    // (r0 - H0 is even and M is even, so a row pair never straddles the periodic wrap)
     {
-        const int total = S0 * S0;
-        constexpr int UL = 8;
-        for (int e0 = tid; e0 < total; e0 += UL * 256) {
-            T v[UL];
-            int li[UL];
+        typedef typename VecOf<T, 2>::type T2;
+        const int S0h = S0 >> 1;                   // S0 is even
+        int gr = r0 - H[0] + 2 * ti;
+        for (int ih = ti; ih < S0h; ih += 64, gr += 128) {
+            int g = gr;
+            if (g < 0) g += a.M;
+            if (g >= a.M) g -= a.M;
+            for (int j = tj; j < S0; j += 4 * 8) {
+                T2 v[4];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const int e = e0 + u * 256;
-                if (e < total) {
-                    const int j = e / S0, i = e - j * S0;
-                    int gr = r0 - H[0] + i, gc = c0 - H[0] + j;
-                    if (gr < 0) gr += a.M;
-                    if (gr >= a.M) gr -= a.M;
-                    if (gc < 0) gc += a.N;
-                    if (gc >= a.N) gc -= a.N;
-                    v[u] = a.src[gr + (int64_t)gc * a.lds];
-                    li[u] = i + j * ld;
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u * 8;
+                    if (jj < S0) {
+                        int gc = c0 - H[0] + jj;
+                        if (gc < 0) gc += a.N;
+                        if (gc >= a.N) gc -= a.N;
+                        v[u] = *reinterpret_cast<const T2 *>(a.src + g + (int64_t)gc * a.lds);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u * 8;
+                    if (jj < S0) { A[2 * ih + jj * ld] = v[u].x; A[2 * ih + 1 + jj * ld] = v[u].y; }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (e0 + u * 256 < total) A[li[u]] = v[u];
         }
     }
     lds_barrier_vm();
@@ -673,44 +679,48 @@ __global__ void __launch_bounds__(256) k_fwd2d_multi(Multi2DArgs<T, F> a)
     for (int t = 1; t <= NL; ++t) {
         const int own = a.OT >> t;
         const int Lout = own + 2 * H[t];
-        // dim-2 pass: rows i in [0,S), column pairs c in [0,Lout): window A[i, 2c .. 2c+2F-3]
-        for (int e = tid; e < S * Lout; e += 256) {
-            const int c = e / S, i = e - c * S;
-            T xv[2 * F - 2];
+        // dim-2 pass: rows i in [0,S) (threads along i), column pairs c in [0,Lout): window A[i, 2c .. 2c+2F-3]
+        for (int i = ti; i < S; i += 64) {
+            for (int c = tj; c < Lout; c += 8) {
+                T xv[2 * F - 2];
 #pragma unroll
-            for (int q = 0; q < 2 * F - 2; ++q) xv[q] = A[i + (2 * c + q) * ld];
-            T sv, dv;
-            window_pair<T, F>(xv, a.tp, sv, dv);
-            Rs[i + c * ld] = sv;
-            Rd[i + c * ld] = dv;
+                for (int q = 0; q < 2 * F - 2; ++q) xv[q] = A[i + (2 * c + q) * ld];
+                T sv, dv;
+                window_pair<T, F>(xv, a.tp, sv, dv);
+                Rs[i + c * ld] = sv;
+                Rd[i + c * ld] = dv;
+            }
         }
         lds_barrier();
-        // dim-1 pass: columns c in [0,Lout) of Rs and Rd, row pairs r in [0,Lout)
+        // dim-1 pass: columns c of Rs and Rd (2*Lout of them), row pairs r in [0,Lout) (threads along r)
         const int Mt = a.M >> t, Nt = a.N >> t;                    // quadrant extents of this level
         const int gr0 = (r0 >> t) - H[t], gc0 = (c0 >> t) - H[t];
         const bool lastlev = (t == NL);
-        for (int e = tid; e < 2 * Lout * Lout; e += 256) {
-            const int which = e / (Lout * Lout);                   // 0: from Rs (s_j), 1: from Rd (d_j)
-            const int e2 = e - which * Lout * Lout;
-            const int c = e2 / Lout, r = e2 - c * Lout;
-            const T *Rp = which ? Rd : Rs;
-            T xv[2 * F - 2];
+        for (int r = ti; r < Lout; r += 64) {
+            const int ro = r - H[t];
+            const int64_t grow = gr0 + r;
+            for (int cc = tj; cc < 2 * Lout; cc += 8) {
+                const int which = cc >= Lout;                       // 0: from Rs (s_j), 1: from Rd (d_j)
+                const int c = which ? cc - Lout : cc;
+                const T *Rp = (which ? Rd : Rs) + c * ld + 2 * r;
+                T xv[2 * F - 2];
 #pragma unroll
-            for (int q = 0; q < 2 * F - 2; ++q) xv[q] = Rp[2 * r + q + c * ld];
-            T sv, dv;
-            window_pair<T, F>(xv, a.tp, sv, dv);
-            const int ro = r - H[t], co = c - H[t];
-            const bool owned = ro >= 0 && ro < own && co >= 0 && co < own;
-            const int64_t grow = gr0 + r, gcol = gc0 + c;          // global coordinates inside the quadrant
-            if (which == 0) {
-                if (!lastlev) A[r + c * ld] = sv;                  // LL of this level -> next level input
-                if (owned) {
-                    if (lastlev) a.ll[grow + gcol * a.ldll] = sv;
-                    a.y[(Mt + grow) + gcol * a.ldy] = dv;          // d_i(s_j)
+                for (int q = 0; q < 2 * F - 2; ++q) xv[q] = Rp[q];
+                T sv, dv;
+                window_pair<T, F>(xv, a.tp, sv, dv);
+                const int co = c - H[t];
+                const bool owned = ro >= 0 && ro < own && co >= 0 && co < own;
+                const int64_t gcol = gc0 + c;                      // global coordinates inside the quadrant
+                if (which == 0) {
+                    if (!lastlev) A[r + c * ld] = sv;              // LL of this level -> next level input
+                    if (owned) {
+                        if (lastlev) a.ll[grow + gcol * a.ldll] = sv;
+                        a.y[(Mt + grow) + gcol * a.ldy] = dv;      // d_i(s_j)
+                    }
+                } else if (owned) {
+                    a.y[grow + (Nt + gcol) * a.ldy] = sv;          // s_i(d_j)
+                    a.y[(Mt + grow) + (Nt + gcol) * a.ldy] = dv;  // d_i(d_j)
                 }
-            } else if (owned) {
-                a.y[grow + (Nt + gcol) * a.ldy] = sv;              // s_i(d_j)
-                a.y[(Mt + grow) + (Nt + gcol) * a.ldy] = dv;      // d_i(d_j)
             }
         }
         lds_barrier();
@@ -965,7 +975,8 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
     // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
-    while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * 8) TJ >>= 1;
+    const int wpc = env_int("WL_WAVES_PER_CU", 8);
+    while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;
     while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * 2) TJ >>= 1;
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
@@ -1004,8 +1015,15 @@ static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    if (lvl1) hipLaunchKernelGGL((k_fwd1d_stream<T, F, 1>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_fwd1d_stream<T, F, 0>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    // gridDim.y is limited to 65535: launch in slabs of lines
+    const int64_t slab = env_int("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Fwd1DArgs<T, F> b = a;
+        b.src = a.src + l0 * a.src_ls; b.sdst = a.sdst + l0 * a.s_ls; b.ddst = a.ddst + l0 * a.d_ls;
+        if (lvl1) hipLaunchKernelGGL((k_fwd1d_stream<T, F, 1>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL((k_fwd1d_stream<T, F, 0>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+    }
     return hipGetLastError();
 }
 
@@ -1025,8 +1043,14 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + (size_t)(a.TS / 2 + 2 * H1 + 8);
     const size_t shmem = elems * sizeof(T);
     const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
-    if (lvl1) hipLaunchKernelGGL((k_fwd1d_multi<T, F, 1>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
-    else hipLaunchKernelGGL((k_fwd1d_multi<T, F, 0>), dim3(ntiles, (unsigned)nlines), dim3(256), shmem, st, a);
+    const int64_t slab = env_int("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Multi1DArgs<T, F> b = a;
+        b.src = a.src + l0 * a.src_ls; b.y = a.y + l0 * a.y_ls; b.sdst = a.sdst + l0 * a.s_ls;
+        if (lvl1) hipLaunchKernelGGL((k_fwd1d_multi<T, F, 1>), dim3(ntiles, (unsigned)nl), dim3(256), shmem, st, b);
+        else hipLaunchKernelGGL((k_fwd1d_multi<T, F, 0>), dim3(ntiles, (unsigned)nl), dim3(256), shmem, st, b);
+    }
     return hipGetLastError();
 }
 
@@ -1052,7 +1076,7 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_multi<T, F>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_fwd2d_multi<T, F>), dim3((unsigned)(M / OT), (unsigned)(N / OT)), dim3(256), shmem, st, a);
+    hipLaunchKernelGGL((k_fwd2d_multi<T, F>), dim3((unsigned)(M / OT), (unsigned)(N / OT)), dim3(512), shmem, st, a);
     return hipGetLastError();
 }
 
@@ -1138,7 +1162,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         bool done = false;
         // ---- 1-D multi-level tile kernel: up to 4 levels per pass over HBM ----
         if (fastF && lines && env_int("WL_NO_MULTI", 0) == 0 && n[0] > tail_cap<T>() && (n[0] % (8 * VEC)) == 0 &&
-            cur_st.s[0] == 1 && aligned16(cur) && aligned16(y) && nlines <= 65535 &&
+            cur_st.s[0] == 1 && aligned16(cur) && aligned16(y) &&
             (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0))) {
             int NL = L - l + 1;
             const int nlmax = env_int("WL_NLMAX", 4);
@@ -1171,7 +1195,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         // ---- streaming 1-D level (vector, or every column of a matrix) ----
         if (!done && fastF && lines && n[0] >= 512 && (n[0] % 8) == 0 && cur_st.s[0] == 1 && aligned16(cur) &&
             aligned16(y) && aligned16(llbuf) && (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0)) &&
-            nlines <= 65535) {
+            true) {
             T *sd = last ? y : llbuf;
             int64_t sls = last ? b.full.s[1] : ll_st.s[1];
             WL_DISPATCH_F(F, WL_TRY((launch_fwd1d<T, FF>(st, taps, l == 1, cur, cur_st.s[1], sd, sls, y + (n[0] >> 1),
@@ -1211,7 +1235,7 @@ bool fast_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
-    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || nlines > 65535 || !aligned16(src) || !aligned16(sdst) ||
+    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || !aligned16(src) || !aligned16(sdst) ||
         !aligned16(ddst) || (src_ls % VEC) != 0 || (s_ls % VEC) != 0 || (d_ls % VEC) != 0)
         return false;
     bool done = false;

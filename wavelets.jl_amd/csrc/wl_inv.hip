@@ -224,7 +224,13 @@ static hipError_t launch_inv1d(hipStream_t st, const Taps<T> &taps, const T *ssr
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((k_inv1d_stream<T, F>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    const int64_t slab = i_env("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Inv1DArgs<T, F> b = a;
+        b.ssrc = a.ssrc + l0 * a.s_ls; b.dsrc = a.dsrc + l0 * a.d_ls; b.dst = a.dst + l0 * a.o_ls;
+        hipLaunchKernelGGL((k_inv1d_stream<T, F>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+    }
     return hipGetLastError();
 }
 
@@ -289,7 +295,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         bool done = false;
 
         if (fastF && lines && n[0] >= 512 && (n[0] % 8) == 0 && b.full.s[0] == 1 && i_al16(x) && i_al16(y) &&
-            nlines <= 65535 && (nlines == 1 || (b.full.s[1] % VEC) == 0)) {
+            (nlines == 1 || (b.full.s[1] % VEC) == 0)) {
             const T *ss = llsrc ? llsrc : x;
             const int64_t sls = llsrc ? llsrc_st.s[1] : b.full.s[1];
             WL_DISPATCH_FI(F, WL_TRYI((launch_inv1d<T, FF>(st, taps, ss, sls, x + (n[0] >> 1), b.full.s[1], res, res_st.s[1],
@@ -298,7 +304,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             if (done) dominant = "k_inv1d_stream";
         }
         if (!done && fastF && two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 16) == 0 &&
-            b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) && i_al16(y) && n[1] <= 65535) {
+            b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) && i_al16(y)) {
             // dim-1 pass: every column is a line of length n0: s = rows [0,h0), d = rows [h0,n0)
             const int64_t h0 = n[0] >> 1, h1 = n[1] >> 1;
             T *tmp = w.T0;                         // n0 x n1 dense
@@ -348,7 +354,7 @@ bool fast_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, in
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
-    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || nlines > 65535 || !i_al16(ssrc) || !i_al16(dsrc) ||
+    if ((F % 2) != 0 || F > 10 || n < 512 || (n % 8) != 0 || !i_al16(ssrc) || !i_al16(dsrc) ||
         !i_al16(dst) || (s_ls % VEC) != 0 || (d_ls % VEC) != 0 || (o_ls % VEC) != 0)
         return false;
     bool done = false;

@@ -16,6 +16,8 @@
 // x += c1*a; x += c2*b; ... (lift_perboundary!, :437-451); no FMA contraction.
 #include "wl_fast.h"
 
+#include <cstdlib>
+
 namespace wl {
 
 // ---- scheme shapes known at compile time (coefficients stay run-time data) -----------------------
@@ -288,6 +290,12 @@ __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftSchem
 }
 
 // --------------------------------------------------------------------------------------------------
+static int l_env(const char *name, int dflt)
+{
+    const char *s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+
 template <typename T>
 constexpr int lift_tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }
 
@@ -297,7 +305,14 @@ static void launch_stream_id(hipStream_t st, const Lift1DArgs<T> &a, int64_t nli
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((k_lift1d_stream<T, ID, FW>), dim3((unsigned)gx, (unsigned)nlines), dim3(256), 0, st, a);
+    const int64_t slab = l_env("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Lift1DArgs<T> b = a;
+        b.a = a.a + l0 * a.a_ls; b.b = a.b ? a.b + l0 * a.b_ls : nullptr;
+        b.o0 = a.o0 + l0 * a.o0_ls; b.o1 = a.o1 ? a.o1 + l0 * a.o1_ls : nullptr;
+        hipLaunchKernelGGL((k_lift1d_stream<T, ID, FW>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+    }
 }
 
 template <typename T>
@@ -326,7 +341,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     *handled = 0;
     constexpr int VEC = 16 / sizeof(T);
     const int id = match_shape<T>(sc);
-    if (L < 1 || !al16(x) || !al16(y) || nlines > 65535) return WL_OK;
+    if (L < 1 || !al16(x) || !al16(y)) return WL_OK;
     if (nlines > 1 && (ld % VEC) != 0) return WL_OK;
     const int cap = lift_tail_cap<T>();
     // every level must be either stream-able (known shape, n_l >= 512, n_l % 8 == 0) or inside the tail

@@ -189,6 +189,19 @@ def test_inplace_api_and_types(gpu, W, oracle):
     assert np.array_equal(host(W, yt), oracle.dwt_filter(a, wt.qmf, 2))
 
 
+def test_degenerate_sizes(gpu, W, oracle):
+    """length-0 and length-1 arrays: maxtransformlevels is 0, the transform is the identity copy."""
+    import torch
+    wt = W.wavelet(W.WT.db2)
+    e = torch.zeros(0, dtype=torch.float32, device=gpu)
+    assert W.dwt(e, wt).shape == (0,) and W.idwt(e, wt).shape == (0,)
+    one = torch.tensor([3.5], dtype=torch.float64, device=gpu)
+    assert float(W.dwt(one, wt)[0]) == 3.5 and W.maxtransformlevels(one) == 0
+    assert float(W.dwt(one, W.wavelet(W.WT.cdf97, W.WT.Lifting))[0]) == 3.5
+    two = dev(W, np.array([1.0, 2.0]))
+    assert np.array_equal(host(W, W.dwt(two, wt)), oracle.dwt_filter(np.array([1.0, 2.0]), wt.qmf))
+
+
 def test_argument_contract_on_gpu(gpu, W):
     import torch
     wt = W.wavelet(W.WT.db2)

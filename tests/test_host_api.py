@@ -1,5 +1,6 @@
 """Host-side mirror of the reference interface (WT types, Util helpers, argument contract).
 No GPU needed: these tests stop at the ABI boundary."""
+import os
 import re
 
 import numpy as np
@@ -104,3 +105,16 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"wl_oracle|libwl_oracle|import oracle|from oracle|wlo_", txt), (dp, f)
+
+
+def test_bench_refuses_to_run_without_gpu():
+    """bench.py measures the HIP path only; on a GPU-less host it must stop, not fall back."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "no CPU path" in (p.stderr + p.stdout)

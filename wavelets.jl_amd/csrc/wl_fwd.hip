@@ -300,8 +300,14 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
     const uint32_t lwg = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
-    const uint32_t logical = lwg * wpb + (threadIdx.x >> 6);
+    uint32_t logical = lwg * wpb + (threadIdx.x >> 6);
     if (logical >= (uint32_t)(a.nstrips * a.nchunks)) return;
+    // levels >= 2 walk each XCD's range backwards: the columns the previous level wrote last are the
+    // ones most likely still resident in that XCD's L2 / the Infinity Cache
+    if (a.nt & 4) {
+        const uint32_t cnt = q8 + (xcd < r8 ? 1u : 0u), first = xcd * q8 + (xcd < r8 ? xcd : r8);
+        logical = first + (cnt - 1 - (logical - first));
+    }
     const int strip = (int)(logical % (uint32_t)a.nstrips);
     const int chunk = (int)(logical / (uint32_t)a.nstrips);
 
@@ -970,7 +976,7 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     Fwd2DArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
     a.nstrips = (int)((ms + VR - 1) / VR);
-    a.nt = env_int("WL_NT", 0);
+    a.nt = env_int("WL_NT", 0) | ((!lvl1 && env_int("WL_REVERSE", 1)) ? 4 : 0);
     int TJ = env_int("WL_TJ", 128);
     // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
     // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16

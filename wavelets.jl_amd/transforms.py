@@ -220,6 +220,10 @@ def _lifting_call(y: torch.Tensor, x: Optional[torch.Tensor], sch: GLS, L: int, 
 def _xwt(x, wt, L, fw):
     x = _prep_in(x)
     L = _default_L(x, L)
+    if x.numel() == 0:                     # empty array: maxtransformlevels == 0, the transform is a copy
+        if L != 0 and L is not None and int(L) > 0:
+            raise ArgumentError("size must have a sufficient power of 2 factor")
+        return similar(x)
     if isinstance(wt, OrthoFilter):
         return _filter_call(similar(x), x, wt, L, fw)                 # transforms_main.jl:109-113
     if isinstance(wt, GLS):

@@ -91,6 +91,26 @@ def test_fast_and_generic_paths_agree(gpu, W, oracle, dtype):
             assert np.array_equal(yg, yf), (shape, L, fname, W.last_kernel(), np.abs(yg - yf).max())
 
 
+def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
+    """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
+    forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic
+    kernels (odd/even L, non-square blocks, partial strips and chunks, every supported filter length)."""
+    monkeypatch.setenv("WL_FUSE2_MIN", "0")
+    for shape, Ls in (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (4, 9)), ((528, 96), (2, 4)),
+                      ((4096, 64), (2,))):
+        x = rng_array(shape, np.float32, sum(shape))
+        for fname in ("db4", "haar", "db2", "db3", "sym4"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_stream2", (shape, L, W.last_kernel())
+                assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname, L)
+    # f64 has no fused kernel: same call goes through the single-level kernel
+    x = rng_array((512, 512), np.float64, 3)
+    y = host(W, W.dwt(dev(W, x), W.wavelet(W.WT.db4), 3))
+    assert np.array_equal(y, oracle.dwt_filter(x, W.wavelet(W.WT.db4).qmf, 3))
+
+
 # ---- lifting ----------------------------------------------------------------------------------------
 LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256),
            (4, 4, 4), (16, 16, 16), (24, 24, 24)]

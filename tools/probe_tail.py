@@ -19,3 +19,17 @@ for n in (128, 64, 32, 16):
     for L in (1, 2, 3, Lm):
         us = timeit(lambda: W.dwt_(y, x, wt, L))
         print(f"n={n:4d} L={L:2d}  {us:7.2f} us/call  kernel={W.last_kernel()}")
+
+# host-side enqueue cost of one full C3 call (no synchronisation inside the loop)
+import time
+x = torch.randn(8192, 8192, dtype=torch.float32, device="cuda").t()
+y = W.similar(x)
+W.reserve_workspace(x, 13)
+for _ in range(5): W.dwt_(y, x, wt, 13)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): W.dwt_(y, x, wt, 13)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"C3 enqueue {1e6*(t1-t0)/50:.1f} us/call host, total {1e6*(t2-t0)/50:.1f} us/call")

@@ -442,6 +442,170 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - PFD);   // last group: stop prefetching PFD steps early
 }
 
+
+// ==========================================================================================
+// 2-D fused PAIR of levels (l, l+1): same register-streaming scheme as k_fwd2d_stream, but the
+// level-l approximation never goes to HBM -- each lane keeps its two LL rows of the last eight LL
+// columns in an 8-slot register ring and every second step runs level l+1 on them (dim-2 pass on
+// the ring, dim-1 pass across lanes with 3-deep DPP chains).  Traffic for the two levels: read the
+// level-l block once, write its three detail quadrants and the four level-(l+1) quadrants
+// (4.19 -> 3.31 bytes per byte of level-l input: the LL write + re-read disappear), one launch less.
+// Cost: a wave owns 208 rows instead of 240 (lanes 6..57) and a chunk runs 8 extra steps.
+template <typename T, int F>
+struct Fwd2D2Args {
+    const T *src; int64_t lds;
+    T *y; int64_t ldy;
+    T *ll; int64_t ldll;            // level-(l+1) approximation: next stage's input buffer, or y itself
+    int64_t ms, ns;                 // level-l block
+    int TJ;                         // owned input columns per chunk (multiple of 16)
+    int nstrips, nchunks;
+    int rev;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F, int LVL1>
+__global__ void __launch_bounds__(64) k_fwd2d_stream2(Fwd2D2Args<T, F> a)
+{
+    typedef typename VecOf<T, 2>::type T2;
+    constexpr int RPL = 4, ML = 6, VR = (64 - 2 * ML) * RPL, NO = 2, SH = (F - 2) / 2;
+    constexpr int R = 16, U = 8, PFD = (R - F) / 2;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t first = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1u : 0u);
+    uint32_t logical = first + (b >> 3);
+    if (a.rev) logical = first + (cnt - 1 - (logical - first));
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+
+    const int64_t ms = a.ms, ns = a.ns, nxj = ns >> 1, hm = ms >> 1, nxj2 = ns >> 2, hm2 = ms >> 2;
+    const int64_t gi = (int64_t)strip * VR + (int64_t)(lane - ML) * RPL;
+    int64_t row = gi;
+    if (row < 0) row += ms;
+    if (row >= ms) row -= ms;
+    const bool own = (lane >= ML) && (lane < 64 - ML) && (gi < ms);
+    const int64_t ko = gi >> 1, ko2 = gi >> 2;
+    const bool odd = (lane & 1) != 0;
+
+    const int64_t j0 = (int64_t)chunk * a.TJ;
+    const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
+    const int S_own = (int)((jend - j0) >> 1);         // level-l steps whose outputs this chunk owns (multiple of 8)
+    const int S = S_own + U;                           // + 8 steps that only feed level l+1
+    const T *base = a.src + row;
+
+    T ring[R][RPL];
+#pragma unroll
+    for (int c = 0; c < R - 2; ++c) {
+        int64_t jc = j0 + c;
+        if (jc >= ns) jc -= ns;
+        vload<T, RPL>(base + jc * a.lds, ring[c]);
+    }
+    T2 ring2[U];                                       // LL rows (ko, ko+1) of LL column k in slot k % 8
+    T *const yl = a.y + ko;
+    const int64_t kbase = j0 >> 1;                     // multiple of 8
+    const int64_t kbase2 = j0 >> 2;
+
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        if (prefetch) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int64_t jc = j0 + 2 * t + (R - 2) + e;
+                if (jc >= ns) jc -= ns;
+                if (jc >= ns) jc -= ns;
+                vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+            }
+        }
+        // ---- level l: dim-2 pass on row pairs, dim-1 pass across lanes ----
+        T2 A2[2], B2[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            T2 x0 = T2{ring[(2 * u) % R][2 * pr], ring[(2 * u) % R][2 * pr + 1]};
+            T2 sa = a.tp.h[0] * x0;
+            T2 da = a.tp.g[F - 1] * x0;
+#pragma unroll
+            for (int m = 1; m < F; ++m) {
+                T2 xm = T2{ring[(2 * u + m) % R][2 * pr], ring[(2 * u + m) % R][2 * pr + 1]};
+                sa = sa + a.tp.h[m] * xm;
+                da = da + a.tp.g[F - 1 - m] * xm;
+            }
+            A2[pr] = sa;
+            B2[pr] = da;
+        }
+        T2 RD[RPL];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            RD[2 * pr] = T2{A2[pr].x, B2[pr].x};
+            RD[2 * pr + 1] = T2{A2[pr].y, B2[pr].y};
+        }
+        T2 P[NO], Q[NO];                               // P[q] = {ss, sd}, Q[q] = {ds, dd} of output row ko + q
+        lane_axis_pair2<T, F, RPL>(RD, a.tp, P, Q);
+        ring2[u] = T2{P[0].x, P[1].x};                 // LL column kbase + t
+        if (t < S_own) {
+            const int64_t k = kbase + t;
+            int64_t kd = k + SH;
+            if (kd >= nxj) kd -= nxj;
+            // even lane: ds rows ko..ko+3 of column k;  odd lane: sd and dd rows ko-2..ko+1 of column kd
+            T rA[NO], rB[NO];
+#pragma unroll
+            for (int q = 0; q < NO; ++q) {
+                rA[q] = from_partner(odd ? Q[q].x : P[q].y);
+                rB[q] = from_partner(Q[q].y);
+            }
+            T v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < NO; ++q) {
+                v0[q] = odd ? rA[q] : Q[q].x;  v0[NO + q] = odd ? P[q].y : rA[q];
+                v1[q] = rB[q];                 v1[NO + q] = Q[q].y;
+            }
+            if (own) {
+                T *p0 = odd ? (yl - NO + (nxj + kd) * a.ldy) : (yl + k * a.ldy + hm);
+                vstore<T, 4>(p0, v0);
+                if (odd) vstore<T, 4>(yl - NO + (nxj + kd) * a.ldy + hm, v1);
+            }
+        }
+        // ---- level l+1: every second step, on the LL ring (window = LL columns k-7 .. k) ----
+        if ((u & 1) && t >= U - 1) {
+            T2 sa = a.tp.h[0] * ring2[(u + 1) % U];
+            T2 da = a.tp.g[F - 1] * ring2[(u + 1) % U];
+#pragma unroll
+            for (int m = 1; m < F; ++m) {
+                sa = sa + a.tp.h[m] * ring2[(u + 1 + m) % U];
+                da = da + a.tp.g[F - 1 - m] * ring2[(u + 1 + m) % U];
+            }
+            T2 RD2[2];
+            RD2[0] = T2{sa.x, da.x};
+            RD2[1] = T2{sa.y, da.y};
+            T2 P2[1], Q2[1];                           // P2 = {ss2, sd2}, Q2 = {ds2, dd2} of row ko2
+            lane_axis_pair2<T, F, 2>(RD2, a.tp, P2, Q2);
+            if (t < S_own + U - 1) {
+                const int64_t k2 = kbase2 + ((t - (U - 1)) >> 1);
+                int64_t kd2 = k2 + SH;
+                if (kd2 >= nxj2) kd2 -= nxj2;
+                const T rP = from_partner(odd ? P2[0].x : P2[0].y);
+                const T rQ = from_partner(odd ? Q2[0].x : Q2[0].y);
+                T w0[2], w1[2];
+                w0[0] = odd ? rP : P2[0].x;  w0[1] = odd ? P2[0].y : rP;
+                w1[0] = odd ? rQ : Q2[0].x;  w1[1] = odd ? Q2[0].y : rQ;
+                if (own) {
+                    // even lane: ss2 / ds2 rows ko2, ko2+1 of column k2;  odd lane: sd2 / dd2 rows ko2-1, ko2 of column kd2
+                    T *p0 = odd ? (a.y + (ko2 - 1) + (nxj2 + kd2) * a.ldy) : (a.ll + ko2 + k2 * a.ldll);
+                    T *p1 = odd ? (a.y + (ko2 - 1) + (nxj2 + kd2) * a.ldy + hm2) : (a.y + ko2 + k2 * a.ldy + hm2);
+                    vstore<T, 2>(p0, w0);
+                    vstore<T, 2>(p1, w1);
+                }
+            }
+        }
+    };
+
+    int t0 = 0;
+    for (; t0 < S - U; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - PFD);
+}
+
 // ==========================================================================================
 // 1-D level (one line per blockIdx.y)
 template <typename T, int F>
@@ -927,11 +1091,24 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
 
 // ==========================================================================================
 // host side
-static int env_int(const char *name, int dflt)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device): do it once
+static hipError_t set_max_lds_once(const void *fn, size_t bytes, unsigned char (&done)[64], size_t (&cur)[64])
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (done[dev] && cur[dev] >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < 65536 ? 65536 : bytes));
+    if (e == hipSuccess) { done[dev] = 1; cur[dev] = bytes < 65536 ? 65536 : bytes; }
+    return e;
+}
+static int env_int_raw(const char *name, int dflt)
 {
     const char *s = std::getenv(name);
     return (s && *s) ? std::atoi(s) : dflt;
 }
+// tuning knobs are read once per call site (getenv walks the whole environment)
+#define env_int(name, dflt) ([]() { static const int v__ = env_int_raw(name, dflt); return v__; }())
 
 template <typename T>
 constexpr int tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }     // block elements
@@ -952,8 +1129,8 @@ static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src,
     int threads = work >= 4096 ? 1024 : (work >= 512 ? 256 : 64);
 #define WL_TAIL_LAUNCH(FC_)                                                                                   \
     do {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_fwd<T, FC_>),               \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);           \
+        static unsigned char done__[64]; static size_t cur__[64];                                             \
+        hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_tail_fwd<T, FC_>), 160 * 1024, done__, cur__); \
         if (e != hipSuccess) return e;                                                                        \
         hipLaunchKernelGGL((k_tail_fwd<T, FC_>), dim3((unsigned)nitems), dim3(threads), shmem, st, a, taps);  \
     } while (0)
@@ -1010,6 +1187,29 @@ static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     return launch_fwd2d_r<T, F, RPL>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
 }
 
+
+template <typename T, int F>
+static hipError_t launch_fwd2d_pair(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
+                                    T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    Fwd2D2Args<T, F> a;
+    constexpr int VR = 52 * 4;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
+    a.nstrips = (int)((ms + VR - 1) / VR);
+    int TJ = env_int("WL_TJ2", 128);
+    auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
+    const int wpc = env_int("WL_WAVES_PER_CU", 8);
+    while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;
+    a.TJ = TJ;
+    a.nchunks = (int)((ns + TJ - 1) / TJ);
+    a.rev = (!lvl1 && env_int("WL_REVERSE", 1)) ? 1 : 0;
+    a.tp = shrink<T, F>(taps);
+    const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
+    if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream2<T, F, 1>), dim3(nwg), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd2d_stream2<T, F, 0>), dim3(nwg), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 template <typename T, int F>
 static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t src_ls,
                                T *sdst, int64_t s_ls, T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count)
@@ -1022,7 +1222,7 @@ static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
     // gridDim.y is limited to 65535: launch in slabs of lines
-    const int64_t slab = env_int("WL_SLAB_LINES", 32768);
+    const int64_t slab = env_int_raw("WL_SLAB_LINES", 32768);
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Fwd1DArgs<T, F> b = a;
@@ -1049,7 +1249,7 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + (size_t)(a.TS / 2 + 2 * H1 + 8);
     const size_t shmem = elems * sizeof(T);
     const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
-    const int64_t slab = env_int("WL_SLAB_LINES", 32768);
+    const int64_t slab = env_int_raw("WL_SLAB_LINES", 32768);
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Multi1DArgs<T, F> b = a;
@@ -1079,8 +1279,8 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
     const int L1 = (S0 - (F - 2)) / 2 + 1;
     const size_t elems = (size_t)a.ld0 * S0 + 2 * (size_t)a.ld0 * L1 + 16;
     const size_t shmem = elems * sizeof(T);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_multi<T, F>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    static unsigned char done__[64]; static size_t cur__[64];
+    hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_fwd2d_multi<T, F>), 160 * 1024, done__, cur__);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_fwd2d_multi<T, F>), dim3((unsigned)(M / OT), (unsigned)(N / OT)), dim3(512), shmem, st, a);
     return hipGetLastError();
@@ -1187,6 +1387,28 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                 int64_t hn2[3] = {n[0] >> NL, n[1], n[2]};
                 cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
                 continue;
+            }
+        }
+        // ---- streaming 2-D, two levels fused (f32) ----
+        if constexpr (sizeof(T) == 4) {
+            if (fastF && F <= 8 && two_d && env_int("WL_FUSE2", 1) && (L - l + 1) >= 2 && n[0] >= 512 && (n[0] % 16) == 0 &&
+                n[0] * n[1] >= (int64_t)env_int_raw("WL_FUSE2_MIN", 1 << 24) &&
+                n[1] >= 64 && (n[1] % 32) == 0 && cur_st.s[0] == 1 && (cur_st.s[1] % VEC) == 0 && aligned16(cur) &&
+                (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+                const bool lastp = (l + 1 == L);
+                T *lld = lastp ? y : llbuf;
+                const int64_t ldd = lastp ? b.full.s[1] : (n[0] >> 2);
+                bool ok = false;
+                WL_DISPATCH_F(F, WL_TRY((launch_fwd2d_pair<T, FF>(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd,
+                                                                  n[0], n[1], cu_count)));
+                              ok = true);
+                if (ok) {
+                    if (!dominant) dominant = "k_fwd2d_stream2";
+                    lstep = 2;
+                    int64_t hn2[3] = {n[0] >> 2, n[1] >> 2, n[2]};
+                    cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                    continue;
+                }
             }
         }
         // ---- streaming 2-D level ----

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X DWT backend (driver contract: one JSON line).
 
-A "step" is one full forward transform of one synthetic array already resident in HBM:
+A "step" is one full forward transform (the non-allocating dwt!(y, x, wt, L) entry point) of one
+synthetic array already resident in HBM:
     default workload  C3 = 2-D dwt, WT.db4 filter bank, 8192 x 8192 Float32, L = 13 (API default)
                       (BASELINE.json configs[2], the configuration the metric is quoted on)
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank transforms
@@ -96,7 +97,10 @@ def main():
     # filter taps / scheme coefficients travel from rank 0 over RCCL (xGMI): the only collective
     wt = sharding.broadcast_wavelet(wt, dist, device)
     batched = args.workload == "c5"
-    fn = (lambda t: W.dwtc(t, wt, L)) if batched else (lambda t: W.dwt(t, wt, L))
+    # the timed step is the reference's non-allocating entry point dwt!(y, x, wt, L) / dwt_oop!(y, x, scheme, L)
+    # (transforms_main.jl:114-117,193-207): output array and workspace are allocated once, outside the timed region
+    yout = W.similar(x)
+    fn = (lambda t: W.dwtc_(yout, t, wt, L)) if batched else (lambda t: W.dwt_oop_(yout, t, wt, L))
     W.reserve_workspace(x, L)
     nsamples = x.numel()
 
@@ -174,7 +178,8 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
     on the launch stream give its average duration; rocprofv3 --stats reports the same instance
     (the first-level launch has its own template instantiation)."""
     Ldom = 2 if main_kernel == "k_fwd2d_stream2" else 1
-    fn1 = (lambda: W.dwtc(x, wt, Ldom)) if batched else (lambda: W.dwt(x, wt, Ldom))
+    y1 = W.similar(x)
+    fn1 = (lambda: W.dwtc_(y1, x, wt, Ldom)) if batched else (lambda: W.dwt_oop_(y1, x, wt, Ldom))
     reps = max(20, args.steps)
     avg_ms, med_ms, min_ms = _time_launches(fn1, reps)
     kname = W.last_kernel()
@@ -200,7 +205,7 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
            "frac_of_measured_copy_6290GBps": round(achieved / 6290.0, 4)}
     if Ldom == 2:
         # for reference: the single-level kernel (L = 1 call) on the same array
-        a1, m1, _ = _time_launches((lambda: W.dwt(x, wt, 1)), reps)
+        a1, m1, _ = _time_launches((lambda: W.dwt_oop_(y1, x, wt, 1)), reps)
         out["single_level_kernel"] = {"kernel": W.last_kernel() + " (level 1 only)", "avg_launch_ms": round(a1, 5),
                                       "achieved": round(alg_bytes / (a1 * 1e-3) / 1e9, 1),
                                       "frac": round(alg_bytes / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}

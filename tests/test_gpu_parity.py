@@ -198,6 +198,16 @@ def test_inplace_api_and_types(gpu, W, oracle):
     assert r is y and y.dtype == torch.float32
     assert np.array_equal(host(W, y), oracle.dwt_filter(x, wt.qmf, 2))
     assert np.array_equal(host(W, W.dwt_(W.similar(xd), xd, wt)), host(W, W.dwt(xd, wt)))
+    # dwt_oop!(y, x, wt, L) for a filter and for a lifting scheme; column-wise into a given y
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    y2 = W.similar(xd)
+    assert W.dwt_oop_(y2, xd, sch, 3) is y2 and np.array_equal(host(W, y2), oracle.dwt_lifting(x, sch, 3))
+    assert np.array_equal(host(W, xd), x)                                  # x untouched
+    assert np.array_equal(host(W, W.idwt_oop_(W.similar(xd), y2, sch, 3)), oracle.dwt_lifting(oracle.dwt_lifting(x, sch, 3), sch, 3, fw=False))
+    assert np.array_equal(host(W, W.dwt_oop_(W.similar(xd), xd, wt, 2)), oracle.dwt_filter(x, wt.qmf, 2))
+    xm = rng_array((64, 3), np.float32, 9)
+    ym = W.similar(dev(W, xm))
+    assert W.dwtc_(ym, dev(W, xm), wt, 2) is ym and np.array_equal(host(W, ym), oracle.dwtc_filter(xm, wt.qmf, 2))
     # Int -> Float (transforms_main.jl:188-190)
     xi = torch.arange(-8, 8, device=gpu)
     yi = W.dwt(xi, wt, 2)

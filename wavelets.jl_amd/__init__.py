@@ -14,7 +14,7 @@ from . import util as Util
 from .wt import wavelet, OrthoFilter, GLS
 from .util import (maxtransformlevels, sufficientpoweroftwo, detailindex, detailrange, detailn,
                    ndyadicscales, maketree, isvalidtree, iscube, isdyadic)
-from .transforms import (dwt, idwt, dwt_, idwt_, dwtc, idwtc, wpt, iwpt, wpt_, iwpt_,
+from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwtc, dwtc_, idwtc_, wpt, iwpt, wpt_, iwpt_,
                          to_device, to_host, similar, julia_layout, is_julia_layout,
                          reserve_workspace, set_kernel_path, last_kernel,
                          DimensionMismatch, ArgumentError, HIPError)
@@ -22,7 +22,7 @@ from . import _lib
 
 __all__ = [
     "WT", "Util", "wavelet", "OrthoFilter", "GLS",
-    "dwt", "idwt", "dwt_", "idwt_", "dwtc", "idwtc", "wpt", "iwpt", "wpt_", "iwpt_",
+    "dwt", "idwt", "dwt_", "idwt_", "dwt_oop_", "idwt_oop_", "dwtc", "idwtc", "dwtc_", "idwtc_", "wpt", "iwpt", "wpt_", "iwpt_",
     "maxtransformlevels", "sufficientpoweroftwo", "detailindex", "detailrange", "detailn",
     "ndyadicscales", "maketree", "isvalidtree", "iscube", "isdyadic",
     "to_device", "to_host", "similar", "julia_layout", "is_julia_layout",

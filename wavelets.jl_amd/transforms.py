@@ -272,8 +272,33 @@ def idwt_(*args) -> torch.Tensor:
     return _xwt_inplace(args, False)
 
 
+def dwt_oop_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
+    """dwt_oop!(y, x, wt[, L]) (non-exported in the reference, transforms_main.jl:193-207): out of place
+    into a caller-provided y for filters AND lifting schemes (the reference copies x into y and runs in
+    place; here the copy is fused away)."""
+    L = _default_L(x, L)
+    if isinstance(wt, OrthoFilter):
+        return _xwt_inplace((y, x, wt, L), True)
+    if isinstance(wt, GLS):
+        if tuple(x.shape) != tuple(y.shape):
+            raise DimensionMismatch("in and out array size must match")
+        return _lifting_call(y, x, wt, L, True)
+    raise TypeError("wt must be an OrthoFilter or a GLS")
+
+
+def idwt_oop_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
+    L = _default_L(x, L)
+    if isinstance(wt, OrthoFilter):
+        return _xwt_inplace((y, x, wt, L), False)
+    if isinstance(wt, GLS):
+        if tuple(x.shape) != tuple(y.shape):
+            raise DimensionMismatch("in and out array size must match")
+        return _lifting_call(y, x, wt, L, False)
+    raise TypeError("wt must be an OrthoFilter or a GLS")
+
+
 # ---- batched column-wise ----------------------------------------------------------------------
-def _xwtc(x, wt, L, fw):
+def _xwtc(x, wt, L, fw, y=None):
     x = _prep_in(x)
     if x.dim() != 2:
         raise DimensionMismatch("dwtc expects a len x nsignals matrix")
@@ -281,15 +306,19 @@ def _xwtc(x, wt, L, fw):
     L = Util.maxtransformlevels(length) if L is None else int(L)
     lib = _lib.load()
     h, st = _context(x.device)
+    if y is not None and (tuple(y.shape) != tuple(x.shape) or y.dtype != x.dtype or not is_julia_layout(y)):
+        raise DimensionMismatch("in and out array size must match")
     if isinstance(wt, OrthoFilter):
-        y = similar(x)
+        if y is None:
+            y = similar(x)
         q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
         rc = lib.wl_dwtc_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()),
                                 length, nsig, length, _f64p(q), len(q), L, 1 if fw else 0, st)
         _check(rc, h)
         return y
     if isinstance(wt, GLS):
-        y = similar(x)
+        if y is None:
+            y = similar(x)
         y.copy_(x)
         iu, nc, sh, cf = wt.flatten()
         rc = lib.wl_dwtc_lifting(h, _dtype_code(y), C.c_void_p(y.data_ptr()), length, nsig, length,
@@ -307,6 +336,15 @@ def dwtc(x, wt, L: Optional[int] = None) -> torch.Tensor:
 
 def idwtc(x, wt, L: Optional[int] = None) -> torch.Tensor:
     return _xwtc(x, wt, L, False)
+
+
+def dwtc_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
+    """column-wise dwt into a caller-provided y (no allocation)"""
+    return _xwtc(x, wt, L, True, y)
+
+
+def idwtc_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
+    return _xwtc(x, wt, L, False, y)
 
 
 # ---- wavelet packet transforms -------------------------------------------------------------------

@@ -213,6 +213,7 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
 
 
 def cpu_baseline_leg(W, workload, wt, L):
+    extra = {}
     """The oracle (kind 'port': literal C restatement of the reference's single-threaded loops)
     on this host's cores, on a bounded sample (about 10-30 s of CPU work)."""
     import oracle                      # the checker / baseline -- never the product path
@@ -227,6 +228,12 @@ def cpu_baseline_leg(W, workload, wt, L):
         dt = time.perf_counter() - t0
         sample = f"one full 2-D db4 dwt of the {n}x{n} f32 array, L={L}, 1 thread (the reference has no threading)"
         ns = xs.size
+        # secondary number: the same algorithm with its per-level line loops on every host core (OpenMP)
+        t1 = time.perf_counter()
+        oracle.dwt2d_filter_mt(xs, wt.qmf, L)
+        dt_mt = time.perf_counter() - t1
+        extra = {"all_cores": {"value": round(ns / dt_mt / 1e6, 2), "unit": "Msamples/s", "cores": oracle.max_threads(),
+                               "kind": "port", "sample": "same array, line loops parallelised with OpenMP", "seconds": round(dt_mt, 2)}}
     else:
         # parity-test configs: repeat full-size (c5: a 1/64 sub-batch) transforms for about 10 s
         if workload == "c1":
@@ -251,8 +258,10 @@ def cpu_baseline_leg(W, workload, wt, L):
         dt = (time.perf_counter() - t0) / reps
         sample = f"{reps} {what}, 1 thread"
         ns = xs.size
-    return {"value": round(ns / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": sample, "seconds": round(dt, 2), "host_cores_available": os.cpu_count()}
+    out = {"value": round(ns / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": sample, "seconds": round(dt, 2), "host_cores_available": os.cpu_count()}
+    out.update(extra)
+    return out
 
 
 if __name__ == "__main__":

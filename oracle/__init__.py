@@ -92,6 +92,23 @@ def dwt_filter(x: np.ndarray, qmf, L=None, fw=True) -> np.ndarray:
     return np.ascontiguousarray(yf)
 
 
+def dwt2d_filter_mt(x: np.ndarray, qmf, L=None) -> np.ndarray:
+    """forward 2-D filter dwt, the per-level line loops on all OpenMP threads (same results as dwt_filter)"""
+    xf = _col(x)
+    yf = np.empty_like(xf, order="F")
+    q = np.ascontiguousarray(qmf, dtype=np.float64)
+    L = maxtransformlevels(x) if L is None else L
+    rc = lib().wlo_dwt2d_filter_mt(_dt(xf), _p(yf), _p(xf), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]),
+                                   q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L))
+    if rc:
+        raise OracleError(rc)
+    return np.ascontiguousarray(yf)
+
+
+def max_threads() -> int:
+    return int(lib().wlo_max_threads())
+
+
 def dwt_lifting(x: np.ndarray, scheme, L=None, fw=True) -> np.ndarray:
     """dwt/idwt with a GLS scheme (copy + in place), reference _dwt! (transforms_lifting.jl:30-278)."""
     yf = _col(x)

@@ -212,6 +212,25 @@ WLO_API int wlo_dwt_filter(int dtype, void *y, const void *x, int ndims, const i
     return WLO_EINVAL_DTYPE;
 }
 
+/* 2-D forward filter dwt with the line loops on OpenMP threads (cpu_baseline "all cores") */
+WLO_API int wlo_dwt2d_filter_mt(int dtype, void *y, const void *x, int64_t m, int64_t n,
+                                const double *qmf, int flen, int L)
+{
+    if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
+    if (dtype == 0) return f_dwt2d_fw_mt_f32((float *)y, (const float *)x, (long)m, (long)n, qmf, flen, L);
+    if (dtype == 1) return f_dwt2d_fw_mt_f64((double *)y, (const double *)x, (long)m, (long)n, qmf, flen, L);
+    return WLO_EINVAL_DTYPE;
+}
+WLO_API int wlo_max_threads(void)
+{
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* dwt!/idwt! with a GLS lifting scheme, in place on y.                      */
 WLO_API int wlo_dwt_lifting(int dtype, void *y, int ndims, const int64_t *dims,
                             int nsteps, const int32_t *is_update, const int32_t *ncoef,

@@ -69,29 +69,6 @@ __device__ __forceinline__ void vstore(T *p, const T (&v)[N])
         *reinterpret_cast<V *>(p) = t;
     }
 }
-template <typename T, int N>
-__device__ __forceinline__ void vload_nt(const T *p, T (&v)[N])
-{
-    typedef typename VecOf<T, N>::type V;
-    V t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
-    if constexpr (N == 1) v[0] = t;
-    else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = t[i];
-    }
-}
-template <typename T, int N>
-__device__ __forceinline__ void vstore_nt(T *p, const T (&v)[N])
-{
-    typedef typename VecOf<T, N>::type V;
-    if constexpr (N == 1) __builtin_nontemporal_store(v[0], p);
-    else {
-        V t;
-#pragma unroll
-        for (int i = 0; i < N; ++i) t[i] = v[i];
-        __builtin_nontemporal_store(t, reinterpret_cast<V *>(p));
-    }
-}
 // 16-byte-granular load/store of N elements (N*sizeof(T) may exceed 16 bytes)
 template <typename T, int N>
 __device__ __forceinline__ void vload16(const T *p, T (&v)[N])
@@ -279,7 +256,7 @@ struct Fwd2DArgs {
     T *ll; int64_t ldll;            // approximation buffer for the next level (or nullptr)
     int64_t ms, ns;
     int TJ;                         // input columns per chunk (even)
-    int nt;                         // bit 0: nontemporal loads, bit 1: nontemporal stores
+    int nt;                         // bit 2: walk this XCD's range backwards
     int nstrips, nchunks;
     TapsF<T, F> tp;
 };
@@ -335,7 +312,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     for (int c = 0; c < R - 2; ++c) {
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
-        if (a.nt & 1) vload_nt<T, RPL>(base + jc * a.lds, ring[c]); else vload<T, RPL>(base + jc * a.lds, ring[c]);
+        vload<T, RPL>(base + jc * a.lds, ring[c]);
     }
 
     T *const yl = a.y + ko;
@@ -345,13 +322,12 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
 
     // u = t % U is a compile-time constant at every call site
     auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
-        if (prefetch && LVL1 != 4) {
+        if (prefetch) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
-                if (a.nt & 1) vload_nt<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
-                else vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+                vload<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
             }
         }
         // dim-2 pass in registers on row pairs (adjacent registers of the 16-byte loads):
@@ -381,17 +357,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
         }
         // dim-1 pass across lanes: P[q] = {ss, sd}, Q[q] = {ds, dd} for output row ko + q
         T2 P[NO], Q[NO];
-        if constexpr (LVL1 >= 2) {
-            // bandwidth probe (WL_PROBE=1, never used by the product path): same loads and stores,
-            // no arithmetic -- measures what this access pattern can reach
-#pragma unroll
-            for (int qq = 0; qq < NO; ++qq) {
-                P[qq] = T2{ring[(2 * u) % R][qq], ring[(2 * u + 1) % R][qq]};
-                Q[qq] = T2{ring[(2 * u) % R][NO + qq], ring[(2 * u + 1) % R][NO + qq]};
-            }
-        } else {
-            lane_axis_pair2<T, F, RPL>(RD, a.tp, P, Q);
-        }
+        lane_axis_pair2<T, F, RPL>(RD, a.tp, P, Q);
         const int64_t k = kbase + t;
         int64_t kd = k + SH;
         if (kd >= nxj) kd -= nxj;
@@ -413,12 +379,12 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
                 vP[qq] = odd ? rP[qq] : P[qq].x;  vP[NO + qq] = odd ? P[qq].y : rP[qq];
                 vQ[qq] = odd ? rQ[qq] : Q[qq].x;  vQ[NO + qq] = odd ? Q[qq].y : rQ[qq];
             }
-            if (valid && (LVL1 != 3 || vP[0] == (T)123456.789)) {
+            if (valid) {
                 // even: LL / ds of column k at row ko;   odd: sd / dd of column kd at row ko-2
                 T *pP = odd ? (yl - NO + (nxj + kd) * a.ldy) : (llp + k * ldl);
                 T *pQ = odd ? (yl - NO + (nxj + kd) * a.ldy + hm) : (yl + k * a.ldy + hm);
-                if (a.nt & 2) { vstore_nt<T, 4>(pP, vP); vstore_nt<T, 4>(pQ, vQ); }
-                else { vstore<T, 4>(pP, vP); vstore<T, 4>(pQ, vQ); }
+                vstore<T, 4>(pP, vP);
+                vstore<T, 4>(pQ, vQ);
             }
         } else {
             if (valid) {
@@ -1153,7 +1119,7 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     Fwd2DArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
     a.nstrips = (int)((ms + VR - 1) / VR);
-    a.nt = env_int("WL_NT", 0) | ((!lvl1 && env_int("WL_REVERSE", 1)) ? 4 : 0);
+    a.nt = (!lvl1 && env_int("WL_REVERSE", 1)) ? 4 : 0;
     int TJ = env_int("WL_TJ", 128);
     // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
     // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16
@@ -1166,11 +1132,7 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     a.tp = shrink<T, F>(taps);
     const unsigned wpb = 1;      // waves per workgroup (4-wave workgroups measured no faster)
     const unsigned nwg = ((unsigned)(a.nstrips * a.nchunks) + wpb - 1) / wpb;
-    const int probe = env_int("WL_PROBE", 0);
-    if (probe == 1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 2>), dim3(nwg), dim3(64 * wpb), 0, st, a);
-    else if (probe == 2) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 3>), dim3(nwg), dim3(64 * wpb), 0, st, a);
-    else if (probe == 3) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 4>), dim3(nwg), dim3(64 * wpb), 0, st, a);
-    else if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64 * wpb), 0, st, a);
     return hipGetLastError();
 }
@@ -1180,10 +1142,6 @@ static hipError_t launch_fwd2d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
                                T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
 {
     constexpr int RPL = 16 / sizeof(T);
-    if constexpr (sizeof(T) == 4 && F <= 8) {
-        if (env_int("WL_RPL", 4) == 8 && ms >= 1024 && (ms % 16) == 0)
-            return launch_fwd2d_r<T, F, 8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    }
     return launch_fwd2d_r<T, F, RPL>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
 }
 

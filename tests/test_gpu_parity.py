@@ -111,6 +111,57 @@ def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
     assert np.array_equal(y, oracle.dwt_filter(x, W.wavelet(W.WT.db4).qmf, 3))
 
 
+def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle, monkeypatch):
+    """Seeded random sweep over shapes that sit on the eligibility boundaries of the fast kernels
+    (strip/tile/chunk multiples, alignment, wrap) -- forward and inverse, against the oracle."""
+    monkeypatch.setenv("WL_FUSE2_MIN", "0")
+    rs = np.random.default_rng(2024)
+    filters = ["haar", "db2", "db3", "db4", "db5", "sym4", "coif2"]
+    n1d = [504, 512, 520, 1000, 1024, 2040, 4088, 16384, 16392, 20480, 32768, 49152, 65536 + 64]
+    for n in n1d:
+        x = rng_array((n,), np.float32 if rs.random() < 0.7 else np.float64, n)
+        Lmax = W.maxtransformlevels(n)
+        for _ in range(2):
+            wt = W.wavelet(getattr(W.WT, filters[rs.integers(len(filters))]))
+            L = int(rs.integers(1, Lmax + 1))
+            ye = oracle.dwt_filter(x, wt.qmf, L)
+            assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (n, wt.name, L, W.last_kernel())
+            assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (n, wt.name, L, "inv")
+    dims = [240, 248, 256, 264, 496, 504, 512, 528, 544, 1024, 1040]
+    cols = [16, 24, 32, 48, 64, 96, 128, 136, 256, 272]
+    for _ in range(40):
+        m, n = int(dims[rs.integers(len(dims))]), int(cols[rs.integers(len(cols))])
+        if rs.random() < 0.3:
+            m, n = n * 4, m // 4 * 2
+        x = rng_array((m, n), np.float32 if rs.random() < 0.75 else np.float64, m * 7 + n)
+        Lmax = W.maxtransformlevels(x)
+        if Lmax == 0:
+            continue
+        wt = W.wavelet(getattr(W.WT, filters[rs.integers(len(filters))]))
+        L = int(rs.integers(1, Lmax + 1))
+        ye = oracle.dwt_filter(x, wt.qmf, L)
+        assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), ((m, n), x.dtype, wt.name, L, W.last_kernel())
+        assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), oracle.dwt_filter(ye, wt.qmf, L, fw=False)), ((m, n), wt.name, L, "inv")
+    # lifting lines around the stream / tail thresholds
+    for n in (504, 512, 520, 8192, 8200, 16384, 16392, 32768 + 8, 65536):
+        x = rng_array((n,), np.float32 if n % 16 else np.float64, n)
+        sch = W.wavelet(getattr(W.WT, ("cdf97", "db2", "haar")[n % 3]), W.WT.Lifting)
+        L = int(rs.integers(1, W.maxtransformlevels(n) + 1))
+        ye = oracle.dwt_lifting(x, sch, L)
+        assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (n, sch.name, L, W.last_kernel())
+        t = dev(W, ye)
+        W.idwt_(t, sch, L)
+        assert np.array_equal(host(W, t), oracle.dwt_lifting(ye, sch, L, fw=False)), (n, sch.name, L, "inv in place")
+    # batched columns with leading dimension / line counts around the slab and alignment rules
+    for (n, ns) in ((520, 3), (4096, 5), (16392, 2), (32768, 9)):
+        x = rng_array((n, ns), np.float32, n + ns)
+        wt = W.wavelet(W.WT.db4)
+        L = W.maxtransformlevels(n)
+        ye = oracle.dwtc_filter(x, wt.qmf, L)
+        assert np.array_equal(host(W, W.dwtc(dev(W, x), wt, L)), ye), (n, ns)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ye), wt, L)), oracle.dwtc_filter(ye, wt.qmf, L, fw=False))
+
+
 # ---- lifting ----------------------------------------------------------------------------------------
 LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256),
            (4, 4, 4), (16, 16, 16), (24, 24, 24)]

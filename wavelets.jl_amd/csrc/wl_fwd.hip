@@ -946,7 +946,9 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *A = reinterpret_cast<T *>(smem_raw);
     T *B = A + a.cap;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x;
+    int nthr = blockDim.x;
+    bool multi = nthr > 64;      // several waves -> workgroup barriers; wave 0 alone -> LDS wait only
     const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
     T *y = a.y + (int64_t)blockIdx.x * a.y_item;
     int m0 = a.m0, m1 = a.m1;
@@ -1001,6 +1003,11 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
     for (int lev = 0; lev < a.nlev; ++lev) {
         const bool last = (lev == a.nlev - 1);
         const int h0 = m0 >> 1;
+        // small levels: hand the rest of the transform to wave 0 (no barrier round trips)
+        if (multi && m0 * m1 <= 256) {
+            if (tid >= 64) return;
+            multi = false; nthr = 64;
+        }
         const int lg0 = ilog2_or_neg(m0), lgh = ilog2_or_neg(h0);
         if (a.nt == 1) {
             // single line of length m0 in A
@@ -1011,7 +1018,7 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
                 if (last) y[k] = s;
                 else B[k] = s;
             }
-            lds_barrier();
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             T *t = A; A = B; B = t;
             m0 = h0;
         } else {
@@ -1029,7 +1036,7 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
                 B[i0 + (h1 + k0) * ld] = d0;
                 if (two) { B[i1 + k1 * ld] = s1; B[i1 + (h1 + k1) * ld] = d1; }
             }
-            lds_barrier();
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // dim-1 pass: B -> details to y, LL to A (h0 x h1) or y
             for (int idx = tid; idx < h0 * m1; idx += 2 * nthr) {
                 int k0, j0, k1 = 0, j1 = 0;
@@ -1048,7 +1055,7 @@ __global__ void __launch_bounds__(1024) k_tail_fwd(TailArgs<T> a, Taps<T> tp)
                     else y[(int64_t)j1 * a.ldy + k1] = s1;
                 }
             }
-            lds_barrier();
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             m0 = h0;
             m1 = h1;
         }

@@ -196,6 +196,119 @@ __global__ void __launch_bounds__(256) k_lift1d_stream(Lift1DArgs<T> a)
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// Three forward lifting levels per pass over HBM, entirely in registers: after level t the lane keeps
+// its normalised approximations (4, then 2, then 1 pairs per lane) and runs level t+1 on them; the
+// out-of-lane operands again come from the neighbouring lanes by DPP (distance up to 2 lanes at the
+// last level).  The dependency cone costs 4 lanes at each wave edge (lanes 4..59 own 224 pairs).
+// Traffic: read n, write n for three levels (level by level: 3.5 n) and a third of the launches.
+constexpr __host__ __device__ int l_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+template <typename T, int PPL>
+__device__ __forceinline__ T lane_operand(const T (&op)[PPL], int off)
+{
+    // value of op at pair offset `off` relative to this lane's first pair (off is a compile-time constant
+    // at every call site after unrolling)
+    const int delta = l_floordiv(off, PPL);
+    const int e = off - delta * PPL;
+    T v = op[e];
+    if (delta == 1) v = l_next(v);
+    else if (delta == 2) v = l_next(l_next(v));
+    else if (delta == -1) v = l_prev(v);
+    else if (delta == -2) v = l_prev(l_prev(v));
+    return v;
+}
+
+template <typename T, int ID, int PPL>
+__device__ __forceinline__ void lift_steps_lane(T (&s)[PPL], T (&d)[PPL], const T (&c)[WL_MAX_STEPS][WL_MAX_NCOEF],
+                                                int64_t kfirst, int64_t half)
+{
+    typedef Shape<ID> SH;
+#pragma unroll
+    for (int st = 0; st < SH::NS; ++st) {
+        const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+        T res[PPL];
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) {
+            T o[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                o[kk] = (T)0;
+                if (kk < nc) o[kk] = upd ? lane_operand<T, PPL>(s, jj + kk - sh) : lane_operand<T, PPL>(d, jj + kk - sh);
+            }
+            const int64_t jg = kfirst + jj - sh;
+            const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+            const T x = upd ? d[jj] : s[jj];
+            T acc = c[st][0] * o[0];
+            if (nc > 1) acc = acc + c[st][1] * o[1];
+            if (nc > 2) acc = acc + c[st][2] * o[2];
+            const T xin = x + acc;
+            T xb = x + c[st][0] * o[0];
+            if (nc > 1) xb = xb + c[st][1] * o[1];
+            if (nc > 2) xb = xb + c[st][2] * o[2];
+            res[jj] = inb ? xin : xb;
+        }
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) { if (upd) d[jj] = res[jj]; else s[jj] = res[jj]; }
+    }
+}
+
+template <typename T>
+struct Lift3Args {
+    const T *src; int64_t src_ls;
+    T *y; int64_t y_ls;             // details: level t (1..3) at y[(n >> t) + k]
+    T *d1; int64_t d1_ls;           // level-1 detail destination (y + n/2, or a staging buffer)
+    T *sdst; int64_t s_ls;          // approximation after three levels
+    int64_t n;
+    int64_t ntiles;
+    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(256) k_lift1d_fwd3(Lift3Args<T> a)
+{
+    constexpr int ML = 4, VP = (64 - 2 * ML) * 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t n = a.n, half = n >> 1;
+    const int64_t line = blockIdx.y;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k0 = tile * VP + (int64_t)(lane - ML) * 4;
+        int64_t kw = k0;
+        if (kw < 0) kw += half;
+        if (kw >= half) kw -= half;
+        T v[8];
+        ld8<T>(a.src + line * a.src_ls + 2 * kw, v);
+        T s1[4], d1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[j] = v[2 * j]; d1[j] = v[2 * j + 1]; }
+        lift_steps_lane<T, ID, 4>(s1, d1, a.c, kw, half);
+        T s2[2], d2[2], dO1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dO1[j] = d1[j] * a.norm2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { s2[j] = s1[2 * j] * a.norm1; d2[j] = s1[2 * j + 1] * a.norm1; }
+        lift_steps_lane<T, ID, 2>(s2, d2, a.c, kw >> 1, half >> 1);
+        T s3[1], d3[1], dO2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dO2[j] = d2[j] * a.norm2;
+        s3[0] = s2[0] * a.norm1;
+        d3[0] = s2[1] * a.norm1;
+        lift_steps_lane<T, ID, 1>(s3, d3, a.c, kw >> 2, half >> 2);
+        if (lane >= ML && lane < 64 - ML && k0 < half) {
+            stN<T, 4>(a.d1 + line * a.d1_ls + k0, dO1);
+            typedef T V2 __attribute__((ext_vector_type(2)));
+            V2 t2; t2[0] = dO2[0]; t2[1] = dO2[1];
+            *reinterpret_cast<V2 *>(a.y + line * a.y_ls + (n >> 2) + (k0 >> 1)) = t2;
+            a.y[line * a.y_ls + (n >> 3) + (k0 >> 2)] = d3[0] * a.norm2;
+            a.sdst[line * a.s_ls + (k0 >> 2)] = s3[0] * a.norm1;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // LDS tail: all remaining levels of one line per workgroup (any scheme)
 template <typename T>
@@ -208,8 +321,22 @@ struct LiftTailArgs {
     int cap;
 };
 
+// Synchronisation inside the tail kernels: a workgroup barrier while several waves work on the line,
+// just "my own LDS traffic has landed" once only wave 0 is left (small levels: the other waves have
+// returned, and a barrier round trip per lifting step would dominate the run time).
+__device__ __forceinline__ void tail_sync(bool multi)
+{
+    if (multi) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void tail_sync_vm(bool multi)
+{
+    if (multi) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 template <typename T>
-__device__ __forceinline__ void tail_lift_steps(T *w, int half, const LiftScheme<T> &sc, int tid, int nthr)
+__device__ __forceinline__ void tail_lift_steps(T *w, int half, const LiftScheme<T> &sc, int tid, int nthr, bool multi)
 {
     for (int st = 0; st < sc.nsteps; ++st) {
         const LiftStep<T> &sp = sc.step[st];
@@ -234,9 +361,11 @@ __device__ __forceinline__ void tail_lift_steps(T *w, int half, const LiftScheme
             }
             tgt[j] = x;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        tail_sync(multi);
     }
 }
+
+constexpr int kSingleWavePairs = 128;     // levels with at most this many pairs run on wave 0 alone
 
 template <typename T, int FW>
 __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftScheme<T> sc)
@@ -244,18 +373,30 @@ __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftSchem
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *A = reinterpret_cast<T *>(smem_raw);       // current approximation (natural order)
     T *W = A + a.cap;                             // [s ; d] work line
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x;
+    int nthr = blockDim.x;
+    bool multi = nthr > 64;
     T *y = a.y + (int64_t)blockIdx.x * a.y_item;
     if (FW) {
         const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
         int n = a.n0;
-        for (int i = tid; i < n; i += nthr) A[i] = src[i];
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i0 = tid; i0 < n; i0 += 8 * nthr) {       // eight independent loads in flight per thread
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * nthr < n) v[u] = src[i0 + u * nthr];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * nthr < n) A[i0 + u * nthr] = v[u];
+        }
+        tail_sync_vm(multi);
         for (int lev = 0; lev < a.nlev; ++lev) {
             const int half = n >> 1;
+            if (multi && half <= kSingleWavePairs) {      // hand the rest to wave 0 (all earlier LDS writes are synced)
+                if (tid >= 64) return;
+                multi = false; nthr = 64;
+            }
             for (int j = tid; j < half; j += nthr) { W[j] = A[2 * j]; W[half + j] = A[2 * j + 1]; }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            tail_lift_steps<T>(W, half, sc, tid, nthr);
+            tail_sync(multi);
+            tail_lift_steps<T>(W, half, sc, tid, nthr, multi);
             const bool last = (lev == a.nlev - 1);
             for (int j = tid; j < half; j += nthr) {
                 T s = W[j] * sc.norm1, d = W[half + j] * sc.norm2;
@@ -263,27 +404,41 @@ __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftSchem
                 if (last) y[j] = s;
                 else A[j] = s;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            tail_sync(multi);
             n = half;
         }
     } else {
-        // deepest level first: output lengths n0 >> (nlev-1), ..., n0
+        // deepest level first: output lengths n0 >> (nlev-1), ..., n0.  Small levels come FIRST here, so
+        // wave 0 starts alone and the other waves join (after one barrier) when the level is big enough.
         const T *ll = a.ll + (int64_t)blockIdx.x * a.ll_item;
         const T *src = a.src + (int64_t)blockIdx.x * a.src_item;     // detail coefficients live in src (x)
         int n = a.n0 >> (a.nlev - 1);
-        for (int j = tid; j < (n >> 1); j += nthr) A[j] = ll[j];
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool have_multi = multi;
+        bool solo = have_multi && (n >> 1) <= kSingleWavePairs;
+        if (!solo || tid < 64) {
+            const int nt0 = solo ? 64 : nthr;
+            for (int j = tid; j < (n >> 1); j += nt0) A[j] = ll[j];
+        }
+        tail_sync_vm(have_multi);
         for (int lev = 0; lev < a.nlev; ++lev) {
             const int half = n >> 1;
-            for (int j = tid; j < half; j += nthr) { W[j] = sc.norm1 * A[j]; W[half + j] = sc.norm2 * src[half + j]; }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            tail_lift_steps<T>(W, half, sc, tid, nthr);
+            solo = have_multi && half <= kSingleWavePairs;
             const bool last = (lev == a.nlev - 1);
-            for (int j = tid; j < half; j += nthr) {
-                if (last) { y[2 * j] = W[j]; y[2 * j + 1] = W[half + j]; }
-                else { A[2 * j] = W[j]; A[2 * j + 1] = W[half + j]; }
+            if (!solo || tid < 64) {
+                const int nt = solo ? 64 : nthr;
+                const bool m = have_multi && !solo;
+                for (int j = tid; j < half; j += nt) { W[j] = sc.norm1 * A[j]; W[half + j] = sc.norm2 * src[half + j]; }
+                tail_sync_vm(m);
+                tail_lift_steps<T>(W, half, sc, tid, nt, m);
+                for (int j = tid; j < half; j += nt) {
+                    if (last) { y[2 * j] = W[j]; y[2 * j + 1] = W[half + j]; }
+                    else { A[2 * j] = W[j]; A[2 * j + 1] = W[half + j]; }
+                }
+                tail_sync(m);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // when the NEXT level switches from solo to all waves, everybody meets here once
+            const bool next_solo = have_multi && (half << 1) <= kSingleWavePairs;
+            if (solo && !next_solo && !last) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             n <<= 1;
         }
     }
@@ -315,6 +470,21 @@ static void launch_stream_id(hipStream_t st, const Lift1DArgs<T> &a, int64_t nli
     }
 }
 
+template <typename T, int ID>
+static void launch_fwd3_id(hipStream_t st, const Lift3Args<T> &a, int64_t nlines, int cu_count)
+{
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    const int64_t slab = l_env("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Lift3Args<T> b = a;
+        b.src = a.src + l0 * a.src_ls; b.y = a.y + l0 * a.y_ls; b.d1 = a.d1 + l0 * a.d1_ls; b.sdst = a.sdst + l0 * a.s_ls;
+        hipLaunchKernelGGL((k_lift1d_fwd3<T, ID>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+    }
+}
+
 template <typename T>
 static int match_shape(const LiftScheme<T> &sc)
 {
@@ -343,7 +513,9 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     const int id = match_shape<T>(sc);
     if (L < 1 || !al16(x) || !al16(y)) return WL_OK;
     if (nlines > 1 && (ld % VEC) != 0) return WL_OK;
-    const int cap = lift_tail_cap<T>();
+    // the LDS tail can hold up to lift_tail_cap samples; a single line (or a few) hands over later, at 2048
+    // samples, because one workgroup is slow on a long line while the streaming kernels use the whole chip
+    const int cap = (nlines >= 32) ? lift_tail_cap<T>() : 2048;
     // every level must be either stream-able (known shape, n_l >= 512, n_l % 8 == 0) or inside the tail
     int l_tail = L + 1;                       // first level (1-based) handled by the tail (fw) ...
     for (int l = 1; l <= L; ++l) {
@@ -379,6 +551,28 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
         for (int l = 1; l < l_tail && l <= L; ++l) {
             const int64_t nl = n >> (l - 1), hl = nl >> 1;
             const bool last = (l == L);
+            // three levels per launch while the line is long (forward shapes 0/2/4), not for the in-place
+            // first level (its outputs would land in regions other waves still read)
+            if ((id == 0 || id == 2 || id == 4) && l_env("WL_LIFT3", 1) && (L - l + 1) >= 3 && (l + 2 < l_tail) &&
+                nl >= 4096 && (nl % 32) == 0 && !(inplace && l == 1)) {
+                const bool last3 = (l + 2 == L);
+                T *llbuf3 = pp ? w.B : w.A;
+                Lift3Args<T> a3;
+                for (int i = 0; i < WL_MAX_STEPS; ++i)
+                    for (int k = 0; k < WL_MAX_NCOEF; ++k) a3.c[i][k] = a.c[i][k];
+                a3.norm1 = a.norm1; a3.norm2 = a.norm2;
+                a3.src = cur; a3.src_ls = cur_ls; a3.y = y; a3.y_ls = ld; a3.d1 = y + hl; a3.d1_ls = ld;
+                a3.sdst = last3 ? y : llbuf3; a3.s_ls = last3 ? ld : (nl >> 3);
+                a3.n = nl; a3.ntiles = (hl + 223) / 224;
+                if (id == 0) launch_fwd3_id<T, 0>(st, a3, nlines, cu_count);
+                else if (id == 2) launch_fwd3_id<T, 2>(st, a3, nlines, cu_count);
+                else launch_fwd3_id<T, 4>(st, a3, nlines, cu_count);
+                WL_CHECK_LAUNCH();
+                if (!dom) dom = "k_lift1d_fwd3";
+                cur = llbuf3; cur_ls = nl >> 3; pp ^= 1;
+                l += 2;
+                continue;
+            }
             T *llbuf = pp ? w.B : w.A;
             a.a = cur; a.a_ls = cur_ls; a.b = nullptr; a.b_ls = 0;
             // in place, level 1 reads all of y while other waves would already write s / d into it:

@@ -163,7 +163,7 @@ def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle, monkeypatch)
 
 
 # ---- lifting ----------------------------------------------------------------------------------------
-LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256),
+LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256), (512, 512), (1024, 1024), (576, 576),
            (4, 4, 4), (16, 16, 16), (24, 24, 24)]
 
 

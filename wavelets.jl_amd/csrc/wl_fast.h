@@ -35,4 +35,10 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
                        T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
                        int *handled, const char **kernel_name, int *hip_err);
 
+// 2-D lifting transform of a square n0 x n0 array (leading dimension ldy) through the fused line
+// kernels + tiled transposes.  *handled = 1 when it was enqueued.
+template <typename T>
+int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
+                    const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
+
 }  // namespace wl

@@ -1233,7 +1233,7 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
     Multi2DArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.M = M; a.N = N; a.NL = NL;
     // owned tile: 64 x 64 inputs, smaller while there would be fewer than ~64 workgroups
-    int OT = 64;
+    int OT = (NL >= 3) ? 32 : 64;          // (OT + 2*H0)^2 tile + two row-pass buffers must fit 160 KiB of LDS
     const int mn = M < N ? M : N;
     while (OT > 16 && ((int64_t)(M / OT) * (N / OT) < 64 || OT > mn)) OT >>= 1;
     a.OT = OT;
@@ -1302,7 +1302,10 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 128) &&
             n[1] <= env_int("WL_M2D_MAX", 128) && n[0] >= 64 && n[1] >= 64 && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
             cur_st.s[0] == 1) {
-            int NL = (L - l + 1) >= 2 ? 2 : 1;
+            int NL = (L - l + 1);
+            const int nl2max = env_int("WL_M2D_NL", 2);
+            if (NL > nl2max) NL = nl2max;
+            while (NL > 1 && ((n[0] >> NL) < 1 || (n[1] >> NL) < 1)) --NL;
             const bool lastm = (l + NL - 1 == L);
             T *lld = lastm ? y : llbuf;
             const int64_t ldd = lastm ? b.full.s[1] : (n[0] >> NL);

@@ -1,8 +1,8 @@
 // wl_internal.h -- shared declarations of libwavelets_mi355x (not part of the ABI).
 //
 // Arithmetic contract (all kernels): products and sums are rounded separately
-// (no FMA contraction; the library is built with -ffp-contract=off and a unit
-// test greps the gfx950 ISA for v_fma/v_mac/v_fmac) and sums run in the order of
+// (no FMA contraction: the library is built with -ffp-contract=off and this header
+// sets `#pragma clang fp contract(off)`; the GPU parity tests compare bits) and sums run in the order of
 // the reference's shift-register loops:
 //   forward  s[k] = ((h0*x[2k] + h1*x[2k+1]) + h2*x[2k+2]) + ...            (m ascending)
 //            d[k] = ((g[F-1]*x[2k+2-F] + g[F-2]*x[2k+3-F]) + ...) + g0*x[2k+1] (m descending)
@@ -121,12 +121,6 @@ inline Extent3 low_corner(const BoxSpec &b, const int64_t n[3])
     for (int d = 0; d < 3; ++d) lo.n[d] = (d < b.nt) ? (n[d] >> 1) : n[d];
     return lo;
 }
-
-// ---- un-fused arithmetic helpers ----
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
 
 __device__ __forceinline__ int64_t pmod(int64_t a, int64_t n)
 {

@@ -31,7 +31,6 @@ template <> struct Shape<2> { static constexpr int NS = 3; static constexpr Step
 template <> struct Shape<3> { static constexpr int NS = 3; static constexpr StepShape S[3] = {{0, 1, -1}, {1, 2, 1}, {0, 1, 0}}; };             // db2 inv
 template <> struct Shape<4> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{0, 1, 0}, {1, 1, 0}}; };                          // haar/db1 fw
 template <> struct Shape<5> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{1, 1, 0}, {0, 1, 0}}; };                          // haar/db1 inv
-constexpr int kNumShapes = 6;
 
 template <int ID>
 static bool shape_matches(int nsteps, const int *upd, const int *nc, const int *sh)
@@ -670,5 +669,142 @@ template int lifting_lines_fast<float>(void *, int, hipStream_t, int64_t, int64_
                                        const LiftScheme<float> &, int, int, int *, const char **, int *);
 template int lifting_lines_fast<double>(void *, int, hipStream_t, int64_t, int64_t, int64_t, double *, const double *,
                                         const LiftScheme<double> &, int, int, int *, const char **, int *);
+
+// --------------------------------------------------------------------------------------------------
+// 2-D lifting (square arrays): each level is the reference's two passes -- rows (dim 2) then columns
+// (dim 1) forward, the reverse inverse (transforms_lifting.jl:158-189) -- with every pass executed
+// by the fused LINE kernel: the strided dim-2 pass becomes contiguous lines after a tiled LDS
+// transpose (same arithmetic per line => same bits).  4 streaming passes per level instead of the
+// generic path's ~14 strided ones.  Levels smaller than 512 fall back to the generic kernels.
+template <typename T>
+__global__ void __launch_bounds__(256) k_transpose(const T *__restrict__ src, int64_t lds, T *__restrict__ dst, int64_t ldd)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[(i0 + tx) + (j0 + r) * lds];       // tile[j][i]
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) dst[(j0 + tx) + (i0 + r) * ldd] = tile[tx][r];       // dst[j + i*ldd]
+}
+
+template <typename T>
+static hipError_t launch_transpose(hipStream_t st, const T *src, int64_t lds, T *dst, int64_t ldd, int64_t n)
+{
+    hipLaunchKernelGGL((k_transpose<T>), dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, src, lds, dst, ldd);
+    return hipGetLastError();
+}
+
+template <typename T, int FWV>
+static void launch_lines_id(int id, hipStream_t st, const Lift1DArgs<T> &a, int64_t nlines, int cu_count)
+{
+    switch (id) {
+    case 0: launch_stream_id<T, 0, FWV>(st, a, nlines, cu_count); break;
+    case 1: launch_stream_id<T, 1, FWV>(st, a, nlines, cu_count); break;
+    case 2: launch_stream_id<T, 2, FWV>(st, a, nlines, cu_count); break;
+    case 3: launch_stream_id<T, 3, FWV>(st, a, nlines, cu_count); break;
+    case 4: launch_stream_id<T, 4, FWV>(st, a, nlines, cu_count); break;
+    default: launch_stream_id<T, 5, FWV>(st, a, nlines, cu_count); break;
+    }
+}
+
+template <typename T>
+int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
+                    const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err)
+{
+    *handled = 0;
+    constexpr int VEC = 16 / sizeof(T);
+    const int id = match_shape<T>(sc);
+    if (id < 0 || L < 1 || n0 < 512 || (n0 % 64) != 0 || (ldy % VEC) != 0 || !al16(x) || !al16(y)) return WL_OK;
+#define WL_E(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } } while (0)
+#define WL_EL() WL_E(hipGetLastError())
+    const int64_t N = n0 * n0;
+    Work<T> w = carve<T>(ws, N);
+    Lift1DArgs<T> a;
+    for (int i = 0; i < WL_MAX_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    Strides3 full = {{1, ldy, ldy * n0}};
+    auto fast_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
+
+    if (fw) {
+        const T *cur = x;
+        int64_t cur_ls = ldy;
+        int pp = 0;
+        for (int l = 1; l <= L; ++l) {
+            const int64_t n = n0 >> (l - 1), h = n >> 1;
+            const bool last = (l == L);
+            T *llbuf = pp ? w.B : w.A;
+            T *lld = last ? y : llbuf;
+            const int64_t ldd = last ? ldy : h;
+            if (fast_ok(n)) {
+                WL_E(launch_transpose<T>(st, cur, cur_ls, w.T0, n, n));                 // T0[j + i*n] = cur[i, j]
+                a.a = w.T0; a.a_ls = n; a.b = nullptr; a.b_ls = 0;                      // rows as lines
+                a.o0 = w.T1; a.o0_ls = n; a.o1 = w.T1 + h; a.o1_ls = n; a.n = n; a.ntiles = (h + 247) / 248;
+                launch_lines_id<T, 1>(id, st, a, n, cu_count); WL_EL();
+                WL_E(launch_transpose<T>(st, w.T1, n, w.T0, n, n));                     // back to normal orientation
+                // columns [0, h): s -> LL, d -> y[h.., j]
+                a.a = w.T0; a.a_ls = n; a.o0 = lld; a.o0_ls = ldd; a.o1 = y + h; a.o1_ls = ldy;
+                launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
+                // columns [h, n): s -> y[0..h, j], d -> y[h.., j]
+                a.a = w.T0 + h * n; a.o0 = y + h * ldy; a.o0_ls = ldy; a.o1 = y + h * ldy + h; a.o1_ls = ldy;
+                launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
+            } else {
+                Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
+                Strides3 box = {{1, n, n * n}}, cst = {{1, cur_ls, cur_ls * n}}, lst = {{1, ldd, ldd * h}};
+                // rows (axis 1) then columns (axis 0), as generic_lifting_fwd
+                WL_E(generic_lift_split<T>(st, cur, cst, w.W, box, ext, 1));
+                for (int q = 0; q < sc.nsteps; ++q) WL_E(generic_lift_step<T>(st, sc.step[q], w.W, box, ext, 1));
+                WL_E(generic_lift_finish_fwd<T>(st, sc.norm1, sc.norm2, w.W, box, w.T0, box, (T *)nullptr, box, ext, 1, lo));
+                WL_E(generic_lift_split<T>(st, w.T0, box, w.W, box, ext, 0));
+                for (int q = 0; q < sc.nsteps; ++q) WL_E(generic_lift_step<T>(st, sc.step[q], w.W, box, ext, 0));
+                WL_E(generic_lift_finish_fwd<T>(st, sc.norm1, sc.norm2, w.W, box, y, full, last ? (T *)nullptr : llbuf, lst, ext, 0, lo));
+            }
+            cur = llbuf; cur_ls = h; pp ^= 1;
+        }
+    } else {
+        const T *llsrc = nullptr;
+        int64_t ll_ls = 0;
+        int pp = 0;
+        for (int l = L; l >= 1; --l) {
+            const int64_t n = n0 >> (l - 1), h = n >> 1;
+            T *out = (l == 1) ? y : (pp ? w.B : w.A);
+            const int64_t ldo = (l == 1) ? ldy : n;
+            if (fast_ok(n)) {
+                // columns: merged column j -> T0[:, j]
+                a.o0 = w.T0; a.o0_ls = n; a.o1 = nullptr; a.o1_ls = 0; a.n = n; a.ntiles = (h + 247) / 248;
+                if (llsrc) { a.a = llsrc; a.a_ls = ll_ls; } else { a.a = x; a.a_ls = ldy; }
+                a.b = x + h; a.b_ls = ldy;
+                launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
+                a.a = x + h * ldy; a.a_ls = ldy; a.b = x + h * ldy + h; a.b_ls = ldy; a.o0 = w.T0 + h * n;
+                launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
+                WL_E(launch_transpose<T>(st, w.T0, n, w.T1, n, n));                     // rows as lines
+                a.a = w.T1; a.a_ls = n; a.b = w.T1 + h; a.b_ls = n; a.o0 = w.T0; a.o0_ls = n;
+                launch_lines_id<T, 0>(id, st, a, n, cu_count); WL_EL();
+                WL_E(launch_transpose<T>(st, w.T0, n, out, ldo, n));
+            } else {
+                Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
+                Strides3 box = {{1, n, n * n}}, lst = {{1, ll_ls, ll_ls * h}}, ost = {{1, ldo, ldo * n}};
+                WL_E(generic_lift_norm_inv<T>(st, sc.norm1, sc.norm2, x, full, llsrc, lst, w.W, box, ext, 0, lo));
+                for (int q = 0; q < sc.nsteps; ++q) WL_E(generic_lift_step<T>(st, sc.step[q], w.W, box, ext, 0));
+                WL_E(generic_lift_merge<T>(st, w.W, box, w.T0, box, ext, 0));
+                WL_E(generic_lift_norm_inv<T>(st, sc.norm1, sc.norm2, w.T0, box, (const T *)nullptr, box, w.W, box, ext, 1, lo));
+                for (int q = 0; q < sc.nsteps; ++q) WL_E(generic_lift_step<T>(st, sc.step[q], w.W, box, ext, 1));
+                WL_E(generic_lift_merge<T>(st, w.W, box, out, ost, ext, 1));
+            }
+            llsrc = out; ll_ls = ldo; pp ^= 1;
+        }
+    }
+#undef WL_E
+#undef WL_EL
+    *handled = 1;
+    if (kernel_name) *kernel_name = "k_lift1d_stream+k_transpose";
+    return WL_OK;
+}
+template int lifting_2d_fast<float>(void *, int, hipStream_t, int64_t, int64_t, float *, const float *, const LiftScheme<float> &,
+                                    int, int, int *, const char **, int *);
+template int lifting_2d_fast<double>(void *, int, hipStream_t, int64_t, int64_t, double *, const double *,
+                                     const LiftScheme<double> &, int, int, int *, const char **, int *);
 
 }  // namespace wl

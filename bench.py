@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=None, help="override L (default: maxtransformlevels)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--path", type=int, default=0, help="0 fast kernels, 1 generic kernels only")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs")
     return ap.parse_args()
 
 
@@ -147,12 +148,44 @@ def main():
 
     if rank == 0:
         out["roofline"] = roofline_leg(W, x, wt, batched, esize, args, kernel)
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_secondary:
+        del yout
+        out["secondary_configs"] = secondary_leg(W, device)
+    if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_leg(W, args.workload, wt, L)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_leg(W, device):
+    """Short device-timed runs of the other BASELINE.json configs (parity-test configs, not the headline):
+    reported for context only."""
+    res = []
+    for name in ("c1", "c2", "c4", "c5"):
+        label, x, wt, L, dtag = make_workload(W, name, device, 42)
+        y = W.similar(x)
+        fn = (lambda: W.dwtc_(y, x, wt, L)) if name == "c5" else (lambda: W.dwt_oop_(y, x, wt, L))
+        W.reserve_workspace(x, L)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res.append({"workload": label, "L": int(L), "dtype": dtag, "ms_per_step": round(ms, 5),
+                    "Msamples_per_s": round(x.numel() / ms / 1e3, 1),
+                    "algorithmic_GBps": round(2 * x.numel() * x.element_size() / ms / 1e6, 1), "kernel": W.last_kernel()})
+        del x, y
+        torch.cuda.empty_cache()
+    return res
 
 
 def _time_launches(fn, reps):

@@ -766,7 +766,6 @@ template <typename T, int F>
 __global__ void __launch_bounds__(512) k_fwd2d_multi(Multi2DArgs<T, F> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int NT = 512;
     const int tid = threadIdx.x;
     const int ti = tid & 63, tj = tid >> 6;        // 64 threads along dim 1, 8 along dim 2
     const int NL = a.NL;

@@ -205,6 +205,169 @@ __global__ void __launch_bounds__(64) k_inv_dim2_stream(InvD2Args<T, F> a)
     for (int u = 0; u < R; ++u) step(t0 + u, u, u <= SH);     // last group: columns beyond the chunk's window are not fetched
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS tail for the inverse: the deepest levels (output block <= 16 Ki f32 / 8 Ki f64 elements, 1-D line
+// per workgroup or one 2-D block) reconstructed inside one workgroup.  The running reconstruction stays
+// in LDS (fixed leading dimension, so the next level only has to stage its detail quadrants around it);
+// true periodic indexing, any filter length (FC = 0: run-time length, odd lengths included).
+template <typename T>
+struct TailInvArgs {
+    const T *x; int64_t ldx; int64_t x_item;     // coefficient array (details + deepest approximation)
+    T *out; int64_t ldo; int64_t out_item;       // reconstruction of the last level done here
+    int n0, n1;                                  // OUTPUT extents of the last level done here (n1 == 1: line)
+    int nt, nlev, cap, ld;
+};
+
+__device__ __forceinline__ int iw(int i, int n)
+{
+    while (i >= n) i -= n;
+    while (i < 0) i += n;
+    return i;
+}
+// x[o] = S + D from s[0..nx) (stride ss) and d[0..nx) (stride sd), wl_internal.h closed form
+template <typename T, int FC>
+__device__ __forceinline__ T tail_inv_one(const T *sp, int ss, const T *dp, int sd, int o, int nx, const Taps<T> &tp)
+{
+    const int F = (FC > 0) ? FC : tp.F;
+    T S = (T)0, D = (T)0;
+    bool first = true;
+    if constexpr (FC > 0) {
+#pragma unroll
+        for (int m = FC - 1; m >= 0; --m)
+            if (((o - m) & 1) == 0) {
+                T term = tp.h[m] * sp[iw((o - m) / 2, nx) * ss];
+                S = first ? term : (S + term);
+                first = false;
+            }
+        first = true;
+#pragma unroll
+        for (int m = 0; m < FC; ++m)
+            if (((o + m - 1) & 1) == 0) {
+                T term = tp.g[m] * dp[iw((o + m - 1) / 2, nx) * sd];
+                D = first ? term : (D + term);
+                first = false;
+            }
+    } else {
+        for (int m = F - 1; m >= 0; --m)
+            if (((o - m) & 1) == 0) {
+                T term = tp.h[m] * sp[iw((o - m) / 2, nx) * ss];
+                S = first ? term : (S + term);
+                first = false;
+            }
+        first = true;
+        for (int m = 0; m < F; ++m)
+            if (((o + m - 1) & 1) == 0) {
+                T term = tp.g[m] * dp[iw((o + m - 1) / 2, nx) * sd];
+                D = first ? term : (D + term);
+                first = false;
+            }
+    }
+    return S + D;
+}
+
+template <typename T, int FC>
+__global__ void __launch_bounds__(1024) k_tail_inv(TailInvArgs<T> a, Taps<T> tp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);
+    T *Q = P + a.cap;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const T *x = a.x + (int64_t)blockIdx.x * a.x_item;
+    T *out = a.out + (int64_t)blockIdx.x * a.out_item;
+    const int ld = a.ld;
+    if (a.nt == 1) {
+        int n = a.n0 >> (a.nlev - 1);                       // output length of the deepest level
+        for (int k = tid; k < (n >> 1); k += nthr) P[k] = x[k];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int nx = n >> 1;
+            const bool last = (lev == a.nlev - 1);
+            for (int k = tid; k < nx; k += nthr) Q[(a.n0 >> 1) + k] = x[nx + k];   // details of this level
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int o = tid; o < n; o += nthr) {
+                T v = tail_inv_one<T, FC>(P, 1, Q + (a.n0 >> 1), 1, o, nx, tp);
+                if (last) out[o] = v;
+                else Q[o] = v;                                                      // Q[0..n), n <= n0/2 here
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!last) { for (int o = tid; o < n; o += nthr) P[o] = Q[o]; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            n <<= 1;
+        }
+    } else {
+        int m0 = a.n0 >> (a.nlev - 1), m1 = a.n1 >> (a.nlev - 1);
+        // deepest approximation: top-left (m0/2 x m1/2) of x
+        for (int e = tid; e < (m0 >> 1) * (m1 >> 1); e += nthr) {
+            const int j = e / (m0 >> 1), i = e - j * (m0 >> 1);
+            P[i + j * ld] = x[i + (int64_t)j * a.ldx];
+        }
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int h0 = m0 >> 1, h1 = m1 >> 1;
+            const bool last = (lev == a.nlev - 1);
+            // stage the three detail quadrants of this level around the running approximation
+            for (int e = tid; e < m0 * m1; e += nthr) {
+                const int j = e / m0, i = e - j * m0;
+                if (i >= h0 || j >= h1) P[i + j * ld] = x[i + (int64_t)j * a.ldx];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // dim-1 pass (columns): Q[:, j] from P[0..h0, j] (s) and P[h0..m0, j] (d)
+            for (int e = tid; e < m0 * m1; e += nthr) {
+                const int j = e / m0, o = e - j * m0;
+                Q[o + j * ld] = tail_inv_one<T, FC>(P + j * ld, 1, P + j * ld + h0, 1, o, h0, tp);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // dim-2 pass (rows): result[i, o] from Q[i, 0..h1) (s) and Q[i, h1..m1) (d)
+            for (int e = tid; e < m0 * m1; e += nthr) {
+                const int o = e / m0, i = e - o * m0;
+                T v = tail_inv_one<T, FC>(Q + i, ld, Q + i + h1 * ld, ld, o, h1, tp);
+                if (last) out[i + (int64_t)o * a.ldo] = v;
+                else P[i + o * ld] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            m0 <<= 1;
+            m1 <<= 1;
+        }
+    }
+}
+
+template <typename T>
+constexpr int inv_tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }
+
+template <typename T>
+static hipError_t launch_tail_inv(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, int64_t x_item,
+                                  T *out, int64_t ldo, int64_t out_item, int nitems, int n0, int n1, int nt, int nlev)
+{
+    TailInvArgs<T> a;
+    a.x = x; a.ldx = ldx; a.x_item = x_item; a.out = out; a.ldo = ldo; a.out_item = out_item;
+    a.n0 = n0; a.n1 = n1; a.nt = nt; a.nlev = nlev;
+    a.ld = (nt == 2) ? (n0 | 1) : n0;
+    a.cap = (int)((((int64_t)a.ld * n1) + 15) & ~15);
+    size_t shmem = 2 * (size_t)a.cap * sizeof(T);
+    if (nt == 1) {      // P: approximation (<= n0/2), Q: [output of the non-final levels (<= n0/2) | details (<= n0/2)]
+        a.cap = (int)((((int64_t)n0 >> 1) + 15) & ~15);
+        shmem = ((size_t)a.cap + (size_t)n0 + 16) * sizeof(T);
+    }
+    const int64_t work = (int64_t)n0 * n1;
+    const int threads = work >= 4096 ? 1024 : (work >= 512 ? 256 : 64);
+#define WL_TI(FC_)                                                                                             \
+    do {                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_inv<T, FC_>),                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+        if (e != hipSuccess) return e;                                                                         \
+        hipLaunchKernelGGL((k_tail_inv<T, FC_>), dim3((unsigned)nitems), dim3(threads), shmem, st, a, taps);   \
+    } while (0)
+    switch (taps.F) {
+    case 2: WL_TI(2); break;
+    case 4: WL_TI(4); break;
+    case 6: WL_TI(6); break;
+    case 8: WL_TI(8); break;
+    default: WL_TI(0); break;
+    }
+#undef WL_TI
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 static int i_env(const char *name, int dflt)
 {
@@ -284,7 +447,34 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
     int pp = 0;
     const T *llsrc = nullptr;              // reconstruction of the deeper level (dense), nullptr: take it from x
     Strides3 llsrc_st = {{0, 0, 0}};
-    for (int l = L; l >= 1; --l) {
+    int l_start = L;
+    // ---- LDS tail: the deepest levels whose output fits one workgroup's LDS ----
+    if (path == 0 && i_env("WL_NO_INVTAIL", 0) == 0 && (two_d || lines) && b.full.s[0] == 1) {
+        int l_lo = L + 1;
+        for (int q = L; q >= 1; --q) {
+            int64_t nq[3];
+            level_box(b, q, nq);
+            const int64_t blk = two_d ? nq[0] * nq[1] : nq[0];
+            const bool fits = two_d ? (((nq[0] | 1) * nq[1]) <= inv_tail_cap<T>() + 256 && nq[1] <= 256)
+                                    : (2 * nq[0] <= 2 * (int64_t)inv_tail_cap<T>());
+            if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 1024) && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
+        }
+        if (l_lo <= L) {
+            int64_t nq[3];
+            level_box(b, l_lo, nq);
+            const bool to_y = (l_lo == 1);
+            T *res = to_y ? y : (pp ? w.B : w.A);
+            Strides3 res_st = to_y ? b.full : dense_strides(nq);
+            if (two_d)
+                WL_TRYI(launch_tail_inv<T>(st, taps, x, b.full.s[1], 0, res, res_st.s[1], 0, 1, (int)nq[0], (int)nq[1], 2, L - l_lo + 1));
+            else
+                WL_TRYI(launch_tail_inv<T>(st, taps, x, 0, b.full.s[1], res, 0, res_st.s[1], (int)nlines, (int)nq[0], 1, 1, L - l_lo + 1));
+            dominant = "k_tail_inv";
+            llsrc = res; llsrc_st = dense_strides(nq); pp ^= 1;
+            l_start = l_lo - 1;
+        }
+    }
+    for (int l = l_start; l >= 1; --l) {
         int64_t n[3];
         level_box(b, l, n);
         Extent3 ext = {{n[0], n[1], n[2]}};

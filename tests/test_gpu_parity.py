@@ -91,6 +91,45 @@ def test_fast_and_generic_paths_agree(gpu, W, oracle, dtype):
             assert np.array_equal(yg, yf), (shape, L, fname, W.last_kernel(), np.abs(yg - yf).max())
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
+    """3-D levels assembled from k_fwd_axis_stream / k_inv_axis_stream / k_short_lines (wl_axis.hip): bit for bit
+    against the oracle and the generic kernels, forward and inverse, every supported filter length."""
+    for n, Ls in ((16, (1, 4)), (32, (1, 5)), (64, (1, 3, 6)), (128, (2,)), (256, (2,))):
+        x = rng_array((n, n, n), dtype, n)
+        for fname in ("db4", "haar", "db2", "db3", "db5", "sym8"):
+            if n >= 128 and fname not in ("db4", "db5"):
+                continue
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                xd = dev(W, x)
+                y = host(W, W.dwt(xd, wt, L))
+                kf = W.last_kernel()
+                assert (kf == "k_fwd_axis_stream") == (len(wt.qmf) <= 10), (n, fname, kf)
+                if n <= 128:
+                    ye = oracle.dwt_filter(x, wt.qmf, L)
+                else:
+                    try:
+                        W.set_kernel_path(1)
+                        ye = host(W, W.dwt(xd, wt, L))
+                    finally:
+                        W.set_kernel_path(0)
+                assert np.array_equal(y, ye), (n, fname, L, np.abs(y - ye).max())
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                ki = W.last_kernel()
+                assert (ki == "k_inv_axis_stream") == (len(wt.qmf) <= 10), (n, fname, ki)
+                if n <= 128:
+                    xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+                else:
+                    try:
+                        W.set_kernel_path(1)
+                        xe = host(W, W.idwt(dev(W, ye), wt, L))
+                    finally:
+                        W.set_kernel_path(0)
+                assert np.array_equal(xr, xe), (n, fname, L, "inv", np.abs(xr - xe).max())
+                assert np.abs(xr - x).max() < (1e-4 if dtype == np.float32 else 1e-11)
+
+
 def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
     """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
     forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic

@@ -1,0 +1,417 @@
+// wl_axis.hip -- single-axis streaming passes used to assemble the 3-D filter-bank transform
+// (reference: planes / rows / columns passes of _dwt! 3-D, transforms_filter.jl:246-287).
+//
+//   k_fwd_axis_stream / k_inv_axis_stream
+//       one level along a STRIDED axis of a (rows x axis-length) matrix whose rows are contiguous:
+//       lanes own 16 bytes of consecutive rows (coalesced 1 KiB per wave-instruction), the wave marches
+//       along the axis with a register ring; no cross-lane traffic.  A 3-D box maps onto it twice:
+//       axis 3 = matrix of n0*n1 rows x n2 columns; axis 2 = n2 independent n0 x n1 matrices (blockIdx.y).
+//   k_fwd_short_lines / k_inv_short_lines
+//       one level along the CONTIGUOUS axis for short lines (n0 in {8,...,512}: volumes are rarely longer):
+//       n0/8 lanes hold one whole line (8 samples per lane), 64/(n0/8) lines per wave; the periodic halo
+//       comes from the neighbouring lane of the same group by ds_bpermute, so there is no tile overlap.
+// Arithmetic: the closed forms of wl_internal.h, bit-identical to the generic kernels.
+#include "wl_fast.h"
+
+#include <cstdlib>
+
+namespace wl {
+
+template <typename T, int F>
+struct TapsA { T h[F]; T g[F]; };
+template <typename T, int F>
+static TapsA<T, F> shrink_a(const Taps<T> &t)
+{
+    TapsA<T, F> r;
+    for (int i = 0; i < F; ++i) { r.h[i] = t.h[i]; r.g[i] = t.g[i]; }
+    return r;
+}
+template <typename T, int N>
+__device__ __forceinline__ void a_ld(const T *p, T (&v)[N])
+{
+    constexpr int C = (16 / sizeof(T)) < N ? (16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void a_st(T *p, const T (&v)[N])
+{
+    constexpr int C = (16 / sizeof(T)) < N ? (16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int F>
+struct AxisArgs {
+    const T *src; int64_t lds; int64_t bs_src;     // column stride, batch stride
+    T *dst; int64_t ldd; int64_t bs_dst;
+    int64_t R, C;                                  // rows (contiguous), axis length
+    int TJ;                                        // forward: input columns per chunk (multiple of 16); inverse: output pairs per chunk (multiple of 8)
+    int nstrips, nchunks;
+    TapsA<T, F> tp;
+};
+
+// forward: dst[:, p] = s[p], dst[:, C/2 + p] = d[p]
+template <typename T, int F, int RPL>
+__global__ void __launch_bounds__(64) k_fwd_axis_stream(AxisArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, R = 16, U = 8, PFD = (R - F) / 2;
+    const int lane = threadIdx.x;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
+    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t row = ((int64_t)strip * 64 + lane) * RPL;
+    const bool valid = row < a.R;
+    const int64_t rr = valid ? row : 0;
+    const int64_t C = a.C, nx = C >> 1;
+    const int64_t j0 = (int64_t)chunk * a.TJ;
+    const int64_t jend = (j0 + a.TJ < C) ? (j0 + a.TJ) : C;
+    const int S = (int)((jend - j0) >> 1);          // multiple of 8
+    const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + rr;
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + rr;
+    T ring[R][RPL];
+#pragma unroll
+    for (int c = 0; c < R - 2; ++c) {
+        int64_t jc = j0 + c;
+        if (jc >= C) jc -= C;
+        a_ld<T, RPL>(base + jc * a.lds, ring[c]);
+    }
+    const int64_t kbase = j0 >> 1;
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        if (prefetch) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int64_t jc = j0 + 2 * t + (R - 2) + e;
+                if (jc >= C) jc -= C;
+                a_ld<T, RPL>(base + jc * a.lds, ring[(2 * u + R - 2 + e) % R]);
+            }
+        }
+        T sv[RPL], dv[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            T s = a.tp.h[0] * ring[(2 * u) % R][q];
+#pragma unroll
+            for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * ring[(2 * u + m) % R][q];
+            T d = a.tp.g[F - 1] * ring[(2 * u) % R][q];
+#pragma unroll
+            for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * ring[(2 * u + F - 1 - m) % R][q];
+            sv[q] = s;
+            dv[q] = d;
+        }
+        if (valid) {
+            const int64_t k = kbase + t;
+            int64_t kd = k + SH;
+            if (kd >= nx) kd -= nx;
+            a_st<T, RPL>(out + k * a.ldd, sv);
+            a_st<T, RPL>(out + (nx + kd) * a.ldd, dv);
+        }
+    };
+    int t0 = 0;
+    for (; t0 < S - U; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - PFD);
+}
+
+// inverse: src[:, 0..C/2) = s, src[:, C/2..C) = d  ->  dst[:, 0..C)
+template <typename T, int F>
+__device__ __forceinline__ void a_inv_pair(const T *sw, const T *dw, const TapsA<T, F> &tp, T &xe, T &xo)
+{
+    constexpr int SH = (F - 2) / 2;
+    T Se = tp.h[F - 2] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
+    T De = tp.g[1] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    xe = Se + De;
+    T So = tp.h[F - 1] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
+    T Do = tp.g[0] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    xo = So + Do;
+}
+
+template <typename T, int F, int RPL>
+__global__ void __launch_bounds__(64) k_inv_axis_stream(AxisArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, R = 8;
+    const int lane = threadIdx.x;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
+    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t row = ((int64_t)strip * 64 + lane) * RPL;
+    const bool valid = row < a.R;
+    const int64_t rr = valid ? row : 0;
+    const int64_t nx = a.C >> 1;
+    const int64_t p0 = (int64_t)chunk * a.TJ;
+    const int64_t pend = (p0 + a.TJ < nx) ? (p0 + a.TJ) : nx;
+    const int S = (int)(pend - p0);
+    const T *sbase = a.src + (int64_t)blockIdx.y * a.bs_src + rr;
+    const T *dbase = sbase + nx * a.lds;
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + rr;
+    T rs[R][RPL], rd[R][RPL];
+#pragma unroll
+    for (int c = 0; c < R - 1; ++c) {
+        int64_t js = p0 - SH + c;
+        if (js < 0) js += nx;
+        if (js >= nx) js -= nx;
+        int64_t jd = p0 + c;
+        if (jd >= nx) jd -= nx;
+        a_ld<T, RPL>(sbase + js * a.lds, rs[c]);
+        a_ld<T, RPL>(dbase + jd * a.lds, rd[c]);
+    }
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        if (prefetch) {
+            int64_t js = p0 - SH + t + (R - 1);
+            if (js >= nx) js -= nx;
+            int64_t jd = p0 + t + (R - 1);
+            if (jd >= nx) jd -= nx;
+            a_ld<T, RPL>(sbase + js * a.lds, rs[(u + R - 1) % R]);
+            a_ld<T, RPL>(dbase + jd * a.lds, rd[(u + R - 1) % R]);
+        }
+        T xe[RPL], xo[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sw[i] = rs[(u + i) % R][q]; dw[i] = rd[(u + i) % R][q]; }
+            a_inv_pair<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+        }
+        if (valid) {
+            const int64_t p = p0 + t;
+            a_st<T, RPL>(out + (2 * p) * a.ldd, xe);
+            a_st<T, RPL>(out + (2 * p + 1) * a.ldd, xo);
+        }
+    };
+    int t0 = 0;
+    for (; t0 < S - R; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) step(t0 + u, u, u <= SH);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// short contiguous lines; lines are addressed as a 2-D grid (i2 < c2, i3 < c3)
+template <typename T, int F>
+struct ShortArgs {
+    const T *a; int64_t a2, a3;      // fw: src          inv: approximation source
+    const T *b; int64_t b2, b3;      // fw: unused       inv: detail source
+    T *o0; int64_t o02, o03;         // fw: s dest       inv: dst
+    T *o1; int64_t o12, o13;         // fw: d dest       inv: unused
+    int n;                           // line length: 8*G, G | 64
+    int G, c2;
+    int64_t nlines;                  // c2 * c3
+    TapsA<T, F> tp;
+};
+
+template <typename T, int F, int FW>
+__global__ void __launch_bounds__(256) k_short_lines(ShortArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2;
+    const int lane = threadIdx.x & 63;
+    const int G = a.G, lpw = 64 / G;
+    const int g = lane / G, r = lane - g * G;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t li = wave * lpw + g;
+    const bool valid = li < a.nlines;
+    const int64_t lc = valid ? li : 0;
+    const int64_t i3 = lc / a.c2, i2 = lc - i3 * a.c2;
+    const int nxt = g * G + (r + 1 == G ? 0 : r + 1), prv = g * G + (r == 0 ? G - 1 : r - 1);
+    if (FW) {
+        T v[8];
+        a_ld<T, 8>(a.a + i2 * a.a2 + i3 * a.a3 + 8 * r, v);
+        constexpr int LO = -(F - 2), HI = 8 + F - 2;
+        T ext[HI - LO];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ext[e - LO] = v[e];
+#pragma unroll
+        for (int e = 0; e < F - 2; ++e) {
+            ext[8 + e - LO] = __shfl(v[e], nxt, 64);                 // next lane's first F-2 samples
+            ext[e] = __shfl(v[8 - (F - 2) + e], prv, 64);            // previous lane's last F-2 samples
+        }
+        T so[4], dO[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            T s = a.tp.h[0] * ext[2 * q - LO];
+#pragma unroll
+            for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * ext[2 * q + m - LO];
+            T d = a.tp.g[F - 1] * ext[2 * q + 1 - (F - 1) - LO];
+#pragma unroll
+            for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * ext[2 * q + 1 - m - LO];
+            so[q] = s;
+            dO[q] = d;
+        }
+        if (valid) {
+            a_st<T, 4>(a.o0 + i2 * a.o02 + i3 * a.o03 + 4 * r, so);
+            a_st<T, 4>(a.o1 + i2 * a.o12 + i3 * a.o13 + 4 * r, dO);
+        }
+    } else {
+        T s[4], d[4];
+        a_ld<T, 4>(a.a + i2 * a.a2 + i3 * a.a3 + 4 * r, s);
+        a_ld<T, 4>(a.b + i2 * a.b2 + i3 * a.b3 + 4 * r, d);
+        T sx[4 + SH], dx[4 + SH];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sx[SH + i] = s[i]; dx[i] = d[i]; }
+#pragma unroll
+        for (int i = 0; i < SH; ++i) {
+            sx[i] = __shfl(s[4 - SH + i], prv, 64);
+            dx[4 + i] = __shfl(d[i], nxt, 64);
+        }
+        T out[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a_inv_pair<T, F>(&sx[p], &dx[p], a.tp, out[2 * p], out[2 * p + 1]);
+        if (valid) a_st<T, 8>(a.o0 + i2 * a.o02 + i3 * a.o03 + 8 * r, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static inline bool a_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool short_ok(int64_t n) { return n >= 16 && n <= 512 && (n % 8) == 0 && (64 % (n / 8)) == 0; }
+
+template <typename T, int F, int FW>
+static hipError_t launch_short(hipStream_t st, const Taps<T> &taps, ShortArgs<T, F> a, int n, int c2, int64_t c3)
+{
+    a.n = n; a.G = n / 8; a.c2 = c2; a.nlines = (int64_t)c2 * c3;
+    a.tp = shrink_a<T, F>(taps);
+    if (a.nlines <= 0) return hipSuccess;
+    const int lpw = 64 / a.G;
+    const int64_t nwaves = (a.nlines + lpw - 1) / lpw;
+    hipLaunchKernelGGL((k_short_lines<T, F, FW>), dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int F, int FW>
+static hipError_t launch_axis(hipStream_t st, const Taps<T> &taps, const T *src, int64_t lds, int64_t bs_src,
+                              T *dst, int64_t ldd, int64_t bs_dst, int64_t R, int64_t C, int64_t batch, int cu_count)
+{
+    constexpr int RPL = 16 / sizeof(T);
+    AxisArgs<T, F> a;
+    a.src = src; a.lds = lds; a.bs_src = bs_src; a.dst = dst; a.ldd = ldd; a.bs_dst = bs_dst; a.R = R; a.C = C;
+    a.nstrips = (int)((R + 64 * RPL - 1) / (64 * RPL));
+    const int64_t units = FW ? C : (C >> 1);           // chunked quantity: input columns (fw) / output pairs (inv)
+    const int unit = FW ? 16 : 8;
+    int TJ = FW ? 128 : 64;
+    while (TJ > unit && (int64_t)a.nstrips * ((units + TJ - 1) / TJ) * batch < (int64_t)cu_count * 8) TJ >>= 1;
+    a.TJ = TJ;
+    a.nchunks = (int)((units + TJ - 1) / TJ);
+    a.tp = shrink_a<T, F>(taps);
+    for (int64_t b0 = 0; b0 < batch; b0 += 32768) {
+        const int64_t nb = (batch - b0 < 32768) ? (batch - b0) : 32768;
+        AxisArgs<T, F> b = a;
+        b.src = a.src + b0 * bs_src; b.dst = a.dst + b0 * bs_dst;
+        if (FW) hipLaunchKernelGGL((k_fwd_axis_stream<T, F, RPL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nb), dim3(64), 0, st, b);
+        else hipLaunchKernelGGL((k_inv_axis_stream<T, F, RPL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nb), dim3(64), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
+#define WL_DISPATCH_FA(F_, ...)                              \
+    switch (F_) {                                            \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break;    \
+    case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
+    case 10: { constexpr int FF = 10; __VA_ARGS__; } break;  \
+    default: break;                                          \
+    }
+
+// One forward 3-D level: box (n0,n1,n2) read from `cur` (strides 1, c1, c2 with c1 == n0), details to y
+// (dense full array strides 1, y1, y2), LLL corner to `ll` (dense h0,h1,h2) or to y when ll == nullptr.
+// T0/T1: dense scratch of the box size.  Returns false when the shape is not eligible.
+template <typename T>
+bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
+                      T *ll, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
+    if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||
+        (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || !a_al16(cur) || !a_al16(y) || !a_al16(T0) || !a_al16(T1) ||
+        (ll && !a_al16(ll)) || n1 > 32767)
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FA(F, {
+        // planes: axis 3 on the (n0*n1) x n2 matrix
+        *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, n0 * n1, 0, n0 * n1, n2, 1, cu_count);
+        // rows: axis 2 on n2 matrices of n0 x n1
+        if (*err == hipSuccess) *err = launch_axis<T, FF, 1>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
+        // columns: short lines, four (i2, i3) quadrants; only the low-low one sends its approximation to ll
+        for (int q3 = 0; q3 < 2 && *err == hipSuccess; ++q3)
+            for (int q2 = 0; q2 < 2 && *err == hipSuccess; ++q2) {
+                ShortArgs<T, FF> s;
+                const int64_t o2 = q2 * h1, o3 = q3 * h2;
+                s.a = T1 + o2 * n0 + o3 * n0 * n1; s.a2 = n0; s.a3 = n0 * n1; s.b = nullptr; s.b2 = s.b3 = 0;
+                if (q2 == 0 && q3 == 0 && ll) { s.o0 = ll; s.o02 = h0; s.o03 = h0 * h1; }
+                else { s.o0 = y + o2 * y1 + o3 * y2; s.o02 = y1; s.o03 = y2; }
+                s.o1 = y + h0 + o2 * y1 + o3 * y2; s.o12 = y1; s.o13 = y2;
+                *err = launch_short<T, FF, 1>(st, taps, s, (int)n0, (int)h1, h2);
+            }
+        ok = true;
+    });
+    return ok;
+}
+
+// One inverse 3-D level (output box n): approximation from `llsrc` (dense h0,h1,h2) or from x when nullptr,
+// details from x (dense full strides 1, x1, x2); result to `out` (strides 1, o1, o2 with o1 == n0).
+template <typename T>
+bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
+                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
+    if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || o1 != n0 ||
+        (o2 % VEC) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 || !a_al16(x) || !a_al16(out) || !a_al16(T0) || !a_al16(T1) ||
+        (llsrc && !a_al16(llsrc)) || n1 > 32767 || (h0 % 4) != 0)
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FA(F, {
+        // columns first (transforms_filter.jl:269-273): merged lines into T0 (dense box)
+        for (int q3 = 0; q3 < 2 && *err == hipSuccess; ++q3)
+            for (int q2 = 0; q2 < 2 && *err == hipSuccess; ++q2) {
+                ShortArgs<T, FF> s;
+                const int64_t p2 = q2 * h1, p3 = q3 * h2;
+                if (q2 == 0 && q3 == 0 && llsrc) { s.a = llsrc; s.a2 = h0; s.a3 = h0 * h1; }
+                else { s.a = x + p2 * x1 + p3 * x2; s.a2 = x1; s.a3 = x2; }
+                s.b = x + h0 + p2 * x1 + p3 * x2; s.b2 = x1; s.b3 = x2;
+                s.o0 = T0 + p2 * n0 + p3 * n0 * n1; s.o02 = n0; s.o03 = n0 * n1; s.o1 = nullptr; s.o12 = s.o13 = 0;
+                *err = launch_short<T, FF, 0>(st, taps, s, (int)n0, (int)h1, h2);
+            }
+        // rows: axis 2 on n2 matrices
+        if (*err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
+        // planes: axis 3
+        if (*err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T1, n0 * n1, 0, out, o2, 0, n0 * n1, n2, 1, cu_count);
+        ok = true;
+    });
+    return ok;
+}
+
+template bool fast3d_fwd_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, float *, int64_t, int64_t,
+                                      float *, const int64_t[3], float *, float *, int, hipError_t *);
+template bool fast3d_fwd_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t,
+                                       double *, const int64_t[3], double *, double *, int, hipError_t *);
+template bool fast3d_inv_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *,
+                                      int64_t, int64_t, const int64_t[3], float *, float *, int, hipError_t *);
+template bool fast3d_inv_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *,
+                                       int64_t, int64_t, const int64_t[3], double *, double *, int, hipError_t *);
+
+}  // namespace wl

@@ -41,4 +41,12 @@ template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
+// One 3-D filter-bank level assembled from single-axis streaming passes (wl_axis.hip); false = not eligible.
+template <typename T>
+bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
+                      T *ll, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
+template <typename T>
+bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
+                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
+
 }  // namespace wl

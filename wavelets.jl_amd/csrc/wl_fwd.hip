@@ -1398,6 +1398,14 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                           done = true);
             if (done && !dominant) dominant = "k_fwd1d_stream";
         }
+        // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
+        if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {
+            hipError_t e3 = hipSuccess;
+            done = fast3d_fwd_level<T>(st, taps, cur, cur_st.s[1], cur_st.s[2], y, b.full.s[1], b.full.s[2],
+                                       last ? (T *)nullptr : llbuf, n, w.T0, w.T1, cu_count, &e3);
+            WL_TRY(e3);
+            if (done && !dominant) dominant = "k_fwd_axis_stream";
+        }
         // ---- generic level (any rank / size / filter) ----
         if (!done) {
             const T *in = cur;

@@ -515,6 +515,13 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             done = true;
             dominant = "k_inv_dim2_stream";
         }
+        if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
+            hipError_t e3 = hipSuccess;
+            done = fast3d_inv_level<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, res_st.s[1], res_st.s[2], n,
+                                       w.T0, w.T1, cu_count, &e3);
+            WL_TRYI(e3);
+            if (done) dominant = "k_inv_axis_stream";
+        }
         if (!done) {
             const T *in = x;
             Strides3 in_st = b.full;

@@ -130,6 +130,27 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 assert np.abs(xr - x).max() < (1e-4 if dtype == np.float32 else 1e-11)
 
 
+@pytest.mark.parametrize("ppl", ["2", "4"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_inverse_2d_kernel(gpu, W, oracle, monkeypatch, dtype, ppl):
+    """k_inv2d_stream (dim-1 + dim-2 reconstruction of a 2-D level in one pass): bit for bit against the oracle;
+    partial strips / chunks, non-square blocks, both lane widths, approximation taken from x (L = 1) and from the
+    deeper reconstruction (L > 1)."""
+    monkeypatch.setenv("WL_INV2D_PPL", ppl)
+    for shape, Ls in (((512, 512), (1, 2, 9)), ((1024, 2048), (1, 3)), ((2048, 512), (2, 9)), ((528, 96), (1, 4)),
+                      ((4096, 16), (1,)), ((1000, 24), (1, 3)), ((128, 128), (1, 7)), ((256, 64), (1, 2)), ((136, 24), (1, 3)),
+                      ((264, 528), (1, 3))):
+        x = rng_array(shape, dtype, sum(shape))
+        for fname in ("db4", "haar", "db2", "db3", "sym4", "db5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = oracle.dwt_filter(x, wt.qmf, L)
+                xr = host(W, W.idwt(dev(W, y), wt, L))
+                if len(wt.qmf) <= 8:      # blocks of <= 4096 elements are reconstructed by the LDS tail kernel instead
+                    assert W.last_kernel() == ("k_inv2d_stream" if shape[0] * shape[1] > 4096 else "k_tail_inv"), (shape, L)
+                assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (shape, fname, L)
+
+
 def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
     """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
     forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic

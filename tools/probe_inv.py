@@ -14,6 +14,8 @@ def timeit(fn, reps=10):
 x = torch.randn(8192, 8192, dtype=torch.float32, device="cuda").t()
 y = W.dwt(x, wt); z = W.similar(x)
 t2 = timeit(lambda: W.idwt_(z, y, wt, 13))
+t21 = timeit(lambda: W.idwt_(z, y, wt, 1))
+print("L=1: %.1f us" % t21, W.last_kernel())
 v = torch.randn(1 << 24, dtype=torch.float32, device="cuda"); yv = W.dwt(v, wt); zv = W.similar(v)
 t1 = timeit(lambda: W.idwt_(zv, yv, wt))
-print("INVTAIL_MAX", os.environ.get("WL_INVTAIL_MAX"), "idwt2d %.1f us, idwt1d %.1f us" % (t2, t1))
+print("PPL", os.environ.get("WL_INV2D_PPL"), "TP", os.environ.get("WL_INV2D_TP"), "NO", os.environ.get("WL_NO_INV2D"), "idwt2d %.1f us, idwt1d %.1f us" % (t2, t1))

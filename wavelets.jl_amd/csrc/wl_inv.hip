@@ -266,6 +266,43 @@ __device__ __forceinline__ T tail_inv_one(const T *sp, int ss, const T *dp, int 
     return S + D;
 }
 
+// the output pair (x[2p], x[2p+1]) for an even compile-time filter length, nx >= (FC-2)/2 (one wrap at most)
+template <typename T, int FC>
+__device__ __forceinline__ void tail_inv_pair(const T *sp, int ss, const T *dp, int sd, int p, int nx, const Taps<T> &tp, T &xe, T &xo)
+{
+    constexpr int SH = (FC - 2) / 2;
+    T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+    for (int q = 0; q <= SH; ++q) {
+        int is = p - SH + q;
+        if (is < 0) is += nx;
+        int id = p + q;
+        if (id >= nx) id -= nx;
+        sw[q] = sp[is * ss];
+        dw[q] = dp[id * sd];
+    }
+    T Se = tp.h[FC - 2] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[FC - 2 - 2 * q] * sw[q];
+    T De = tp.g[1] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    xe = Se + De;
+    T So = tp.h[FC - 1] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) So = So + tp.h[FC - 1 - 2 * q] * sw[q];
+    T Do = tp.g[0] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    xo = So + Do;
+}
+// e -> (e / d, e % d) without the emulated division when d is a power of two
+__device__ __forceinline__ void split_idx(int e, int d, int &q, int &r)
+{
+    if ((d & (d - 1)) == 0) { const int lg = 31 - __clz(d); q = e >> lg; r = e & (d - 1); }
+    else { q = e / d; r = e - q * d; }
+}
+
 template <typename T, int FC>
 __global__ void __launch_bounds__(1024) k_tail_inv(TailInvArgs<T> a, Taps<T> tp)
 {
@@ -276,55 +313,98 @@ __global__ void __launch_bounds__(1024) k_tail_inv(TailInvArgs<T> a, Taps<T> tp)
     const T *x = a.x + (int64_t)blockIdx.x * a.x_item;
     T *out = a.out + (int64_t)blockIdx.x * a.out_item;
     const int ld = a.ld;
+    // The coefficients of every level done here lie inside the n0 (x n1) corner of x: stage that corner once
+    // (one global-memory latency for the whole tail), then run the levels out of LDS.
     if (a.nt == 1) {
-        int n = a.n0 >> (a.nlev - 1);                       // output length of the deepest level
-        for (int k = tid; k < (n >> 1); k += nthr) P[k] = x[k];
+        for (int k = tid; k < a.n0; k += nthr) P[k] = x[k];
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int n = a.n0 >> (a.nlev - 1);                       // output length of the deepest level
+        // details always at P[nx..n); the running approximation starts at P[0..nx) and then ping-pongs between
+        // Q and Q + n0/2 (never written where another thread may still be reading)
+        const T *sp = P;
+        T *q0 = Q, *q1 = Q + (a.n0 >> 1);
         for (int lev = 0; lev < a.nlev; ++lev) {
             const int nx = n >> 1;
             const bool last = (lev == a.nlev - 1);
-            for (int k = tid; k < nx; k += nthr) Q[(a.n0 >> 1) + k] = x[nx + k];   // details of this level
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            for (int o = tid; o < n; o += nthr) {
-                T v = tail_inv_one<T, FC>(P, 1, Q + (a.n0 >> 1), 1, o, nx, tp);
-                if (last) out[o] = v;
-                else Q[o] = v;                                                      // Q[0..n), n <= n0/2 here
+            bool paired = false;
+            if constexpr (FC > 0) {
+                if (nx >= (FC - 2) / 2) {
+                    paired = true;
+                    for (int p = tid; p < nx; p += nthr) {
+                        T xe, xo;
+                        tail_inv_pair<T, FC>(sp, 1, P + nx, 1, p, nx, tp, xe, xo);
+                        if (last) { out[2 * p] = xe; out[2 * p + 1] = xo; }
+                        else { q0[2 * p] = xe; q0[2 * p + 1] = xo; }
+                    }
+                }
+            }
+            if (!paired) {
+                for (int o = tid; o < n; o += nthr) {
+                    T v = tail_inv_one<T, FC>(sp, 1, P + nx, 1, o, nx, tp);
+                    if (last) out[o] = v;
+                    else q0[o] = v;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!last) { for (int o = tid; o < n; o += nthr) P[o] = Q[o]; }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            sp = q0;
+            T *t = q0; q0 = q1; q1 = t;
             n <<= 1;
         }
     } else {
-        int m0 = a.n0 >> (a.nlev - 1), m1 = a.n1 >> (a.nlev - 1);
-        // deepest approximation: top-left (m0/2 x m1/2) of x
-        for (int e = tid; e < (m0 >> 1) * (m1 >> 1); e += nthr) {
-            const int j = e / (m0 >> 1), i = e - j * (m0 >> 1);
+        for (int e = tid; e < a.n0 * a.n1; e += nthr) {
+            int j, i;
+            split_idx(e, a.n0, j, i);
             P[i + j * ld] = x[i + (int64_t)j * a.ldx];
         }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int m0 = a.n0 >> (a.nlev - 1), m1 = a.n1 >> (a.nlev - 1);
         for (int lev = 0; lev < a.nlev; ++lev) {
             const int h0 = m0 >> 1, h1 = m1 >> 1;
             const bool last = (lev == a.nlev - 1);
-            // stage the three detail quadrants of this level around the running approximation
-            for (int e = tid; e < m0 * m1; e += nthr) {
-                const int j = e / m0, i = e - j * m0;
-                if (i >= h0 || j >= h1) P[i + j * ld] = x[i + (int64_t)j * a.ldx];
+            bool paired = false;
+            if constexpr (FC > 0) {
+                if (h0 >= (FC - 2) / 2 && h1 >= (FC - 2) / 2) {
+                    paired = true;
+                    // dim-1 pass (columns): Q[:, j] from P[0..h0, j] (s) and P[h0..m0, j] (d), one output pair per item
+                    for (int e = tid; e < h0 * m1; e += nthr) {
+                        int j, p;
+                        split_idx(e, h0, j, p);
+                        T xe, xo;
+                        tail_inv_pair<T, FC>(P + j * ld, 1, P + j * ld + h0, 1, p, h0, tp, xe, xo);
+                        Q[2 * p + j * ld] = xe;
+                        Q[2 * p + 1 + j * ld] = xo;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    // dim-2 pass (rows): columns 2p, 2p+1 from Q[i, 0..h1) (s) and Q[i, h1..m1) (d); overwrites the m0 x m1 corner of P
+                    for (int e = tid; e < m0 * h1; e += nthr) {
+                        int p, i;
+                        split_idx(e, m0, p, i);
+                        T xe, xo;
+                        tail_inv_pair<T, FC>(Q + i, ld, Q + i + h1 * ld, ld, p, h1, tp, xe, xo);
+                        if (last) { out[i + (int64_t)(2 * p) * a.ldo] = xe; out[i + (int64_t)(2 * p + 1) * a.ldo] = xo; }
+                        else { P[i + (2 * p) * ld] = xe; P[i + (2 * p + 1) * ld] = xo; }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // dim-1 pass (columns): Q[:, j] from P[0..h0, j] (s) and P[h0..m0, j] (d)
-            for (int e = tid; e < m0 * m1; e += nthr) {
-                const int j = e / m0, o = e - j * m0;
-                Q[o + j * ld] = tail_inv_one<T, FC>(P + j * ld, 1, P + j * ld + h0, 1, o, h0, tp);
+            if (!paired) {
+                // dim-1 pass (columns): Q[:, j] from P[0..h0, j] (s) and P[h0..m0, j] (d)
+                for (int e = tid; e < m0 * m1; e += nthr) {
+                    int j, o;
+                    split_idx(e, m0, j, o);
+                    Q[o + j * ld] = tail_inv_one<T, FC>(P + j * ld, 1, P + j * ld + h0, 1, o, h0, tp);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // dim-2 pass (rows): result[i, o] from Q[i, 0..h1) (s) and Q[i, h1..m1) (d); overwrites the m0 x m1 corner of P
+                for (int e = tid; e < m0 * m1; e += nthr) {
+                    int o, i;
+                    split_idx(e, m0, o, i);
+                    T v = tail_inv_one<T, FC>(Q + i, ld, Q + i + h1 * ld, ld, o, h1, tp);
+                    if (last) out[i + (int64_t)o * a.ldo] = v;
+                    else P[i + o * ld] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // dim-2 pass (rows): result[i, o] from Q[i, 0..h1) (s) and Q[i, h1..m1) (d)
-            for (int e = tid; e < m0 * m1; e += nthr) {
-                const int o = e / m0, i = e - o * m0;
-                T v = tail_inv_one<T, FC>(Q + i, ld, Q + i + h1 * ld, ld, o, h1, tp);
-                if (last) out[i + (int64_t)o * a.ldo] = v;
-                else P[i + o * ld] = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             m0 <<= 1;
             m1 <<= 1;
         }
@@ -344,17 +424,24 @@ static hipError_t launch_tail_inv(hipStream_t st, const Taps<T> &taps, const T *
     a.ld = (nt == 2) ? (n0 | 1) : n0;
     a.cap = (int)((((int64_t)a.ld * n1) + 15) & ~15);
     size_t shmem = 2 * (size_t)a.cap * sizeof(T);
-    if (nt == 1) {      // P: approximation (<= n0/2), Q: [output of the non-final levels (<= n0/2) | details (<= n0/2)]
-        a.cap = (int)((((int64_t)n0 >> 1) + 15) & ~15);
+    if (nt == 1) {      // P: the staged line (n0), Q: two ping-pong approximation buffers of n0/2
+        a.cap = (int)(((int64_t)n0 + 15) & ~15);
         shmem = ((size_t)a.cap + (size_t)n0 + 16) * sizeof(T);
     }
     const int64_t work = (int64_t)n0 * n1;
     const int threads = work >= 4096 ? 1024 : (work >= 512 ? 256 : 64);
 #define WL_TI(FC_)                                                                                             \
     do {                                                                                                       \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_inv<T, FC_>),                \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
-        if (e != hipSuccess) return e;                                                                         \
+        static unsigned char attr_set[64] = {0};                                                               \
+        int dev = 0;                                                                                           \
+        (void)hipGetDevice(&dev);                                                                              \
+        dev &= 63;                                                                                             \
+        if (!attr_set[dev]) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_inv<T, FC_>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+            if (e != hipSuccess) return e;                                                                     \
+            attr_set[dev] = 1;                                                                                 \
+        }                                                                                                      \
         hipLaunchKernelGGL((k_tail_inv<T, FC_>), dim3((unsigned)nitems), dim3(threads), shmem, st, a, taps);   \
     } while (0)
     switch (taps.F) {
@@ -415,6 +502,178 @@ static hipError_t launch_inv_dim2(hipStream_t st, const Taps<T> &taps, const T *
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One fused 2-D inverse level (columns = dim-1 pass, then rows = dim-2 pass, transforms_filter.jl:231-243)
+// in a single pass over HBM.  Lanes run along dim 1 (PPL coefficient pairs = 2*PPL output rows per lane,
+// halo lanes on both sides of the wave refetch their neighbours' coefficients); the wave marches along the
+// output column pairs p.  Per step it loads the raw coefficient column p of the left half and column
+// p + SH of the right half (prefetched 4 steps ahead in a static register ring), reconstructs both along
+// dim 1 (DPP neighbour exchange) into two 4-slot rings of dim-1-reconstructed columns, and combines
+// columns p-SH..p / p..p+SH of those rings into output columns 2p, 2p+1.
+template <typename T, int F>
+struct Inv2DArgs {
+    const T *x; int64_t ldx;        // coefficient array (details; approximation quadrant too when ll == nullptr)
+    const T *ll; int64_t ldl;       // deeper reconstruction, h0 x h1 (or nullptr)
+    T *dst; int64_t ldd;
+    int64_t n0, n1;                 // OUTPUT block extents
+    int TP;                         // output column pairs per chunk (multiple of 4)
+    int nstrips, nchunks;
+    TapsI<T, F> tp;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void ldn(const T *p, T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stn(T *p, const T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+template <typename T, int NB>
+__device__ __forceinline__ T i_prev_n(T v)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v = i_prev(v);
+    return v;
+}
+template <typename T, int NB>
+__device__ __forceinline__ T i_next_n(T v)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v = i_next(v);
+    return v;
+}
+
+// dim-1 reconstruction of one column: the lane's PPL approximation / detail coefficients -> 2*PPL samples
+template <typename T, int F, int PPL>
+__device__ __forceinline__ void inv_column(const T (&s)[PPL], const T (&d)[PPL], const TapsI<T, F> &tp, T (&out)[2 * PPL])
+{
+    constexpr int SH = (F - 2) / 2;
+    T sx[PPL + SH], dx[PPL + SH];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) { sx[SH + i] = s[i]; dx[i] = d[i]; }
+    if constexpr (SH >= 1) { constexpr int rel = 1, nb = (rel + PPL - 1) / PPL; sx[SH - 1] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
+    if constexpr (SH >= 2) { constexpr int rel = 2, nb = (rel + PPL - 1) / PPL; sx[SH - 2] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
+    if constexpr (SH >= 3) { constexpr int rel = 3, nb = (rel + PPL - 1) / PPL; sx[SH - 3] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
+    if constexpr (SH >= 1) { constexpr int rel = PPL + 0, nb = rel / PPL; dx[PPL + 0] = i_next_n<T, nb>(d[rel - nb * PPL]); }
+    if constexpr (SH >= 2) { constexpr int rel = PPL + 1, nb = rel / PPL; dx[PPL + 1] = i_next_n<T, nb>(d[rel - nb * PPL]); }
+    if constexpr (SH >= 3) { constexpr int rel = PPL + 2, nb = rel / PPL; dx[PPL + 2] = i_next_n<T, nb>(d[rel - nb * PPL]); }
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) inv_pair<T, F>(&sx[p], &dx[p], tp, out[2 * p], out[2 * p + 1]);
+}
+
+template <typename T, int F, int PPL>
+__global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL, R = 4;
+    static_assert(SH <= 3, "ring depth");
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+    const int64_t h0 = a.n0 >> 1, h1 = a.n1 >> 1;
+    const int64_t k0 = (int64_t)strip * VP + (int64_t)(lane - HL) * PPL;
+    int64_t kw = k0;
+    if (kw < 0) kw += h0;
+    if (kw >= h0) kw -= h0;
+    const bool store = lane >= HL && lane < 64 - HL && k0 < h0;
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
+    const int S = (int)(pend - p0);                  // multiple of 4
+    // left-half columns: approximation rows from ll (when given), detail rows from x; right half: both from x
+    const T *ls_base = (a.ll ? a.ll : a.x) + kw;
+    const int64_t ls_ld = a.ll ? a.ldl : a.ldx;
+    const T *ld_base = a.x + h0 + kw;
+    const T *rs_base = a.x + h1 * a.ldx + kw;
+    const T *rd_base = rs_base + h0;
+    T rLs[R][PPL], rLd[R][PPL], rRs[R][PPL], rRd[R][PPL];      // raw columns in flight
+    T iS[R][2 * PPL], iD[R][2 * PPL];                           // dim-1-reconstructed columns
+    auto load_raw = [&](const int64_t t, const int slot) __attribute__((always_inline)) {
+        int64_t js = p0 + t;
+        if (js < 0) js += h1;
+        int64_t jd = p0 + t + SH;
+        if (jd >= h1) jd -= h1;
+        ldn<T, PPL>(ls_base + js * ls_ld, rLs[slot]);
+        ldn<T, PPL>(ld_base + js * a.ldx, rLd[slot]);
+        ldn<T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
+        ldn<T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
+    };
+    // prologue: steps -SH .. -1 fill the reconstructed rings; their raw columns pass through slots (c - SH) mod 4
+#pragma unroll
+    for (int c = 0; c < SH; ++c) load_raw(c - SH, (c - SH + R) % R);
+#pragma unroll
+    for (int c = 0; c < SH; ++c) {
+        constexpr int dummy = 0; (void)dummy;
+        inv_column<T, F, PPL>(rLs[(c - SH + R) % R], rLd[(c - SH + R) % R], a.tp, iS[(c - SH + R) % R]);
+        inv_column<T, F, PPL>(rRs[(c - SH + R) % R], rRd[(c - SH + R) % R], a.tp, iD[(c - SH + R) % R]);
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) load_raw(c, c);
+    T *out = a.dst + 2 * k0;
+    auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+        inv_column<T, F, PPL>(rLs[u], rLd[u], a.tp, iS[u]);
+        inv_column<T, F, PPL>(rRs[u], rRd[u], a.tp, iD[u]);
+        if (prefetch) load_raw(t + R, u);
+        T xe[2 * PPL], xo[2 * PPL];
+#pragma unroll
+        for (int q = 0; q < 2 * PPL; ++q) {
+            T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
+            inv_pair<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+        }
+        if (store) {
+            const int64_t p = p0 + t;
+            stn<T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
+            stn<T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
+        }
+    };
+    int t0 = 0;
+    for (; t0 < S - R; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u, true);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) step(t0 + u, u, false);
+}
+
+template <typename T, int F, int PPL>
+static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                               T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL;
+    Inv2DArgs<T, F> a;
+    a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
+    const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
+    a.nstrips = (int)((h0 + VP - 1) / VP);
+    int TP = i_env("WL_INV2D_TP", 64);
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 16) TP >>= 1;
+    a.TP = TP;
+    a.nchunks = (int)((h1 + TP - 1) / TP);
+    a.tp = shrink_i<T, F>(taps);
+    hipLaunchKernelGGL((k_inv2d_stream<T, F, PPL>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 #define WL_DISPATCH_FI(F_, ...)                              \
     switch (F_) {                                            \
     case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
@@ -422,6 +681,15 @@ static hipError_t launch_inv_dim2(hipStream_t st, const Taps<T> &taps, const T *
     case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
     case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
     case 10: { constexpr int FF = 10; __VA_ARGS__; } break;  \
+    default: break;                                          \
+    }
+
+#define WL_DISPATCH_FI8(F_, ...)                             \
+    switch (F_) {                                            \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break;    \
+    case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
     default: break;                                          \
     }
 
@@ -457,7 +725,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             const int64_t blk = two_d ? nq[0] * nq[1] : nq[0];
             const bool fits = two_d ? (((nq[0] | 1) * nq[1]) <= inv_tail_cap<T>() + 256 && nq[1] <= 256)
                                     : (2 * nq[0] <= 2 * (int64_t)inv_tail_cap<T>());
-            if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 1024) && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
+            if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 4096) && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
         }
         if (l_lo <= L) {
             int64_t nq[3];
@@ -492,6 +760,31 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                                                            n[0], nlines, cu_count)));
                            done = true);
             if (done) dominant = "k_inv1d_stream";
+        }
+        // ---- fused 2-D level: one pass over HBM ----
+        if (!done && fastF && F <= 8 && two_d && i_env("WL_NO_INV2D", 0) == 0 && n[0] >= 128 && (n[0] % 8) == 0 && n[1] >= 16 &&
+            (n[1] % 8) == 0 && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
+            (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
+            // pairs per lane: 2 (8-byte loads / 16-byte stores for f32) from 256 rows, 1 below; 4 is a tuning option for f32
+            int ppl = i_env("WL_INV2D_PPL", 2);
+            if (n[0] < 256) ppl = 1;
+            else if (n[0] < 512 || sizeof(T) != 4 || ppl != 4) ppl = 2;
+            if (ppl == 4) {
+                if constexpr (sizeof(T) == 4) {
+                    WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 4>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                                                                       n[0], n[1], cu_count)));
+                                    done = true);
+                }
+            } else if (ppl == 2) {
+                WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 2>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                                                                   n[0], n[1], cu_count)));
+                                done = true);
+            } else {
+                WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 1>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                                                                   n[0], n[1], cu_count)));
+                                done = true);
+            }
+            if (done) dominant = "k_inv2d_stream";
         }
         if (!done && fastF && two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 16) == 0 &&
             b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) && i_al16(y)) {

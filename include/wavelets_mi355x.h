@@ -159,6 +159,54 @@ WL_API int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
                    double norm1, double norm2,
                    const uint8_t *tree, int64_t ntree, int fw, void *stream);
 
+/* ---- maximal-overlap DWT, 1-D -------------------------- */
+/* floor(log2(n)) -- replaces maxmodwttransformlevels, src/Util/non_dyadic.jl:24-25.        */
+WL_API int wl_maxmodwttransformlevels(int64_t n);
+/* W = modwt(x, filter, L): `out` is the n x (L+1) matrix (column-major, leading dimension
+ * ldo >= n): column j-1 = level-j detail coefficients, column L = level-L scaling
+ * coefficients.  Taps are used in Float64 (divided by sqrt 2) and every partial sum is
+ * rounded to the element type, exactly as the reference's `w1[t] += h[n] * v[k]` does.
+ * Errors: L > floor(log2 n) -> WL_EINVAL_SIZE ("Too many transform levels"), L < 1 ->
+ * WL_EINVAL_L.  replaces modwt + modwt_step, src/Transforms/transforms_maximal_overlap.jl:10-63. */
+WL_API int wl_modwt(wl_ctx *ctx, int dtype, void *out, int64_t ldo, const void *x, int64_t n,
+             const double *qmf, int flen, int L, void *stream);
+/* x = imodwt(xw, filter): xw is n x ncols (leading dimension ldw), x must not alias it.
+ * replaces imodwt + imodwt_step, transforms_maximal_overlap.jl:72-107.                     */
+WL_API int wl_imodwt(wl_ctx *ctx, int dtype, void *x, const void *xw, int64_t ldw, int64_t n, int ncols,
+              const double *qmf, int flen, void *stream);
+
+/* ---- thresholding and noise estimate -------------------- */
+/* THType of src/Threshold/threshold_main.jl:8-15 (BiggestTH has its own entry point).      */
+enum wl_thtype { WL_TH_HARD = 0, WL_TH_SOFT = 1, WL_TH_SEMISOFT = 2, WL_TH_STEIN = 3, WL_TH_POS = 4, WL_TH_NEG = 5 };
+/* threshold!(x, TH, t) in place on n elements.  t_is_f64 selects the arithmetic type Julia's
+ * promotion gives `x[i] op t`: 0 = the element type (t is an Integer or has the element
+ * type), 1 = Float64 (t::Float64, e.g. sigma*dnt.t in denoise), result rounded to the
+ * element type on store.  t is ignored for WL_TH_POS / WL_TH_NEG; t < 0 -> WL_EINVAL_ARG
+ * (the reference's @assert).  replaces threshold!, threshold_main.jl:37-122.               */
+WL_API int wl_threshold(wl_ctx *ctx, int dtype, void *x, int64_t n, int th, double t, int t_is_f64, void *stream);
+/* threshold!(x, BiggestTH(), m): keep the m entries of largest magnitude, zero the rest
+ * (exact order-statistic selection on device; ties at the cut are cleared in index order --
+ * the reference's QuickSort leaves that order unspecified).  Synchronises `stream` once.
+ * replaces threshold_main.jl:22-34.                                                        */
+WL_API int wl_threshold_biggest(wl_ctx *ctx, int dtype, void *x, int64_t n, int64_t m, void *stream);
+/* *result = median(v) (Statistics.median!: middle order statistic, or a/2 + b/2 of the two
+ * middle ones; NaN if any NaN), computed in the element type and widened to double.  `v` is
+ * not modified.  Synchronises `stream` (the result is a host scalar, as in the reference).  */
+WL_API int wl_median(wl_ctx *ctx, int dtype, const void *v, int64_t n, double *result, void *stream);
+/* *result = mad!(y): m = median!(y); y[i] = abs(y[i] - m); median!(y).  y is overwritten by
+ * the absolute deviations.  replaces mad!, src/Threshold/denoising.jl:103-110 (noisest :92-101
+ * = dwt level 1 + this on the level-1 detail range, divided by 0.6745 on the host).        */
+WL_API int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *stream);
+/* b[i] = a[i - shift] (periodic, every dimension; dims/shift have ndims entries, b != a).
+ * replaces Util.circshift! (src/Util/util_main.jl:105-130) and Base.circshift as used by the
+ * translation-invariant branch of denoise (denoising.jl:44-64).                            */
+WL_API int wl_circshift(wl_ctx *ctx, int dtype, void *b, const void *a, int ndims, const int64_t *dims,
+                 const int64_t *shift, void *stream);
+/* y[i] += z[i] -- arrayadd!, denoising.jl:82-88.                                           */
+WL_API int wl_arrayadd(wl_ctx *ctx, int dtype, void *y, const void *z, int64_t n, void *stream);
+/* y[i] = T(y[i] * s) with s::Float64 -- rmul!(y, 1/pns), denoising.jl:66.                  */
+WL_API int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *stream);
+
 /* ---- introspection (tests / bench) ---------------------------------------------------- */
 /* Select the kernel family: 0 = auto (fast paths where they apply), 1 = generic kernels
  * only.  Both produce bit-identical results; the switch exists so tests can prove it.   */

@@ -20,7 +20,7 @@ _lib = None
 
 ERR = {-1: "size must have a sufficient power of 2 factor", -2: "L must be positive", -3: "in array is out array",
        -4: "bad dims", -5: "array must be square/cube", -6: "invalid tree", -7: "bad scheme", -8: "bad dtype",
-       -9: "bad filter"}
+       -9: "bad filter", -10: "bad threshold"}
 
 
 class OracleError(ValueError):
@@ -32,7 +32,7 @@ class OracleError(ValueError):
 def build(force: bool = False):
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("wl_oracle.c", "wl_oracle_impl.h")):
+            for f in ("wl_oracle.c", "wl_oracle_impl.h", "wl_oracle_ext.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
@@ -211,3 +211,130 @@ def split(a):
 def merge(a):
     lib().wlo_merge(_dt(a), _p(a), C.c_int64(len(a)))
     return a
+
+
+# ---- section 8(f) rows 3-4: modwt, threshold, noise estimate (wl_oracle_ext.c; parity unpinned) ----
+TH_KINDS = {"hard": 0, "soft": 1, "semisoft": 2, "stein": 3, "pos": 4, "neg": 5}
+
+
+def maxmodwttransformlevels(n) -> int:
+    n = int(n.shape[0]) if hasattr(n, "shape") else int(n)
+    return int(lib().wlo_maxmodwttransformlevels(C.c_int64(n)))
+
+
+def modwt(x: np.ndarray, qmf, L=None) -> np.ndarray:
+    """modwt(x, wt, L) -> logical (N, L+1) array (transforms_maximal_overlap.jl:47-63)"""
+    xf = np.ascontiguousarray(x)
+    N = len(xf)
+    L = maxmodwttransformlevels(N) if L is None else int(L)
+    q = np.ascontiguousarray(qmf, dtype=np.float64)
+    out = np.empty((max(L, 0) + 1, N), dtype=xf.dtype)          # column-major N x (L+1)
+    rc = lib().wlo_modwt(_dt(xf), _p(out), _p(xf), C.c_int64(N), q.ctypes.data_as(C.POINTER(C.c_double)), len(q), L)
+    if rc:
+        raise OracleError(rc)
+    return np.ascontiguousarray(out.T)
+
+
+def imodwt(xw: np.ndarray, qmf) -> np.ndarray:
+    N, ncols = xw.shape
+    xf = np.ascontiguousarray(xw.T)                              # column-major N x ncols
+    q = np.ascontiguousarray(qmf, dtype=np.float64)
+    out = np.empty(N, dtype=xw.dtype)
+    rc = lib().wlo_imodwt(_dt(xf), _p(out), _p(xf), C.c_int64(N), int(ncols), q.ctypes.data_as(C.POINTER(C.c_double)), len(q))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def threshold(x: np.ndarray, kind: str, t=None, m=None) -> np.ndarray:
+    """threshold(x, TH, t): t a Python int -> arithmetic in the element type, a float -> Julia Float64 promotion."""
+    y = _col(x) if x.ndim > 1 else np.ascontiguousarray(x).copy()
+    if kind == "biggest":
+        rc = lib().wlo_threshold_biggest(_dt(y), _p(y), C.c_int64(y.size), C.c_int64(int(m)))
+    else:
+        t_is_f64 = 0 if (t is None or isinstance(t, (int, np.integer)) or isinstance(t, np.floating) and t.dtype == y.dtype) else 1
+        rc = lib().wlo_threshold(_dt(y), _p(y), C.c_int64(y.size), TH_KINDS[kind], C.c_double(0.0 if t is None else float(t)), t_is_f64)
+    if rc:
+        raise OracleError(rc)
+    return np.ascontiguousarray(y)
+
+
+def median(v: np.ndarray) -> float:
+    w = np.ascontiguousarray(v).copy()
+    out = C.c_double()
+    rc = lib().wlo_median(_dt(w), _p(w), C.c_int64(w.size), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
+def mad(v: np.ndarray) -> float:
+    w = np.ascontiguousarray(v).copy()
+    out = C.c_double()
+    rc = lib().wlo_mad(_dt(w), _p(w), C.c_int64(w.size), C.byref(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value
+
+
+def circshift(a: np.ndarray, shift) -> np.ndarray:
+    af = _col(a)
+    bf = np.empty_like(af, order="F")
+    sh = [int(s) for s in (shift if hasattr(shift, "__len__") else [shift])]
+    rc = lib().wlo_circshift(_dt(af), _p(bf), _p(af), a.ndim, _dims(a), (C.c_int64 * 3)(*(sh + [0] * (3 - len(sh)))))
+    if rc:
+        raise OracleError(rc)
+    return np.ascontiguousarray(bf)
+
+
+def arrayadd(y: np.ndarray, z: np.ndarray) -> np.ndarray:
+    yy = np.ascontiguousarray(y).copy()
+    zz = np.ascontiguousarray(z)
+    rc = lib().wlo_arrayadd(_dt(yy), _p(yy), _p(zz), C.c_int64(yy.size))
+    if rc:
+        raise OracleError(rc)
+    return yy
+
+
+def rmul(y: np.ndarray, s: float) -> np.ndarray:
+    yy = np.ascontiguousarray(y).copy()
+    rc = lib().wlo_rmul(_dt(yy), _p(yy), C.c_int64(yy.size), C.c_double(float(s)))
+    if rc:
+        raise OracleError(rc)
+    return yy
+
+
+def noisest(x: np.ndarray, transform, L=1) -> float:
+    """noisest (denoising.jl:92-101): `transform(x, L)` is the oracle dwt for the wavelet (None: identity);
+    y[detailrange(y, L)] is LINEAR indexing with size(y, 1): for matrices it takes the lower half of the first column."""
+    y = x if transform is None else transform(x, L)
+    n1 = y.shape[0]
+    lo, hi = n1 >> L, n1 >> (L - 1)                      # 0-based [lo, hi)
+    dr = np.asfortranarray(y).reshape(-1, order="F")[lo:hi].copy()
+    return mad(dr) / 0.6745
+
+
+def denoise(x: np.ndarray, fwd, inv, L, th_kind, t_unit, TI=False, nspin=None, lifting=False, noise_transform="same"):
+    """denoise (denoising.jl:21-81) composed from the oracle pieces in the reference's order.
+    fwd(a, L) / inv(a, L): oracle dwt / idwt for the wavelet (None: wt === nothing); t_unit = dnt.t"""
+    sigma = noisest(x, (lambda a, l: fwd(a, l)) if fwd is not None else None)
+    t = sigma * t_unit
+    if TI:
+        nsp = tuple(nspin) if hasattr(nspin, "__len__") else (int(nspin),)
+        pns = int(np.prod(nsp))
+        y = np.zeros_like(x)
+        for i in range(pns):
+            rem, shift = i, []
+            for d in nsp:                                # CartesianIndices: first dimension fastest
+                shift.append(rem % d)
+                rem //= d
+            shift = shift + [0] * (x.ndim - len(shift))
+            z = circshift(x, shift)
+            xt = threshold(fwd(z, L), th_kind, t)
+            z = inv(xt, L)
+            z = circshift(z, [-s for s in shift])
+            y = arrayadd(y, z).reshape(x.shape)
+        return rmul(y, 1 / pns).reshape(x.shape)
+    if fwd is None:
+        return threshold(x, th_kind, t)
+    return inv(threshold(fwd(x, L), th_kind, t), L)

@@ -1,0 +1,144 @@
+"""GPU parity for SURVEY.md section 8(f) rows 3-4: modwt/imodwt, threshold!, median/mad, circshift, and the whole
+denoise pipeline, through the C ABI, BIT-EXACT against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import rng_array
+from test_oracle_ext import doppler
+
+pytestmark = pytest.mark.gpu
+
+
+def host(W, t):
+    import torch
+    torch.cuda.synchronize()
+    return W.to_host(t)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_modwt_bitexact(gpu, W, oracle, dtype):
+    for n, Ls in ((128, (None, 1, 4)), (129, (None, 3)), (1000, (None, 9)), (1 << 16, (None, 5)), (1, ()), (2, (1,)), (3, (1,))):
+        x = np.cumsum(rng_array((n,), np.float64, n)).astype(dtype)
+        for fname in ("db4", "haar", "db2", "sym5", "batt2", "coif6"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                we = oracle.modwt(x, wt.qmf, L)
+                wg = W.modwt(W.to_device(x), wt, L)
+                assert tuple(wg.shape) == we.shape and W.is_julia_layout(wg)
+                assert np.array_equal(host(W, wg), we), (n, fname, L)
+                xr = host(W, W.imodwt(W.to_device(we), wt))
+                assert np.array_equal(xr, oracle.imodwt(we, wt.qmf)), (n, fname, L, "inv")
+                if fname != "batt2":          # the Battle tables are not orthogonal: imodwt is only the adjoint there
+                    assert np.abs(xr - x).max() <= (1e-4 if dtype == np.float32 else 1e-10) * max(1.0, np.abs(x).max())
+    wt = W.wavelet(W.WT.db4)
+    xd = W.to_device(rng_array((100,), dtype, 0))
+    assert W.maxmodwttransformlevels(xd) == 6
+    with pytest.raises(W.ArgumentError, match="Too many transform levels"):
+        W.modwt(xd, wt, 7)
+    with pytest.raises(W.ArgumentError, match="L must be >= 1"):
+        W.modwt(xd, wt, 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_threshold_bitexact(gpu, W, oracle, dtype):
+    kinds = {"hard": W.HardTH(), "soft": W.SoftTH(), "semisoft": W.SemiSoftTH(), "stein": W.SteinTH()}
+    for n in (1, 5, 200, 4099, 1 << 18):
+        x = (rng_array((n,), np.float64, n) * 2).astype(dtype)
+        x[: min(5, n)] = np.array([0.0, 2.0, -2.0, 4.0, -4.0], dtype=dtype)[: min(5, n)]
+        for t in (2, 0, 1.25, 0.0, np.float32(0.7)):
+            for kind, TH in kinds.items():
+                got = host(W, W.threshold(W.to_device(x), TH, t))
+                assert np.array_equal(got, oracle.threshold(x, kind, t), equal_nan=True), (n, kind, t)
+        assert np.array_equal(host(W, W.threshold(W.to_device(x), W.PosTH())), oracle.threshold(x, "pos"))
+        assert np.array_equal(host(W, W.threshold(W.to_device(x), W.NegTH())), oracle.threshold(x, "neg"))
+        for m in sorted({0, 1, n // 3, n - 1, n, n + 5}):
+            if m < 0:
+                continue
+            got = host(W, W.threshold(W.to_device(x), W.BiggestTH(), m))
+            assert np.array_equal(got, oracle.threshold(x, "biggest", m=m)), (n, m)
+    # ties at the cut (equal magnitudes, both signs) and many zeros
+    x = np.array([3, -1, 1, 0, 0, -1, 2, 1, -3, 0, 1, -1], dtype=dtype)
+    for m in range(0, len(x) + 1):
+        got = host(W, W.threshold(W.to_device(x), W.BiggestTH(), m))
+        assert np.array_equal(got, oracle.threshold(x, "biggest", m=m)), m
+    # in place on a Julia-layout matrix; the non-! form leaves its input alone
+    a = rng_array((64, 32), dtype, 4)
+    ad = W.to_device(a)
+    out = W.threshold(ad, W.SoftTH(), 0.5)
+    assert np.array_equal(host(W, ad), a) and np.array_equal(host(W, out), oracle.threshold(a, "soft", 0.5))
+    assert W.threshold_(ad, W.HardTH(), 1) is ad and np.array_equal(host(W, ad), oracle.threshold(a, "hard", 1))
+    with pytest.raises(AssertionError):
+        W.threshold_(ad, W.HardTH(), -1.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_median_mad_bitexact(gpu, W, oracle, dtype):
+    for n in (1, 2, 3, 10, 11, 1000, 4097, (1 << 20) + 3, 1 << 21):
+        v = rng_array((n,), dtype, n)
+        assert W.median(W.to_device(v)) == oracle.median(v), n
+        vd = W.to_device(v)
+        assert W.mad_(vd) == oracle.mad(v), n
+        assert np.array_equal(host(W, vd), np.abs(v - dtype(oracle.median(v))))       # mad! leaves |y - m| behind
+    for v in (np.array([1, 1, 1, 1]), np.array([-2.0, -2.0, 5.0]), np.array([0.0, -0.0, 0.0, 1.0]), np.array([1e30, -1e30, 3, 4]),
+              np.repeat(np.array([2.0, -7.0, 2.0]), 1000), np.array([-1.5, -0.25, -3.0, -0.5])):
+        v = v.astype(dtype)
+        assert W.median(W.to_device(v)) == oracle.median(v)
+        assert W.mad_(W.to_device(v)) == oracle.mad(v)
+    v = rng_array((100,), dtype, 1)
+    v[17] = np.nan
+    assert np.isnan(W.median(W.to_device(v)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_circshift_bitexact(gpu, W, oracle, dtype):
+    for shape, sh in (((10,), [3]), ((10,), [-4]), ((6, 5), [2, -1]), ((4, 3, 5), [1, 2, -2]), ((7,), [0]), ((7,), [15]),
+                      ((1024, 512), [7, 500]), ((64, 64, 64), [1, 0, 63])):
+        a = rng_array(shape, dtype, 1)
+        got = host(W, W.circshift(W.to_device(a), sh))
+        assert np.array_equal(got, oracle.circshift(a, sh)) and np.array_equal(got, np.roll(a, sh, axis=tuple(range(len(sh)))))
+
+
+def _oracle_denoise(oracle, W, x, wt, L, dnt, TI, nspin):
+    kind = type(dnt.th).__name__[:-2].lower()
+    if wt is None:
+        return oracle.denoise(x, None, None, 0, kind, dnt.t)
+    if isinstance(wt, W.GLS):
+        fwd = lambda a, l: oracle.dwt_lifting(a, wt, l)
+        inv = lambda a, l: oracle.dwt_lifting(a, wt, l, fw=False)
+    else:
+        fwd = lambda a, l: oracle.dwt_filter(a, wt.qmf, l)
+        inv = lambda a, l: oracle.dwt_filter(a, wt.qmf, l, fw=False)
+    return oracle.denoise(x, fwd, inv, L, kind, dnt.t, TI=TI, nspin=nspin)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
+    """the calls of test/threshold.jl:12-21, checked value for value"""
+    n = 2 ** 8
+    x0 = doppler(n)
+    x = (x0 + 0.05 * np.random.default_rng(0).standard_normal(n)).astype(dtype)
+    xd = W.to_device(x)
+    vs = W.VisuShrink(n)
+    wt = W.DEFAULT_WAVELET
+    assert W.noisest(xd) == oracle.noisest(x, lambda a, l: oracle.dwt_filter(a, wt.qmf, l))
+    cases = [dict(TI=True), dict(TI=True, nspin=8), dict(TI=False), dict(wt=None), dict(TI=True, nspin=3),
+             dict(wt=W.wavelet(W.WT.cdf97, W.WT.Lifting)), dict(wt=W.wavelet(W.WT.cdf97, W.WT.Lifting), TI=True, nspin=4),
+             dict(dnt=W.VisuShrink(W.SoftTH(), 2.5), L=3), dict(wt=W.wavelet(W.WT.db4), dnt=W.VisuShrink(W.SteinTH(), 3.0))]
+    for kw in cases:
+        y = host(W, W.denoise(xd, **kw))
+        w = kw.get("wt", wt)
+        L = kw.get("L", min(W.maxtransformlevels(n), 6))
+        e = _oracle_denoise(oracle, W, x, w, L, kw.get("dnt", vs), kw.get("TI", False), kw.get("nspin", (8,)))
+        assert y.dtype == dtype and np.array_equal(y, e), kw
+        if "dnt" not in kw and w is not None:          # (thresholding the raw samples is not a denoiser)
+            assert np.linalg.norm(y - x0) < np.linalg.norm(x - x0)
+    assert np.array_equal(host(W, xd), x)                        # denoise never modifies its input
+    # 2-D, translation invariant, 8 x 8 spins (test/threshold.jl:20)
+    a = rng_array((32, 32), dtype, 7)
+    y = host(W, W.denoise(W.to_device(a), TI=True))
+    e = _oracle_denoise(oracle, W, a, wt, min(W.maxtransformlevels(a), 6), W.VisuShrink(32), True, (8, 8))
+    assert np.array_equal(y, e)
+    y = host(W, W.denoise(W.to_device(a), TI=True, nspin=(2, 3)))
+    assert np.array_equal(y, _oracle_denoise(oracle, W, a, wt, 5, W.VisuShrink(32), True, (2, 3)))
+    with pytest.raises(W.ArgumentError, match="square/cube"):
+        W.denoise(W.to_device(rng_array((32, 16), dtype, 1)))

@@ -18,6 +18,9 @@ from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwt
                          to_device, to_host, similar, julia_layout, is_julia_layout,
                          reserve_workspace, set_kernel_path, last_kernel,
                          DimensionMismatch, ArgumentError, HIPError)
+from .modwt import modwt, imodwt, maxmodwttransformlevels
+from .threshold import (THType, HardTH, SoftTH, SemiSoftTH, SteinTH, BiggestTH, PosTH, NegTH, DEFAULT_TH, threshold, threshold_,
+                        DNFT, VisuShrink, denoise, noisest, mad_, median, nspin2circ, circshift, DEFAULT_WAVELET)
 from . import _lib
 
 __all__ = [
@@ -28,4 +31,7 @@ __all__ = [
     "to_device", "to_host", "similar", "julia_layout", "is_julia_layout",
     "reserve_workspace", "set_kernel_path", "last_kernel",
     "DimensionMismatch", "ArgumentError", "HIPError",
+    "modwt", "imodwt", "maxmodwttransformlevels",
+    "THType", "HardTH", "SoftTH", "SemiSoftTH", "SteinTH", "BiggestTH", "PosTH", "NegTH", "DEFAULT_TH", "threshold", "threshold_",
+    "DNFT", "VisuShrink", "denoise", "noisest", "mad_", "median", "nspin2circ", "circshift", "DEFAULT_WAVELET",
 ]

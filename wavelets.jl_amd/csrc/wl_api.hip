@@ -11,32 +11,9 @@
 
 using namespace wl;
 
-struct wl_ctx {
-    int device = 0;
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
-    int last_hip = 0;
-    int path = 0;                       // 0 auto, 1 generic only
-    const char *last_kernel = "none";
-    int cu_count = 256;
-};
+#include "wl_ctx.h"
 
-namespace {
-
-inline int hip_fail(wl_ctx *ctx, hipError_t e)
-{
-    if (ctx) ctx->last_hip = (int)e;
-    return WL_EHIP;
-}
-#define WL_HIP(ctx, expr)                                  \
-    do {                                                   \
-        hipError_t e__ = (expr);                           \
-        if (e__ != hipSuccess) return hip_fail((ctx), e__); \
-    } while (0)
-
-inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int64_t)1 << L)) == 0; }
-
-int ensure_ws(wl_ctx *ctx, size_t bytes)
+int wl_ensure_ws(wl_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return WL_OK;
     // grow-only; the old block may still be in use by kernels queued on the caller's
@@ -51,6 +28,12 @@ int ensure_ws(wl_ctx *ctx, size_t bytes)
     ctx->ws_bytes = want;
     return WL_OK;
 }
+
+namespace {
+
+inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int64_t)1 << L)) == 0; }
+
+inline int ensure_ws(wl_ctx *ctx, size_t bytes) { return wl_ensure_ws(ctx, bytes); }
 
 template <typename T>
 void make_taps(const double *qmf, int flen, Taps<T> &t)
@@ -307,7 +290,9 @@ int wl_ctx_create(int device, wl_ctx **out)
 int wl_ctx_destroy(wl_ctx *ctx)
 {
     if (!ctx) return WL_EINVAL_ARG;
-    if (ctx->ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->ws); }
+    if (ctx->ws || ctx->aux) (void)hipDeviceSynchronize();
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     delete ctx;
     return WL_OK;
 }

@@ -1,0 +1,590 @@
+// wl_ext.hip -- the callers around the hot path:
+//   modwt / imodwt                       transforms_maximal_overlap.jl:10-107
+//   threshold! (all THTypes)             threshold_main.jl:21-117
+//   median! / mad! (noise estimate)      denoising.jl:92-110 (+ Statistics.median!)
+//   circshift / arrayadd! / rmul!        util_main.jl:105-130, denoising.jl:82-88 (translation-invariant denoising)
+// All of it is HBM-bound element-wise or gather work; the arithmetic follows Julia's promotion rules
+// literally (Float32 data with Float64 taps / threshold: compute in Float64, round on every store) so the
+// results are bit-identical to the reference loops.
+#include "wl_ctx.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int EXT_THREADS = 256;
+inline unsigned ext_blocks(int64_t n, int per_thread, int cu_count)
+{
+    int64_t b = (n + (int64_t)EXT_THREADS * per_thread - 1) / ((int64_t)EXT_THREADS * per_thread);
+    const int64_t cap = (int64_t)cu_count * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---- MODWT -----------------------------------------------------------------------------------------
+struct ModwtTaps { int F; double h[WL_MAX_FLEN]; double g[WL_MAX_FLEN]; };   // h: detail, g: scaling (both / sqrt 2)
+
+// WT.makereverseqmfpair(wt) (fw, Float64: g = reverse(qmf), h = mirror(qmf)) then `/= sqrt(2)`, :50-52
+void make_modwt_taps(const double *qmf, int F, ModwtTaps &t)
+{
+    const double r2 = std::sqrt(2.0);
+    t.F = F;
+    for (int i = 0; i < WL_MAX_FLEN; ++i) { t.h[i] = 0.0; t.g[i] = 0.0; }
+    for (int i = 0; i < F; ++i) {
+        t.g[i] = qmf[F - 1 - i] / r2;
+        t.h[i] = ((i & 1) ? -qmf[i] : qmf[i]) / r2;
+    }
+}
+
+// modwt_step (:10-31): w1[t] = sum_n h[n] v[t - n*stride], v1[t] = sum_n g[n] v[...], accumulated in tap order,
+// every partial sum rounded to T (Julia: `w1[t] += h[n] * v[k]` with w1::Vector{T}, h::Vector{Float64}).
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_modwt_step(const T *__restrict__ v, T *__restrict__ v1, T *__restrict__ w1,
+                                                            int64_t N, int64_t stride, ModwtTaps tp)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += nthr) {
+        int64_t k = t;
+        double x = (double)v[k];
+        T w = (T)(tp.h[0] * x), s = (T)(tp.g[0] * x);
+        for (int n = 1; n < tp.F; ++n) {
+            k -= stride;
+            if (k < 0) { k %= N; if (k < 0) k += N; }
+            x = (double)v[k];
+            w = (T)((double)w + tp.h[n] * x);
+            s = (T)((double)s + tp.g[n] * x);
+        }
+        w1[t] = w;
+        v1[t] = s;
+    }
+}
+// imodwt_step (:72-93): v0[t] = sum_n (h[n] w[t + n*stride] + g[n] v[t + n*stride])
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step(const T *__restrict__ v, const T *__restrict__ w, T *__restrict__ v0,
+                                                             int64_t N, int64_t stride, ModwtTaps tp)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += nthr) {
+        int64_t k = t;
+        T acc = (T)(tp.h[0] * (double)w[k] + tp.g[0] * (double)v[k]);
+        for (int n = 1; n < tp.F; ++n) {
+            k += stride;
+            if (k >= N) k %= N;
+            acc = (T)((double)acc + (tp.h[n] * (double)w[k] + tp.g[n] * (double)v[k]));
+        }
+        v0[t] = acc;
+    }
+}
+
+template <typename T>
+int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int64_t N, const double *qmf, int flen, int L)
+{
+    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
+    if (rc != WL_OK) return rc;
+    ModwtTaps tp;
+    make_modwt_taps(qmf, flen, tp);
+    T *A = (T *)ctx->ws, *B = A + N;
+    const T *cur = x;
+    const unsigned nb = ext_blocks(N, 1, ctx->cu_count);
+    for (int j = 1; j <= L; ++j) {
+        T *vdst = (j == L) ? out + (int64_t)L * ldo : ((j & 1) ? A : B);
+        hipLaunchKernelGGL((k_modwt_step<T>), dim3(nb), dim3(EXT_THREADS), 0, st, cur, vdst, out + (int64_t)(j - 1) * ldo, N,
+                           (int64_t)1 << (j - 1), tp);
+        WL_HIP(ctx, hipGetLastError());
+        cur = vdst;
+    }
+    ctx->last_kernel = "k_modwt_step";
+    return WL_OK;
+}
+template <typename T>
+int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int64_t N, int ncols, const double *qmf, int flen)
+{
+    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
+    if (rc != WL_OK) return rc;
+    ModwtTaps tp;
+    make_modwt_taps(qmf, flen, tp);
+    T *A = (T *)ctx->ws, *B = A + N;
+    const T *cur = xw + (int64_t)(ncols - 1) * ldw;
+    if (ncols == 1) { WL_HIP(ctx, hipMemcpyAsync(x, cur, (size_t)N * sizeof(T), hipMemcpyDeviceToDevice, st)); return WL_OK; }
+    const unsigned nb = ext_blocks(N, 1, ctx->cu_count);
+    for (int j = ncols - 1; j >= 1; --j) {
+        if (j - 1 >= 62) return WL_EINVAL_L;
+        T *dst = (j == 1) ? x : ((j & 1) ? A : B);
+        hipLaunchKernelGGL((k_imodwt_step<T>), dim3(nb), dim3(EXT_THREADS), 0, st, cur, xw + (int64_t)(j - 1) * ldw, dst, N,
+                           (int64_t)1 << (j - 1), tp);
+        WL_HIP(ctx, hipGetLastError());
+        cur = dst;
+    }
+    ctx->last_kernel = "k_imodwt_step";
+    return WL_OK;
+}
+
+// ---- threshold! ------------------------------------------------------------------------------------
+// T: element type, C: the type Julia's promotion computes `x[i] op t` in
+template <typename T, typename C>
+__global__ void __launch_bounds__(EXT_THREADS) k_threshold(T *__restrict__ x, int64_t n, int th, C t)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
+        const T xr = x[i];
+        const C xi = (C)xr;
+        const C ax = xi < 0 ? -xi : xi;
+        const C sg = (C)((xi > 0) - (xi < 0));
+        T out = xr;
+        switch (th) {
+        case WL_TH_HARD: if (ax <= t) out = (T)0; break;
+        case WL_TH_SOFT: { const C sh = ax - t; out = (sh < 0) ? (T)0 : (T)(sg * sh); } break;
+        case WL_TH_SEMISOFT:
+            if (xi <= 2 * t) {
+                const C sh = ax - t;
+                if (sh < 0) out = (T)0;
+                else if (sh - t < 0) out = (T)(sg * sh * 2);
+            }
+            break;
+        case WL_TH_STEIN: { const C sh = 1 - t * t / (xi * xi); out = (sh < 0) ? (T)0 : (T)(xi * sh); } break;
+        case WL_TH_POS: if (xi > 0) out = (T)0; break;
+        case WL_TH_NEG: if (xi < 0) out = (T)0; break;
+        }
+        x[i] = out;
+    }
+}
+
+// ---- order statistics: MSB-first radix select on monotone integer keys -------------------------------
+// Two ranks are resolved together (the two middle order statistics of an even-length median).
+struct SelState {
+    unsigned long long prefix[2];
+    unsigned long long k[2];            // remaining 0-based rank inside the current prefix class
+    unsigned int hist[2][256];
+    unsigned int nan_count;
+    unsigned int pad;
+    double result;                      // median / order statistic as Float64
+    double value[2];                    // the two selected values
+    unsigned long long less, equal;     // counts relative to value[0] (threshold_biggest)
+};
+
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+    typedef unsigned int U;
+    static constexpr int BYTES = 4;
+    __device__ static U key(float v, int absmode)
+    {
+        U b = __float_as_uint(v);
+        if (absmode) return b & 0x7fffffffu;
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
+    __device__ static float val(U k, int absmode)
+    {
+        if (absmode) return __uint_as_float(k);
+        return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+    }
+};
+template <> struct KeyOf<double> {
+    typedef unsigned long long U;
+    static constexpr int BYTES = 8;
+    __device__ static U key(double v, int absmode)
+    {
+        U b = (U)__double_as_longlong(v);
+        if (absmode) return b & 0x7fffffffffffffffull;
+        return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+    }
+    __device__ static double val(U k, int absmode)
+    {
+        if (absmode) return __longlong_as_double((long long)k);
+        return __longlong_as_double((long long)((k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k));
+    }
+};
+
+__global__ void k_sel_init(SelState *s, unsigned long long k0, unsigned long long k1)
+{
+    const int t = threadIdx.x;
+    if (t < 256) { s->hist[0][t] = 0; s->hist[1][t] = 0; }
+    if (t == 0) {
+        s->prefix[0] = s->prefix[1] = 0; s->k[0] = k0; s->k[1] = k1; s->nan_count = 0; s->result = 0.0;
+        s->value[0] = s->value[1] = 0.0; s->less = s->equal = 0;
+    }
+}
+// histogram of byte `pass` (0 = most significant) among keys whose higher bytes equal the rank's prefix
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_sel_hist(const T *__restrict__ v, int64_t n, int pass, int absmode, SelState *s)
+{
+    typedef typename KeyOf<T>::U U;
+    constexpr int NB = KeyOf<T>::BYTES;
+    __shared__ unsigned int lh[2][256];
+    lh[0][threadIdx.x] = 0;
+    lh[1][threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 8 * (NB - 1 - pass);
+    const U p0 = (U)s->prefix[0], p1 = (U)s->prefix[1];
+    const bool same = (p0 == p1);
+    unsigned int nans = 0;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
+        const T x = v[i];
+        if (pass == 0 && x != x) ++nans;
+        const U key = KeyOf<T>::key(x, absmode);
+        const U hi = (pass == 0) ? (U)0 : (key >> (shift + 8));
+        const unsigned b = (unsigned)((key >> shift) & 0xff);
+        if (pass == 0 || hi == (p0 >> (shift + 8))) atomicAdd(&lh[0][b], 1u);
+        if (!same && hi == (p1 >> (shift + 8))) atomicAdd(&lh[1][b], 1u);
+    }
+    __syncthreads();
+    if (lh[0][threadIdx.x]) atomicAdd(&s->hist[0][threadIdx.x], lh[0][threadIdx.x]);
+    if (!same && lh[1][threadIdx.x]) atomicAdd(&s->hist[1][threadIdx.x], lh[1][threadIdx.x]);
+    if (nans) atomicAdd(&s->nan_count, nans);
+}
+// pick the bucket holding each rank, extend the prefix, clear the histograms
+template <typename T>
+__global__ void k_sel_scan(int pass, SelState *s)
+{
+    constexpr int NB = KeyOf<T>::BYTES;
+    const int shift = 8 * (NB - 1 - pass);
+    if (threadIdx.x == 0) {
+        const bool same = (s->prefix[0] == s->prefix[1]);
+        for (int r = 0; r < 2; ++r) {
+            const unsigned int *h = s->hist[(same && r == 1) ? 0 : r];
+            unsigned long long k = s->k[r], cum = 0;
+            int b = 0;
+            for (; b < 255; ++b) {
+                if (k < cum + h[b]) break;
+                cum += h[b];
+            }
+            s->k[r] = k - cum;
+            s->prefix[r] |= ((unsigned long long)b) << shift;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) { s->hist[0][threadIdx.x] = 0; s->hist[1][threadIdx.x] = 0; }
+}
+// median!: odd n -> the middle order statistic, even n -> middle(a, b) = a/2 + b/2; NaN anywhere -> NaN
+template <typename T>
+__global__ void k_sel_finish(SelState *s, int absmode, int is_median, T *result_t)
+{
+    typedef typename KeyOf<T>::U U;
+    const T a = KeyOf<T>::val((U)s->prefix[0], absmode), b = KeyOf<T>::val((U)s->prefix[1], absmode);
+    s->value[0] = (double)a;
+    s->value[1] = (double)b;
+    T m = a;
+    if (is_median) {
+        if (s->prefix[0] != s->prefix[1]) m = a / 2 + b / 2;
+        if (s->nan_count) m = (T)NAN;
+    }
+    s->result = (double)m;
+    if (result_t) *result_t = m;
+}
+// mad!: y[i] = abs(y[i] - m)
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_absdev(T *__restrict__ y, int64_t n, const T *m)
+{
+    const T mm = *m;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
+        const T d = y[i] - mm;
+        y[i] = d < 0 ? -d : d;
+    }
+}
+// BiggestTH: counts of |x| below / equal to the cut, then the zeroing passes
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_count_cut(const T *__restrict__ x, int64_t n, SelState *s)
+{
+    const T a = (T)s->value[0];
+    unsigned long long less = 0, eq = 0;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
+        const T v = x[i] < 0 ? -x[i] : x[i];
+        less += (v < a);
+        eq += (v == a);
+    }
+    if (less) atomicAdd(&s->less, less);
+    if (eq) atomicAdd(&s->equal, eq);
+}
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_zero_below(T *__restrict__ x, int64_t n, const SelState *s, int inclusive)
+{
+    const T a = (T)s->value[0];
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
+        const T v = x[i] < 0 ? -x[i] : x[i];
+        if (v < a || (inclusive && v == a)) x[i] = (T)0;
+    }
+}
+// ties at the cut: zero the first `need` entries (index order) whose magnitude equals the cut; one wave, ordered
+template <typename T>
+__global__ void __launch_bounds__(64) k_zero_ties(T *__restrict__ x, int64_t n, const SelState *s, unsigned long long need)
+{
+    const T a = (T)s->value[0];
+    const int lane = threadIdx.x;
+    unsigned long long done = 0;
+    for (int64_t base = 0; base < n && done < need; base += 64) {
+        const int64_t i = base + lane;
+        const T v = (i < n) ? (x[i] < 0 ? -x[i] : x[i]) : (T)-1;
+        const bool tie = (i < n) && (v == a);
+        const unsigned long long mask = __ballot(tie);
+        const unsigned long long before = mask & ((1ull << lane) - 1ull);
+        if (tie && done + (unsigned long long)__popcll(before) < need) x[i] = (T)0;
+        done += (unsigned long long)__popcll(mask);
+    }
+}
+
+int ensure_aux(wl_ctx *ctx)
+{
+    if (ctx->aux) return WL_OK;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, 8192);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return WL_ENOMEM; }
+    ctx->aux = p;
+    return WL_OK;
+}
+
+// enqueue the selection of ranks k0 <= k1 (0-based) of v[0..n); leaves prefix[] resolved in the state
+template <typename T>
+int select_ranks(wl_ctx *ctx, hipStream_t st, const T *v, int64_t n, unsigned long long k0, unsigned long long k1, int absmode)
+{
+    SelState *s = (SelState *)ctx->aux;
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, st, s, k0, k1);
+    const unsigned nb = ext_blocks(n, 8, ctx->cu_count);
+    for (int pass = 0; pass < KeyOf<T>::BYTES; ++pass) {
+        hipLaunchKernelGGL((k_sel_hist<T>), dim3(nb), dim3(EXT_THREADS), 0, st, v, n, pass, absmode, s);
+        hipLaunchKernelGGL((k_sel_scan<T>), dim3(1), dim3(256), 0, st, pass, s);
+    }
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
+template <typename T>
+int median_impl(wl_ctx *ctx, hipStream_t st, const T *v, int64_t n, double *result_host, T *result_dev)
+{
+    int rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    SelState *s = (SelState *)ctx->aux;
+    const unsigned long long k1 = (unsigned long long)(n / 2), k0 = (n & 1) ? k1 : k1 - 1;
+    rc = select_ranks<T>(ctx, st, v, n, k0, k1, 0);
+    if (rc != WL_OK) return rc;
+    hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(1), 0, st, s, 0, 1, result_dev);
+    WL_HIP(ctx, hipGetLastError());
+    if (result_host) {
+        WL_HIP(ctx, hipMemcpyAsync(result_host, &s->result, sizeof(double), hipMemcpyDeviceToHost, st));
+        WL_HIP(ctx, hipStreamSynchronize(st));
+    }
+    return WL_OK;
+}
+
+template <typename T>
+int biggest_impl(wl_ctx *ctx, hipStream_t st, T *x, int64_t n, int64_t m)
+{
+    if (m > n) m = n;
+    const int64_t nz = n - m;                      // entries to clear
+    if (nz <= 0) return WL_OK;
+    int rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    SelState *s = (SelState *)ctx->aux;
+    rc = select_ranks<T>(ctx, st, x, n, (unsigned long long)(nz - 1), (unsigned long long)(nz - 1), 1);
+    if (rc != WL_OK) return rc;
+    hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(1), 0, st, s, 1, 0, (T *)nullptr);
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    hipLaunchKernelGGL((k_count_cut<T>), dim3(nb), dim3(EXT_THREADS), 0, st, x, n, s);
+    WL_HIP(ctx, hipGetLastError());
+    unsigned long long cnt[2] = {0, 0};
+    WL_HIP(ctx, hipMemcpyAsync(cnt, &s->less, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    WL_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned long long need = (unsigned long long)nz - cnt[0];       // ties at the cut that must go
+    if (need >= cnt[1]) {
+        hipLaunchKernelGGL((k_zero_below<T>), dim3(nb), dim3(EXT_THREADS), 0, st, x, n, s, 1);
+    } else {
+        hipLaunchKernelGGL((k_zero_ties<T>), dim3(1), dim3(64), 0, st, x, n, s, need);
+        hipLaunchKernelGGL((k_zero_below<T>), dim3(nb), dim3(EXT_THREADS), 0, st, x, n, s, 0);
+    }
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
+// ---- circshift / arrayadd! / rmul! -------------------------------------------------------------------
+struct Shift3 { int64_t d[3]; int64_t s[3]; };
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_circshift(T *__restrict__ b, const T *__restrict__ a, int64_t n, Shift3 p)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += nthr) {
+        const int64_t i0 = e % p.d[0], r = e / p.d[0], i1 = r % p.d[1], i2 = r / p.d[1];
+        int64_t j0 = i0 - p.s[0], j1 = i1 - p.s[1], j2 = i2 - p.s[2];
+        if (j0 < 0) j0 += p.d[0];
+        if (j1 < 0) j1 += p.d[1];
+        if (j2 < 0) j2 += p.d[2];
+        b[e] = a[j0 + p.d[0] * (j1 + p.d[1] * j2)];
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_arrayadd(T *__restrict__ y, const T *__restrict__ z, int64_t n)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) y[i] = y[i] + z[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_rmul(T *__restrict__ y, int64_t n, double s)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) y[i] = (T)((double)y[i] * s);
+}
+
+inline int ext_enter(wl_ctx *ctx, int dtype)
+{
+    if (!ctx) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    WL_HIP(ctx, hipSetDevice(ctx->device));
+    return WL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wl_maxmodwttransformlevels(int64_t n)
+{
+    int l = 0;
+    while (n > 1) { n >>= 1; ++l; }
+    return l;
+}
+
+int wl_modwt(wl_ctx *ctx, int dtype, void *out, int64_t ldo, const void *x, int64_t n, const double *qmf, int flen, int L,
+             void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!out || !x || !qmf) return WL_EINVAL_ARG;
+    if (flen < 1 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (n < 1 || ldo < n) return WL_EDIMS;
+    if (L > wl_maxmodwttransformlevels(n)) return WL_EINVAL_SIZE;      // "Too many transform levels (length(x) < 2^L)"
+    if (L < 1) return WL_EINVAL_L;                                       // "L must be >= 1"
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? modwt_impl<float>(ctx, st, (float *)out, ldo, (const float *)x, n, qmf, flen, L)
+                           : modwt_impl<double>(ctx, st, (double *)out, ldo, (const double *)x, n, qmf, flen, L);
+}
+
+int wl_imodwt(wl_ctx *ctx, int dtype, void *x, const void *xw, int64_t ldw, int64_t n, int ncols, const double *qmf, int flen,
+              void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!x || !xw || !qmf) return WL_EINVAL_ARG;
+    if (flen < 1 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (n < 1 || ncols < 1 || ldw < n) return WL_EDIMS;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? imodwt_impl<float>(ctx, st, (float *)x, (const float *)xw, ldw, n, ncols, qmf, flen)
+                           : imodwt_impl<double>(ctx, st, (double *)x, (const double *)xw, ldw, n, ncols, qmf, flen);
+}
+
+int wl_threshold(wl_ctx *ctx, int dtype, void *x, int64_t n, int th, double t, int t_is_f64, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!x && n > 0) return WL_EINVAL_ARG;
+    if (th < WL_TH_HARD || th > WL_TH_NEG) return WL_EINVAL_ARG;
+    if (th <= WL_TH_STEIN && !(t >= 0)) return WL_EINVAL_ARG;           // @assert t >= 0
+    if (n <= 0) return WL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    if (dtype == WL_F64) hipLaunchKernelGGL((k_threshold<double, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)x, n, th, t);
+    else if (t_is_f64) hipLaunchKernelGGL((k_threshold<float, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, t);
+    else hipLaunchKernelGGL((k_threshold<float, float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, (float)t);
+    WL_HIP(ctx, hipGetLastError());
+    ctx->last_kernel = "k_threshold";
+    return WL_OK;
+}
+
+int wl_threshold_biggest(wl_ctx *ctx, int dtype, void *x, int64_t n, int64_t m, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if ((!x && n > 0) || m < 0) return WL_EINVAL_ARG;
+    if (n <= 0) return WL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? biggest_impl<float>(ctx, st, (float *)x, n, m) : biggest_impl<double>(ctx, st, (double *)x, n, m);
+}
+
+int wl_median(wl_ctx *ctx, int dtype, const void *v, int64_t n, double *result, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!v || !result) return WL_EINVAL_ARG;
+    if (n < 1) return WL_EDIMS;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32 ? median_impl<float>(ctx, st, (const float *)v, n, result, (float *)nullptr)
+                           : median_impl<double>(ctx, st, (const double *)v, n, result, (double *)nullptr);
+}
+
+int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!y || !result) return WL_EINVAL_ARG;
+    if (n < 1) return WL_EDIMS;
+    rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    void *mdev = (char *)ctx->aux + 4096;          // the first median, in the element type
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    if (dtype == WL_F32) {
+        rc = median_impl<float>(ctx, st, (const float *)y, n, nullptr, (float *)mdev);
+        if (rc != WL_OK) return rc;
+        hipLaunchKernelGGL((k_absdev<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, (const float *)mdev);
+        return median_impl<float>(ctx, st, (const float *)y, n, result, (float *)nullptr);
+    }
+    rc = median_impl<double>(ctx, st, (const double *)y, n, nullptr, (double *)mdev);
+    if (rc != WL_OK) return rc;
+    hipLaunchKernelGGL((k_absdev<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, (const double *)mdev);
+    return median_impl<double>(ctx, st, (const double *)y, n, result, (double *)nullptr);
+}
+
+int wl_circshift(wl_ctx *ctx, int dtype, void *b, const void *a, int ndims, const int64_t *dims, const int64_t *shift, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!b || !a || !dims || !shift) return WL_EINVAL_ARG;
+    if (ndims < 1 || ndims > 3) return WL_EDIMS;
+    if (b == a) return WL_EALIAS;
+    Shift3 p = {{1, 1, 1}, {0, 0, 0}};
+    int64_t n = 1;
+    for (int k = 0; k < ndims; ++k) {
+        if (dims[k] < 1) return (dims[k] == 0) ? WL_OK : WL_EDIMS;
+        p.d[k] = dims[k];
+        p.s[k] = ((shift[k] % dims[k]) + dims[k]) % dims[k];
+        n *= dims[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    if (dtype == WL_F32) hipLaunchKernelGGL((k_circshift<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)b, (const float *)a, n, p);
+    else hipLaunchKernelGGL((k_circshift<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)b, (const double *)a, n, p);
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
+int wl_arrayadd(wl_ctx *ctx, int dtype, void *y, const void *z, int64_t n, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if ((!y || !z) && n > 0) return WL_EINVAL_ARG;
+    if (n <= 0) return WL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    if (dtype == WL_F32) hipLaunchKernelGGL((k_arrayadd<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, (const float *)z, n);
+    else hipLaunchKernelGGL((k_arrayadd<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, (const double *)z, n);
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
+int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    if (!y && n > 0) return WL_EINVAL_ARG;
+    if (n <= 0) return WL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
+    if (dtype == WL_F32) hipLaunchKernelGGL((k_rmul<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, s);
+    else hipLaunchKernelGGL((k_rmul<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, s);
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
+}  // extern "C"

@@ -101,4 +101,66 @@ for (f, fw) in ((:dwtc, true), (:idwtc, false))
     end
 end
 
+# ---- MODWT: replaces modwt / imodwt, transforms_maximal_overlap.jl:47-63, 99-107 ----------------------
+function Transforms.modwt(x::ROCVector{T}, wt::OrthoFilter, L::Integer=Util.maxmodwttransformlevels(x)) where {T<:Union{Float32,Float64}}
+    L <= Util.maxmodwttransformlevels(x) || throw(ArgumentError("Too many transform levels (length(x) < 2^L)"))
+    L >= 1 || throw(ArgumentError("L must be >= 1"))
+    n = length(x)
+    out = similar(x, n, L + 1)
+    check(ccall((:wl_modwt, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(out), n, pointer(x), n, wt.qmf, length(wt.qmf), L, stream()))
+    return out
+end
+function Transforms.imodwt(xw::ROCMatrix{T}, wt::OrthoFilter) where {T<:Union{Float32,Float64}}
+    n, nc = size(xw)
+    x = similar(xw, n)
+    check(ccall((:wl_imodwt, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(x), pointer(xw), n, n, nc, wt.qmf, length(wt.qmf), stream()))
+    return x
+end
+
+# ---- Threshold: replaces threshold! (threshold_main.jl:21-117), mad! (denoising.jl:103-110), and the helpers
+# of the translation-invariant branch of denoise (denoising.jl:44-66).  With these methods `denoise(x::ROCArray, ...)`
+# and `noisest` run unchanged: every array operation they perform dispatches here.
+using Wavelets.Threshold: Threshold, HardTH, SoftTH, SemiSoftTH, SteinTH, BiggestTH, PosTH, NegTH
+const THCODE = Dict(HardTH => Cint(0), SoftTH => Cint(1), SemiSoftTH => Cint(2), SteinTH => Cint(3), PosTH => Cint(4), NegTH => Cint(5))
+# Julia computes `x[i] op t` in promote_type(T, typeof(t)): Float64 only when T is Float32 and t is a Float64
+t_is_f64(::Type{T}, t) where {T} = Cint(promote_type(T, typeof(t)) === Float64 && T !== Float64)
+function Threshold.threshold!(x::ROCArray{T}, th::Union{HardTH,SoftTH,SemiSoftTH,SteinTH}, t::Real) where {T<:Union{Float32,Float64}}
+    @assert t >= 0
+    check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], Float64(t), t_is_f64(T, t), stream()))
+    return x
+end
+function Threshold.threshold!(x::ROCArray{T}, th::Union{PosTH,NegTH}) where {T<:Union{Float32,Float64}}
+    check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], 0.0, Cint(0), stream()))
+    return x
+end
+function Threshold.threshold!(x::ROCArray{T}, ::BiggestTH, m::Int) where {T<:Union{Float32,Float64}}
+    @assert m >= 0
+    check(ccall((:wl_threshold_biggest, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(x), length(x), m, stream()))
+    return x
+end
+function Threshold.mad!(y::ROCArray{T}) where {T<:Union{Float32,Float64}}
+    r = Ref{Cdouble}(0)
+    check(ccall((:wl_mad, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), length(y), r, stream()))
+    return T(r[])
+end
+function Util.circshift!(b::ROCVector{T}, a::ROCVector{T}, shift::Integer) where {T<:Union{Float32,Float64}}
+    check(ccall((:wl_circshift, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(b), pointer(a), 1, Int64[length(a)], Int64[shift], stream()))
+    return b
+end
+function Threshold.arrayadd!(y::ROCArray{T}, z::ROCArray{T}) where {T<:Union{Float32,Float64}}
+    length(y) == length(z) || throw(DimensionMismatch("lengths must be equal"))
+    check(ccall((:wl_arrayadd, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), pointer(z), length(y), stream()))
+    return y
+end
+
 end # module

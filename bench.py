@@ -185,6 +185,35 @@ def secondary_leg(W, device):
                     "algorithmic_GBps": round(2 * x.numel() * x.element_size() / ms / 1e6, 1), "kernel": W.last_kernel()})
         del x, y
         torch.cuda.empty_cache()
+    # the inverse of the headline config and the section 8(f) rows (3-D, modwt), same protocol
+    g = torch.Generator(device="cpu").manual_seed(7)
+    db4 = W.wavelet(W.WT.db4)
+    extra = []
+    x2 = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t()
+    y2 = W.similar(x2)
+    extra.append(("2-D idwt db4 filter 8192x8192 f32", 13, x2, lambda: W.idwt_oop_(y2, x2, db4, 13), 2 * x2.numel() * 4))
+    x3 = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0)
+    y3 = W.similar(x3)
+    extra.append(("3-D dwt db4 filter 512^3 f32", 9, x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4))
+    xm = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
+    extra.append(("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, xm, lambda: W.modwt(xm, db4, 8), (1 + 9) * xm.numel() * 4))
+    for label, L, x, fn, alg in extra:
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res.append({"workload": label, "L": int(L), "dtype": "f32", "ms_per_step": round(ms, 5),
+                    "Msamples_per_s": round(x.numel() / ms / 1e3, 1), "algorithmic_GBps": round(alg / ms / 1e6, 1),
+                    "kernel": W.last_kernel()})
+    del extra, x2, y2, x3, y3, xm
+    torch.cuda.empty_cache()
     return res
 
 

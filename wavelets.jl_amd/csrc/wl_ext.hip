@@ -23,6 +23,41 @@ inline unsigned ext_blocks(int64_t n, int per_thread, int cu_count)
     return (unsigned)b;
 }
 
+
+// element-wise in-place pass: 16-byte vectors when the pointer is aligned, scalar tail
+template <typename T, typename F>
+__device__ __forceinline__ void ew_inplace(T *__restrict__ x, int64_t n, int vec_ok, F f)
+{
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    constexpr int U = 4;                      // independent 16-byte accesses in flight per lane
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = vec_ok ? n / V : 0;
+    VT *xv = reinterpret_cast<VT *>(x);
+    const int64_t tile = (int64_t)U * blockDim.x, ntiles = nv / tile;
+    for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int64_t base = tl * tile + threadIdx.x;
+        VT v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xv[base + (int64_t)u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[u][e] = f(v[u][e], (base + (int64_t)u * blockDim.x) * V + e);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[base + (int64_t)u * blockDim.x] = v[u];
+    }
+    for (int64_t i = ntiles * tile + gid; i < nv; i += nthr) {
+        VT v = xv[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = f(v[e], i * V + e);
+        xv[i] = v;
+    }
+    for (int64_t i = nv * V + gid; i < n; i += nthr) x[i] = f(x[i], i);
+}
+inline int vec_ok16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? 1 : 0; }
+
 // ---- MODWT -----------------------------------------------------------------------------------------
 struct ModwtTaps { int F; double h[WL_MAX_FLEN]; double g[WL_MAX_FLEN]; };   // h: detail, g: scaling (both / sqrt 2)
 
@@ -78,20 +113,82 @@ __global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step(const T *__restrict
     }
 }
 
+// the same two kernels for strides that are multiples of the 16-byte vector width (levels >= 3 for Float32,
+// >= 2 for Float64) and N a multiple of it: every tap of V consecutive outputs is one aligned vector load
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_modwt_step_v(const T *__restrict__ v, T *__restrict__ v1, T *__restrict__ w1,
+                                                              int64_t NV, int64_t strideV, ModwtTaps tp)
+{
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const VT *vv = reinterpret_cast<const VT *>(v);
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < NV; t += nthr) {
+        int64_t k = t;
+        VT x = vv[k], w, s;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const double xd = (double)x[e]; w[e] = (T)(tp.h[0] * xd); s[e] = (T)(tp.g[0] * xd); }
+        for (int n = 1; n < tp.F; ++n) {
+            k -= strideV;
+            if (k < 0) { k %= NV; if (k < 0) k += NV; }
+            x = vv[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const double xd = (double)x[e];
+                w[e] = (T)((double)w[e] + tp.h[n] * xd);
+                s[e] = (T)((double)s[e] + tp.g[n] * xd);
+            }
+        }
+        reinterpret_cast<VT *>(w1)[t] = w;
+        reinterpret_cast<VT *>(v1)[t] = s;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step_v(const T *__restrict__ v, const T *__restrict__ w, T *__restrict__ v0,
+                                                               int64_t NV, int64_t strideV, ModwtTaps tp)
+{
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const VT *vv = reinterpret_cast<const VT *>(v), *wv = reinterpret_cast<const VT *>(w);
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < NV; t += nthr) {
+        int64_t k = t;
+        VT a = vv[k], b = wv[k], acc;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = (T)(tp.h[0] * (double)b[e] + tp.g[0] * (double)a[e]);
+        for (int n = 1; n < tp.F; ++n) {
+            k += strideV;
+            if (k >= NV) k %= NV;
+            a = vv[k];
+            b = wv[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = (T)((double)acc[e] + (tp.h[n] * (double)b[e] + tp.g[n] * (double)a[e]));
+        }
+        reinterpret_cast<VT *>(v0)[t] = acc;
+    }
+}
+
 template <typename T>
 int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int64_t N, const double *qmf, int flen, int L)
 {
+    constexpr int V = 16 / sizeof(T);
     int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
     if (rc != WL_OK) return rc;
     ModwtTaps tp;
     make_modwt_taps(qmf, flen, tp);
     T *A = (T *)ctx->ws, *B = A + N;
     const T *cur = x;
-    const unsigned nb = ext_blocks(N, 1, ctx->cu_count);
+    const bool vec_base = (N % V) == 0 && (ldo % V) == 0 && vec_ok16(x) && vec_ok16(out);
     for (int j = 1; j <= L; ++j) {
         T *vdst = (j == L) ? out + (int64_t)L * ldo : ((j & 1) ? A : B);
-        hipLaunchKernelGGL((k_modwt_step<T>), dim3(nb), dim3(EXT_THREADS), 0, st, cur, vdst, out + (int64_t)(j - 1) * ldo, N,
-                           (int64_t)1 << (j - 1), tp);
+        const int64_t stride = (int64_t)1 << (j - 1);
+        if (vec_base && (stride % V) == 0) {
+            hipLaunchKernelGGL((k_modwt_step_v<T>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur, vdst,
+                               out + (int64_t)(j - 1) * ldo, N / V, stride / V, tp);
+        } else {
+            hipLaunchKernelGGL((k_modwt_step<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur, vdst,
+                               out + (int64_t)(j - 1) * ldo, N, stride, tp);
+        }
         WL_HIP(ctx, hipGetLastError());
         cur = vdst;
     }
@@ -101,6 +198,7 @@ int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int
 template <typename T>
 int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int64_t N, int ncols, const double *qmf, int flen)
 {
+    constexpr int V = 16 / sizeof(T);
     int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
     if (rc != WL_OK) return rc;
     ModwtTaps tp;
@@ -108,12 +206,18 @@ int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int
     T *A = (T *)ctx->ws, *B = A + N;
     const T *cur = xw + (int64_t)(ncols - 1) * ldw;
     if (ncols == 1) { WL_HIP(ctx, hipMemcpyAsync(x, cur, (size_t)N * sizeof(T), hipMemcpyDeviceToDevice, st)); return WL_OK; }
-    const unsigned nb = ext_blocks(N, 1, ctx->cu_count);
+    const bool vec_base = (N % V) == 0 && (ldw % V) == 0 && vec_ok16(x) && vec_ok16(xw);
     for (int j = ncols - 1; j >= 1; --j) {
         if (j - 1 >= 62) return WL_EINVAL_L;
         T *dst = (j == 1) ? x : ((j & 1) ? A : B);
-        hipLaunchKernelGGL((k_imodwt_step<T>), dim3(nb), dim3(EXT_THREADS), 0, st, cur, xw + (int64_t)(j - 1) * ldw, dst, N,
-                           (int64_t)1 << (j - 1), tp);
+        const int64_t stride = (int64_t)1 << (j - 1);
+        if (vec_base && (stride % V) == 0) {
+            hipLaunchKernelGGL((k_imodwt_step_v<T>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur,
+                               xw + (int64_t)(j - 1) * ldw, dst, N / V, stride / V, tp);
+        } else {
+            hipLaunchKernelGGL((k_imodwt_step<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur,
+                               xw + (int64_t)(j - 1) * ldw, dst, N, stride, tp);
+        }
         WL_HIP(ctx, hipGetLastError());
         cur = dst;
     }
@@ -124,31 +228,32 @@ int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int
 // ---- threshold! ------------------------------------------------------------------------------------
 // T: element type, C: the type Julia's promotion computes `x[i] op t` in
 template <typename T, typename C>
-__global__ void __launch_bounds__(EXT_THREADS) k_threshold(T *__restrict__ x, int64_t n, int th, C t)
+__device__ __forceinline__ T threshold_one(T xr, int th, C t)
 {
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
-        const T xr = x[i];
-        const C xi = (C)xr;
-        const C ax = xi < 0 ? -xi : xi;
-        const C sg = (C)((xi > 0) - (xi < 0));
-        T out = xr;
-        switch (th) {
-        case WL_TH_HARD: if (ax <= t) out = (T)0; break;
-        case WL_TH_SOFT: { const C sh = ax - t; out = (sh < 0) ? (T)0 : (T)(sg * sh); } break;
-        case WL_TH_SEMISOFT:
-            if (xi <= 2 * t) {
-                const C sh = ax - t;
-                if (sh < 0) out = (T)0;
-                else if (sh - t < 0) out = (T)(sg * sh * 2);
-            }
-            break;
-        case WL_TH_STEIN: { const C sh = 1 - t * t / (xi * xi); out = (sh < 0) ? (T)0 : (T)(xi * sh); } break;
-        case WL_TH_POS: if (xi > 0) out = (T)0; break;
-        case WL_TH_NEG: if (xi < 0) out = (T)0; break;
+    const C xi = (C)xr;
+    const C ax = xi < 0 ? -xi : xi;
+    const C sg = (C)((xi > 0) - (xi < 0));
+    T out = xr;
+    switch (th) {
+    case WL_TH_HARD: if (ax <= t) out = (T)0; break;
+    case WL_TH_SOFT: { const C sh = ax - t; out = (sh < 0) ? (T)0 : (T)(sg * sh); } break;
+    case WL_TH_SEMISOFT:
+        if (xi <= 2 * t) {
+            const C sh = ax - t;
+            if (sh < 0) out = (T)0;
+            else if (sh - t < 0) out = (T)(sg * sh * 2);
         }
-        x[i] = out;
+        break;
+    case WL_TH_STEIN: { const C sh = 1 - t * t / (xi * xi); out = (sh < 0) ? (T)0 : (T)(xi * sh); } break;
+    case WL_TH_POS: if (xi > 0) out = (T)0; break;
+    case WL_TH_NEG: if (xi < 0) out = (T)0; break;
     }
+    return out;
+}
+template <typename T, typename C>
+__global__ void __launch_bounds__(EXT_THREADS) k_threshold(T *__restrict__ x, int64_t n, int th, C t, int vec_ok)
+{
+    ew_inplace<T>(x, n, vec_ok, [=](T v, int64_t) { return threshold_one<T, C>(v, th, t); });
 }
 
 // ---- order statistics: MSB-first radix select on monotone integer keys -------------------------------
@@ -275,14 +380,10 @@ __global__ void k_sel_finish(SelState *s, int absmode, int is_median, T *result_
 }
 // mad!: y[i] = abs(y[i] - m)
 template <typename T>
-__global__ void __launch_bounds__(EXT_THREADS) k_absdev(T *__restrict__ y, int64_t n, const T *m)
+__global__ void __launch_bounds__(EXT_THREADS) k_absdev(T *__restrict__ y, int64_t n, const T *m, int vec_ok)
 {
     const T mm = *m;
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) {
-        const T d = y[i] - mm;
-        y[i] = d < 0 ? -d : d;
-    }
+    ew_inplace<T>(y, n, vec_ok, [=](T v, int64_t) { const T d = v - mm; return d < 0 ? -d : d; });
 }
 // BiggestTH: counts of |x| below / equal to the cut, then the zeroing passes
 template <typename T>
@@ -415,16 +516,27 @@ __global__ void __launch_bounds__(EXT_THREADS) k_circshift(T *__restrict__ b, co
     }
 }
 template <typename T>
-__global__ void __launch_bounds__(EXT_THREADS) k_arrayadd(T *__restrict__ y, const T *__restrict__ z, int64_t n)
+__global__ void __launch_bounds__(EXT_THREADS) k_arrayadd(T *__restrict__ y, const T *__restrict__ z, int64_t n, int vec_ok)
 {
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) y[i] = y[i] + z[i];
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const VT *zv = reinterpret_cast<const VT *>(z);
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = vec_ok ? n / V : 0;
+    VT *yv = reinterpret_cast<VT *>(y);
+    for (int64_t i = gid; i < nv; i += nthr) {
+        VT a = yv[i];
+        const VT b = zv[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] = a[e] + b[e];
+        yv[i] = a;
+    }
+    for (int64_t i = nv * V + gid; i < n; i += nthr) y[i] = y[i] + z[i];
 }
 template <typename T>
-__global__ void __launch_bounds__(EXT_THREADS) k_rmul(T *__restrict__ y, int64_t n, double s)
+__global__ void __launch_bounds__(EXT_THREADS) k_rmul(T *__restrict__ y, int64_t n, double s, int vec_ok)
 {
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthr) y[i] = (T)((double)y[i] * s);
+    ew_inplace<T>(y, n, vec_ok, [=](T v, int64_t) { return (T)((double)v * s); });
 }
 
 inline int ext_enter(wl_ctx *ctx, int dtype)
@@ -484,9 +596,9 @@ int wl_threshold(wl_ctx *ctx, int dtype, void *x, int64_t n, int th, double t, i
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
-    if (dtype == WL_F64) hipLaunchKernelGGL((k_threshold<double, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)x, n, th, t);
-    else if (t_is_f64) hipLaunchKernelGGL((k_threshold<float, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, t);
-    else hipLaunchKernelGGL((k_threshold<float, float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, (float)t);
+    if (dtype == WL_F64) hipLaunchKernelGGL((k_threshold<double, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)x, n, th, t, vec_ok16(x));
+    else if (t_is_f64) hipLaunchKernelGGL((k_threshold<float, double>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, t, vec_ok16(x));
+    else hipLaunchKernelGGL((k_threshold<float, float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)x, n, th, (float)t, vec_ok16(x));
     WL_HIP(ctx, hipGetLastError());
     ctx->last_kernel = "k_threshold";
     return WL_OK;
@@ -527,12 +639,12 @@ int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *str
     if (dtype == WL_F32) {
         rc = median_impl<float>(ctx, st, (const float *)y, n, nullptr, (float *)mdev);
         if (rc != WL_OK) return rc;
-        hipLaunchKernelGGL((k_absdev<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, (const float *)mdev);
+        hipLaunchKernelGGL((k_absdev<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, (const float *)mdev, vec_ok16(y));
         return median_impl<float>(ctx, st, (const float *)y, n, result, (float *)nullptr);
     }
     rc = median_impl<double>(ctx, st, (const double *)y, n, nullptr, (double *)mdev);
     if (rc != WL_OK) return rc;
-    hipLaunchKernelGGL((k_absdev<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, (const double *)mdev);
+    hipLaunchKernelGGL((k_absdev<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, (const double *)mdev, vec_ok16(y));
     return median_impl<double>(ctx, st, (const double *)y, n, result, (double *)nullptr);
 }
 
@@ -567,8 +679,8 @@ int wl_arrayadd(wl_ctx *ctx, int dtype, void *y, const void *z, int64_t n, void 
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
-    if (dtype == WL_F32) hipLaunchKernelGGL((k_arrayadd<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, (const float *)z, n);
-    else hipLaunchKernelGGL((k_arrayadd<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, (const double *)z, n);
+    if (dtype == WL_F32) hipLaunchKernelGGL((k_arrayadd<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, (const float *)z, n, vec_ok16(y) & vec_ok16(z));
+    else hipLaunchKernelGGL((k_arrayadd<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, (const double *)z, n, vec_ok16(y) & vec_ok16(z));
     WL_HIP(ctx, hipGetLastError());
     return WL_OK;
 }
@@ -581,8 +693,8 @@ int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *stream)
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
-    if (dtype == WL_F32) hipLaunchKernelGGL((k_rmul<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, s);
-    else hipLaunchKernelGGL((k_rmul<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, s);
+    if (dtype == WL_F32) hipLaunchKernelGGL((k_rmul<float>), dim3(nb), dim3(EXT_THREADS), 0, st, (float *)y, n, s, vec_ok16(y));
+    else hipLaunchKernelGGL((k_rmul<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, s, vec_ok16(y));
     WL_HIP(ctx, hipGetLastError());
     return WL_OK;
 }

@@ -224,7 +224,7 @@ def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle, monkeypatch)
 
 # ---- lifting ----------------------------------------------------------------------------------------
 LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256), (512, 512), (1024, 1024), (576, 576),
-           (4, 4, 4), (16, 16, 16), (24, 24, 24)]
+           (4, 4, 4), (8, 8, 8), (16, 16, 16), (24, 24, 24), (32, 32, 32), (64, 64, 64)]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -247,6 +247,52 @@ def test_lifting_fwd_inv_bitexact(gpu, W, oracle, dtype, shape):
             t = dev(W, ye)
             W.idwt_(t, sch, L)
             assert np.array_equal(host(W, t), xr)
+
+
+def test_lifting_cubes_fast_vs_generic(gpu, W, oracle):
+    """3-D lifting through k_lift_axis_stream + k_lift_short_lines: against the oracle (128^3) and against the generic
+    kernels (256^3), forward and inverse."""
+    for n, L in ((128, 7), (128, 2), (256, 3)):
+        x = rng_array((n, n, n), np.float32, n)
+        for sname in ("cdf97", "db2", "haar"):
+            sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+            y = host(W, W.dwt(dev(W, x), sch, L))
+            assert "k_lift_short_lines" in W.last_kernel()
+            if n <= 128:
+                ye = oracle.dwt_lifting(x, sch, L)
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+            else:
+                try:
+                    W.set_kernel_path(1)
+                    ye = host(W, W.dwt(dev(W, x), sch, L))
+                    assert "generic" in W.last_kernel()
+                    xe = host(W, W.idwt(dev(W, ye), sch, L))
+                finally:
+                    W.set_kernel_path(0)
+            assert np.array_equal(y, ye), (n, sname, L)
+            assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (n, sname, L, "inv")
+
+
+@pytest.mark.parametrize("tp", ["64", "24", ""])
+def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, monkeypatch, tp):
+    """k_lift_axis_stream (the dim-2 pass of a 2-D lifting level as a register cascade along the strided axis):
+    every chunk length, every scheme shape, forward and inverse, bit for bit against the oracle."""
+    if tp:
+        monkeypatch.setenv("WL_LIFT_TP", tp)
+    for n, Ls in ((512, (1, 3)), (1024, (2,)), (576, (1,)), (2048, (1, 11))):
+        for dtype in (np.float32, np.float64):
+            if n == 2048 and dtype == np.float64:
+                continue
+            x = rng_array((n, n), dtype, n)
+            for sname in ("cdf97", "db2", "haar"):
+                sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+                for L in Ls:
+                    ye = oracle.dwt_lifting(x, sch, L)
+                    y = host(W, W.dwt(dev(W, x), sch, L))
+                    assert "k_lift_axis_stream" in W.last_kernel()
+                    assert np.array_equal(y, ye), (n, sname, L, dtype, np.abs(y - ye).max())
+                    xr = host(W, W.idwt(dev(W, ye), sch, L))
+                    assert np.array_equal(xr, oracle.dwt_lifting(ye, sch, L, fw=False)), (n, sname, L, dtype, "inv")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -228,6 +228,13 @@ int dwt_lifting_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const 
         if (rc) return rc;
         if (handled) return WL_OK;
     }
+    if (ctx->path == 0 && b.nd == 3 && b.nt == 3 && b.full.s[0] == 1 && b.dims[0] == b.dims[1] && b.dims[1] == b.dims[2] &&
+        b.full.s[1] == b.dims[0] && b.full.s[2] == b.dims[0] * b.dims[1]) {
+        int handled = 0;
+        rc = lifting_3d_fast<T>(ctx->ws, ctx->cu_count, st, b.dims[0], y, x, sc, L, fw, &handled, &ctx->last_kernel, &ctx->last_hip);
+        if (rc) return rc;
+        if (handled) return WL_OK;
+    }
     ctx->last_kernel = fw ? "k_generic_lift_fwd" : "k_generic_lift_inv";
     return fw ? generic_lifting_fwd<T>(ctx, st, b, y, x, sc, L) : generic_lifting_inv<T>(ctx, st, b, y, x, sc, L);
 }

@@ -41,6 +41,11 @@ template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
+// 3-D lifting transform of a cube (2^k <= 512 per side) through the axis-streaming and short-line kernels.
+template <typename T>
+int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, const T *x,
+                    const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
+
 // One 3-D filter-bank level assembled from single-axis streaming passes (wl_axis.hip); false = not eligible.
 template <typename T>
 bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,

@@ -696,6 +696,355 @@ static hipError_t launch_transpose(hipStream_t st, const T *src, int64_t lds, T 
     return hipGetLastError();
 }
 
+template <typename T, int N>
+__device__ __forceinline__ void ldv_l(const T *p, T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stv_l(T *p, const T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// One lifting level along a STRIDED axis (the dim-2 pass of a 2-D level) without transposes: lanes own 16 bytes of
+// consecutive rows, the wave marches along the axis pair by pair.  The steps run as a software cascade on a
+// register ring of (s, d) pairs: at time tau step k updates pair tau - D[k], with the delays D chosen so that
+// every operand is exactly in the state the sequential algorithm would see (all earlier steps done there, no later
+// step yet).  A chunk starts VM pairs early (the left reach of the dependency cone) and runs D_last pairs past
+// its end; nothing crosses lanes.  Rounding as in k_lift1d_stream (in-bounds vs wrapped form per element; the
+// pair index is uniform across the wave).
+struct CascadeTab { int D[WL_MAX_STEPS]; int DL, VM, AMIN; };
+template <int ID>
+struct Cascade {
+    typedef Shape<ID> SH;
+    static constexpr int NS = SH::NS;
+    static constexpr int a(int k) { return -SH::S[k].sh; }
+    static constexpr int b(int k) { return SH::S[k].nc - 1 - SH::S[k].sh; }
+    static constexpr CascadeTab make()
+    {
+        CascadeTab t = {};
+        // delay of step k: see DESIGN.md ("lifting along a strided axis")
+        for (int k = 0; k < NS; ++k) {
+            int d = (k > 0) ? t.D[k - 1] : 0;
+            int bo = b(k);                                  // raw operands: pair tau must be loaded
+            for (int m = 0; m < k; ++m) {
+                if (SH::S[m].upd != SH::S[k].upd) {         // m writes k's operand array and reads k's target array
+                    if (t.D[m] + b(k) > bo) bo = t.D[m] + b(k);
+                    if (t.D[m] - a(m) > d) d = t.D[m] - a(m);
+                }
+            }
+            if (bo > d) d = bo;
+            t.D[k] = d < 0 ? 0 : d;
+        }
+        t.DL = t.D[NS - 1];
+        // first valid output pair relative to the first raw pair loaded
+        int cur_s = 0, cur_d = 0;
+        for (int k = 0; k < NS; ++k) {
+            const int o = SH::S[k].upd ? cur_s : cur_d, tg = SH::S[k].upd ? cur_d : cur_s;
+            int v = -t.D[k];
+            if (o - a(k) > v) v = o - a(k);
+            if (tg > v) v = tg;
+            if (SH::S[k].upd) cur_d = v; else cur_s = v;
+        }
+        t.VM = cur_s > cur_d ? cur_s : cur_d;
+        t.AMIN = 0;
+        for (int k = 0; k < NS; ++k) if (a(k) < t.AMIN) t.AMIN = a(k);
+        return t;
+    }
+    static constexpr CascadeTab TAB = make();
+};
+
+template <typename T>
+struct LiftAxisArgs {
+    const T *src; int64_t lds; int64_t bs_src;     // column stride, batch stride (blockIdx.y)
+    T *dst; int64_t ldd; int64_t bs_dst;
+    int64_t R, C;                                  // rows (contiguous), axis length
+    int TP;                                        // output pairs per chunk (multiple of 8)
+    int nstrips, nchunks;
+    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID, int FW, int RPL>
+__global__ void __launch_bounds__(64) k_lift_axis_stream(LiftAxisArgs<T> a)
+{
+    typedef Shape<ID> SH;
+    typedef Cascade<ID> CS;
+    constexpr int R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1;
+    static_assert(PF >= 2, "ring too small for this scheme");
+    const int lane = threadIdx.x;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
+    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t row = ((int64_t)strip * 64 + lane) * RPL;
+    const bool valid = row < a.R;
+    const int64_t rr = valid ? row : 0;
+    const int64_t half = a.C >> 1;
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < half) ? (p0 + a.TP) : half;
+    const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + rr;
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + rr;
+    T rs[R][RPL], rd[R][RPL];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
+    const int64_t tau0 = p0 - VM;                       // first raw pair of this chunk (may be negative: wraps)
+    auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
+        if (i < 0) { i %= half; if (i < 0) i += half; }
+        else if (i >= half) i %= half;
+        return i;
+    };
+    // pair index tau lives in ring slot (tau - tau0) mod R: static once the loop is unrolled by R
+    auto load_pair = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
+        const int64_t iw = wrapi(tau);
+        if (FW) {
+            ldv_l<T, RPL>(base + (2 * iw) * a.lds, rs[slot]);
+            ldv_l<T, RPL>(base + (2 * iw + 1) * a.lds, rd[slot]);
+        } else {
+            T sv[RPL], dv[RPL];
+            ldv_l<T, RPL>(base + iw * a.lds, sv);
+            ldv_l<T, RPL>(base + (half + iw) * a.lds, dv);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) { rs[slot][q] = a.norm1 * sv[q]; rd[slot][q] = a.norm2 * dv[q]; }
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c) load_pair(tau0 + c, c % R);
+    auto step = [&](const int64_t t, const int u) __attribute__((always_inline)) {
+        const int64_t tau = tau0 + t;
+        load_pair(tau + PF, (u + PF) % R);
+#pragma unroll
+        for (int k = 0; k < SH::NS; ++k) {
+            const int upd = SH::S[k].upd, nc = SH::S[k].nc, ak = -SH::S[k].sh, Dk = CS::TAB.D[k];
+            const int slot = ((u - Dk) % R + R) % R;
+            const int64_t iw = wrapi(tau - Dk);
+            const bool inb = (iw + ak >= 0) && (iw + ak + nc - 1 <= half - 1);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                T o[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                    if (kk < nc) o[kk] = upd ? rs[((u - Dk + ak + kk) % R + R) % R][q] : rd[((u - Dk + ak + kk) % R + R) % R][q];
+                const T x = upd ? rd[slot][q] : rs[slot][q];
+                T acc = a.c[k][0] * o[0];
+                if (nc > 1) acc = acc + a.c[k][1] * o[1];
+                if (nc > 2) acc = acc + a.c[k][2] * o[2];
+                const T xin = x + acc;
+                T xb = x + a.c[k][0] * o[0];
+                if (nc > 1) xb = xb + a.c[k][1] * o[1];
+                if (nc > 2) xb = xb + a.c[k][2] * o[2];
+                const T res = inb ? xin : xb;
+                if (upd) rd[slot][q] = res; else rs[slot][q] = res;
+            }
+        }
+        const int64_t io = tau - DL;
+        if (valid && io >= p0 && io < pend) {
+            const int slot = ((u - DL) % R + R) % R;
+            if (FW) {
+                T so[RPL], dO[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) { so[q] = rs[slot][q] * a.norm1; dO[q] = rd[slot][q] * a.norm2; }
+                stv_l<T, RPL>(out + io * a.ldd, so);
+                stv_l<T, RPL>(out + (half + io) * a.ldd, dO);
+            } else {
+                stv_l<T, RPL>(out + (2 * io) * a.ldd, rs[slot]);
+                stv_l<T, RPL>(out + (2 * io + 1) * a.ldd, rd[slot]);
+            }
+        }
+    };
+    const int64_t nstep = (pend - p0) + VM + DL;
+    for (int64_t t0 = 0; t0 < nstep; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u);
+    }
+}
+
+template <typename T, int ID, int FW, int RPL>
+static hipError_t launch_lift_axis_r(hipStream_t st, LiftAxisArgs<T> a, int64_t batch, int cu_count)
+{
+    a.nstrips = (int)((a.R + 64 * RPL - 1) / (64 * RPL));
+    const int64_t half = a.C >> 1;
+    int TP = 64;
+    while (TP > 8 && (int64_t)a.nstrips * ((half + TP - 1) / TP) * batch < (int64_t)cu_count * 8) TP >>= 1;
+    const char *e = std::getenv("WL_LIFT_TP");          // test knob: force the chunk length (multiple of 8)
+    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    a.TP = TP;
+    a.nchunks = (int)((half + TP - 1) / TP);
+    for (int64_t b0 = 0; b0 < batch; b0 += 32768) {
+        const int64_t nb = (batch - b0 < 32768) ? (batch - b0) : 32768;
+        LiftAxisArgs<T> b = a;
+        b.src = a.src + b0 * a.bs_src; b.dst = a.dst + b0 * a.bs_dst;
+        hipLaunchKernelGGL((k_lift_axis_stream<T, ID, FW, RPL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nb), dim3(64), 0, st, b);
+    }
+    return hipGetLastError();
+}
+// 16 bytes of rows per lane when the geometry allows it, single rows otherwise (tiny blocks)
+template <typename T, int ID, int FW>
+static hipError_t launch_lift_axis(hipStream_t st, const LiftAxisArgs<T> &a, int64_t batch, int cu_count)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec = (a.R % VEC) == 0 && (a.lds % VEC) == 0 && (a.ldd % VEC) == 0 && (a.bs_src % VEC) == 0 && (a.bs_dst % VEC) == 0 &&
+                     al16(a.src) && al16(a.dst);
+    if (vec) return launch_lift_axis_r<T, ID, FW, VEC>(st, a, batch, cu_count);
+    return launch_lift_axis_r<T, ID, FW, 1>(st, a, batch, cu_count);
+}
+template <typename T, int FWV>
+static hipError_t launch_lift_axis_id(int id, hipStream_t st, const LiftAxisArgs<T> &a, int64_t batch, int cu_count)
+{
+    switch (id) {
+    case 0: return launch_lift_axis<T, 0, FWV>(st, a, batch, cu_count);
+    case 1: return launch_lift_axis<T, 1, FWV>(st, a, batch, cu_count);
+    case 2: return launch_lift_axis<T, 2, FWV>(st, a, batch, cu_count);
+    case 3: return launch_lift_axis<T, 3, FWV>(st, a, batch, cu_count);
+    case 4: return launch_lift_axis<T, 4, FWV>(st, a, batch, cu_count);
+    default: return launch_lift_axis<T, 5, FWV>(st, a, batch, cu_count);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// One lifting level of SHORT contiguous lines (n <= 512: the dim-1 pass of small 2-D blocks and of 3-D cubes):
+// G = n/(2*PPL) lanes hold one whole line (PPL (s, d) pairs per lane), 64/G lines per wave; a step's operands
+// outside the lane come from the neighbouring lane OF THE SAME GROUP by ds_bpermute with true periodic wrap, so
+// there is no overlap and no boundary recomputation.  Lines are addressed as a 2-D grid (i2 < c2, i3 < c3).
+template <typename T>
+struct LiftShortArgs {
+    const T *a; int64_t a2, a3;      // fw: src          inv: approximation source
+    const T *b; int64_t b2, b3;      // fw: unused       inv: detail source
+    T *o0; int64_t o02, o03;         // fw: s dest       inv: dst
+    T *o1; int64_t o12, o13;         // fw: d dest       inv: unused
+    int n, G, c2;
+    int64_t nlines;
+    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID, int FW, int PPL>
+__global__ void __launch_bounds__(256) k_lift_short_lines(LiftShortArgs<T> a)
+{
+    typedef Shape<ID> SH;
+    const int lane = threadIdx.x & 63;
+    const int G = a.G, lpw = 64 / G;
+    const int g = lane / G, r = lane - g * G;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t li = wave * lpw + g;
+    const bool valid = li < a.nlines;
+    const int64_t lc = valid ? li : 0;
+    const int64_t i3 = lc / a.c2, i2 = lc - i3 * a.c2;
+    const int64_t half = a.n >> 1;
+    T s[PPL], d[PPL];
+    if (FW) {
+        T v[2 * PPL];
+        ldv_l<T, 2 * PPL>(a.a + i2 * a.a2 + i3 * a.a3 + 2 * PPL * r, v);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { s[j] = v[2 * j]; d[j] = v[2 * j + 1]; }                 // Util.split!
+    } else {
+        T sv[PPL], dv[PPL];
+        ldv_l<T, PPL>(a.a + i2 * a.a2 + i3 * a.a3 + PPL * r, sv);
+        ldv_l<T, PPL>(a.b + i2 * a.b2 + i3 * a.b3 + PPL * r, dv);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { s[j] = a.norm1 * sv[j]; d[j] = a.norm2 * dv[j]; }       // normalize! (inverse first)
+    }
+#pragma unroll
+    for (int st = 0; st < SH::NS; ++st) {
+        const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+        T res[PPL];
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) {
+            T o[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                if (kk < nc) {
+                    const int off = jj + kk - sh;
+                    const int delta = l_floordiv(off, PPL), e = off - delta * PPL;
+                    const T v = upd ? s[e] : d[e];
+                    if (delta == 0) o[kk] = v;
+                    else {
+                        int rs = r + delta;                     // |delta| <= 3 (PPL >= 1, |off| <= 3): wrap by repeated add
+                        while (rs < 0) rs += G;
+                        while (rs >= G) rs -= G;
+                        o[kk] = __shfl(v, g * G + rs, 64);
+                    }
+                }
+            }
+            const int64_t jg = (int64_t)PPL * r + jj - sh;
+            const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+            const T x = upd ? d[jj] : s[jj];
+            T acc = a.c[st][0] * o[0];
+            if (nc > 1) acc = acc + a.c[st][1] * o[1];
+            if (nc > 2) acc = acc + a.c[st][2] * o[2];
+            const T xin = x + acc;
+            T xb = x + a.c[st][0] * o[0];
+            if (nc > 1) xb = xb + a.c[st][1] * o[1];
+            if (nc > 2) xb = xb + a.c[st][2] * o[2];
+            res[jj] = inb ? xin : xb;
+        }
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) { if (upd) d[jj] = res[jj]; else s[jj] = res[jj]; }
+    }
+    if (FW) {
+        T so[PPL], dO[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { so[j] = s[j] * a.norm1; dO[j] = d[j] * a.norm2; }        // normalize!
+        if (valid) {
+            stv_l<T, PPL>(a.o0 + i2 * a.o02 + i3 * a.o03 + PPL * r, so);
+            stv_l<T, PPL>(a.o1 + i2 * a.o12 + i3 * a.o13 + PPL * r, dO);
+        }
+    } else {
+        T v[2 * PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { v[2 * j] = s[j]; v[2 * j + 1] = d[j]; }                  // Util.merge!
+        if (valid) stv_l<T, 2 * PPL>(a.o0 + i2 * a.o02 + i3 * a.o03 + 2 * PPL * r, v);
+    }
+}
+
+// n in {2, 4} (one lane per line) or {8, 16, ..., 512}
+static inline bool short_lift_ok(int64_t n) { return n == 2 || n == 4 || (n >= 8 && n <= 512 && (n & (n - 1)) == 0); }
+
+template <typename T, int ID, int FW>
+static hipError_t launch_lift_short(hipStream_t st, LiftShortArgs<T> a, int n, int c2, int64_t c3)
+{
+    a.n = n; a.c2 = c2; a.nlines = (int64_t)c2 * c3;
+    if (a.nlines <= 0) return hipSuccess;
+    const int ppl = (n >= 8) ? 4 : n / 2;
+    a.G = (n / 2) / ppl;
+    const int lpw = 64 / a.G;
+    const int64_t nwaves = (a.nlines + lpw - 1) / lpw;
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+    if (ppl == 4) hipLaunchKernelGGL((k_lift_short_lines<T, ID, FW, 4>), grid, block, 0, st, a);
+    else if (ppl == 2) hipLaunchKernelGGL((k_lift_short_lines<T, ID, FW, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_lift_short_lines<T, ID, FW, 1>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+template <typename T, int FWV>
+static hipError_t launch_lift_short_id(int id, hipStream_t st, const LiftShortArgs<T> &a, int n, int c2, int64_t c3)
+{
+    switch (id) {
+    case 0: return launch_lift_short<T, 0, FWV>(st, a, n, c2, c3);
+    case 1: return launch_lift_short<T, 1, FWV>(st, a, n, c2, c3);
+    case 2: return launch_lift_short<T, 2, FWV>(st, a, n, c2, c3);
+    case 3: return launch_lift_short<T, 3, FWV>(st, a, n, c2, c3);
+    case 4: return launch_lift_short<T, 4, FWV>(st, a, n, c2, c3);
+    default: return launch_lift_short<T, 5, FWV>(st, a, n, c2, c3);
+    }
+}
+
 template <typename T, int FWV>
 static void launch_lines_id(int id, hipStream_t st, const Lift1DArgs<T> &a, int64_t nlines, int cu_count)
 {
@@ -709,6 +1058,9 @@ static void launch_lines_id(int id, hipStream_t st, const Lift1DArgs<T> &a, int6
     }
 }
 
+// 2-D (square) lifting transform: per level the dim-2 pass streams along the strided axis (k_lift_axis_stream) and
+// the dim-1 pass runs on contiguous lines (k_lift1d_stream from 512 rows, k_lift_short_lines below); levels whose
+// size fits neither (not a power of two below 512) use the generic kernels.
 template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err)
@@ -716,17 +1068,25 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     *handled = 0;
     constexpr int VEC = 16 / sizeof(T);
     const int id = match_shape<T>(sc);
-    if (id < 0 || L < 1 || n0 < 512 || (n0 % 64) != 0 || (ldy % VEC) != 0 || !al16(x) || !al16(y)) return WL_OK;
+    if (id < 0 || L < 1 || n0 < 2 || (ldy % VEC) != 0 || !al16(x) || !al16(y)) return WL_OK;
 #define WL_E(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } } while (0)
 #define WL_EL() WL_E(hipGetLastError())
     const int64_t N = n0 * n0;
     Work<T> w = carve<T>(ws, N);
     Lift1DArgs<T> a;
+    LiftAxisArgs<T> ax;
+    LiftShortArgs<T> sa;
     for (int i = 0; i < WL_MAX_STEPS; ++i)
-        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
-    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) {
+            a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+            ax.c[i][k] = a.c[i][k];
+            sa.c[i][k] = a.c[i][k];
+        }
+    a.norm1 = ax.norm1 = sa.norm1 = sc.norm1;
+    a.norm2 = ax.norm2 = sa.norm2 = sc.norm2;
     Strides3 full = {{1, ldy, ldy * n0}};
-    auto fast_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
+    auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
+    bool any_fast = false;
 
     if (fw) {
         const T *cur = x;
@@ -738,18 +1098,26 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             T *llbuf = pp ? w.B : w.A;
             T *lld = last ? y : llbuf;
             const int64_t ldd = last ? ldy : h;
-            if (fast_ok(n)) {
-                WL_E(launch_transpose<T>(st, cur, cur_ls, w.T0, n, n));                 // T0[j + i*n] = cur[i, j]
-                a.a = w.T0; a.a_ls = n; a.b = nullptr; a.b_ls = 0;                      // rows as lines
-                a.o0 = w.T1; a.o0_ls = n; a.o1 = w.T1 + h; a.o1_ls = n; a.n = n; a.ntiles = (h + 247) / 248;
-                launch_lines_id<T, 1>(id, st, a, n, cu_count); WL_EL();
-                WL_E(launch_transpose<T>(st, w.T1, n, w.T0, n, n));                     // back to normal orientation
-                // columns [0, h): s -> LL, d -> y[h.., j]
-                a.a = w.T0; a.a_ls = n; a.o0 = lld; a.o0_ls = ldd; a.o1 = y + h; a.o1_ls = ldy;
-                launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
-                // columns [h, n): s -> y[0..h, j], d -> y[h.., j]
-                a.a = w.T0 + h * n; a.o0 = y + h * ldy; a.o0_ls = ldy; a.o1 = y + h * ldy + h; a.o1_ls = ldy;
-                launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
+            if (lines_ok(n) || short_lift_ok(n)) {
+                any_fast = true;
+                // rows (dim 2): one streaming pass along the strided axis, T0 = [s-columns | d-columns]
+                ax.src = cur; ax.lds = cur_ls; ax.bs_src = 0; ax.dst = w.T0; ax.ldd = n; ax.bs_dst = 0; ax.R = n; ax.C = n;
+                WL_E((launch_lift_axis_id<T, 1>(id, st, ax, 1, cu_count)));
+                if (lines_ok(n)) {
+                    a.b = nullptr; a.b_ls = 0; a.n = n; a.ntiles = (h + 247) / 248;
+                    // columns [0, h): s -> LL, d -> y[h.., j]
+                    a.a = w.T0; a.a_ls = n; a.o0 = lld; a.o0_ls = ldd; a.o1 = y + h; a.o1_ls = ldy;
+                    launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
+                    // columns [h, n): s -> y[0..h, j], d -> y[h.., j]
+                    a.a = w.T0 + h * n; a.o0 = y + h * ldy; a.o0_ls = ldy; a.o1 = y + h * ldy + h; a.o1_ls = ldy;
+                    launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
+                } else {
+                    sa.b = nullptr; sa.b2 = sa.b3 = 0; sa.a3 = sa.o03 = sa.o13 = 0;
+                    sa.a = w.T0; sa.a2 = n; sa.o0 = lld; sa.o02 = ldd; sa.o1 = y + h; sa.o12 = ldy;
+                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, 1)));
+                    sa.a = w.T0 + h * n; sa.o0 = y + h * ldy; sa.o02 = ldy; sa.o1 = y + h * ldy + h; sa.o12 = ldy;
+                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, 1)));
+                }
             } else {
                 Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
                 Strides3 box = {{1, n, n * n}}, cst = {{1, cur_ls, cur_ls * n}}, lst = {{1, ldd, ldd * h}};
@@ -771,18 +1139,28 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
-            if (fast_ok(n)) {
+            if (lines_ok(n) || short_lift_ok(n)) {
+                any_fast = true;
                 // columns: merged column j -> T0[:, j]
-                a.o0 = w.T0; a.o0_ls = n; a.o1 = nullptr; a.o1_ls = 0; a.n = n; a.ntiles = (h + 247) / 248;
-                if (llsrc) { a.a = llsrc; a.a_ls = ll_ls; } else { a.a = x; a.a_ls = ldy; }
-                a.b = x + h; a.b_ls = ldy;
-                launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
-                a.a = x + h * ldy; a.a_ls = ldy; a.b = x + h * ldy + h; a.b_ls = ldy; a.o0 = w.T0 + h * n;
-                launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
-                WL_E(launch_transpose<T>(st, w.T0, n, w.T1, n, n));                     // rows as lines
-                a.a = w.T1; a.a_ls = n; a.b = w.T1 + h; a.b_ls = n; a.o0 = w.T0; a.o0_ls = n;
-                launch_lines_id<T, 0>(id, st, a, n, cu_count); WL_EL();
-                WL_E(launch_transpose<T>(st, w.T0, n, out, ldo, n));
+                if (lines_ok(n)) {
+                    a.o0 = w.T0; a.o0_ls = n; a.o1 = nullptr; a.o1_ls = 0; a.n = n; a.ntiles = (h + 247) / 248;
+                    if (llsrc) { a.a = llsrc; a.a_ls = ll_ls; } else { a.a = x; a.a_ls = ldy; }
+                    a.b = x + h; a.b_ls = ldy;
+                    launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
+                    a.a = x + h * ldy; a.a_ls = ldy; a.b = x + h * ldy + h; a.b_ls = ldy; a.o0 = w.T0 + h * n;
+                    launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
+                } else {
+                    sa.o1 = nullptr; sa.o12 = sa.o13 = 0; sa.a3 = sa.b3 = sa.o03 = 0;
+                    sa.o0 = w.T0; sa.o02 = n;
+                    if (llsrc) { sa.a = llsrc; sa.a2 = ll_ls; } else { sa.a = x; sa.a2 = ldy; }
+                    sa.b = x + h; sa.b2 = ldy;
+                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, 1)));
+                    sa.a = x + h * ldy; sa.a2 = ldy; sa.b = x + h * ldy + h; sa.b2 = ldy; sa.o0 = w.T0 + h * n;
+                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, 1)));
+                }
+                // rows (dim 2): streaming pass along the strided axis straight into the result
+                ax.src = w.T0; ax.lds = n; ax.bs_src = 0; ax.dst = out; ax.ldd = ldo; ax.bs_dst = 0; ax.R = n; ax.C = n;
+                WL_E((launch_lift_axis_id<T, 0>(id, st, ax, 1, cu_count)));
             } else {
                 Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
                 Strides3 box = {{1, n, n * n}}, lst = {{1, ll_ls, ll_ls * h}}, ost = {{1, ldo, ldo * n}};
@@ -796,12 +1174,102 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             llsrc = out; ll_ls = ldo; pp ^= 1;
         }
     }
+    *handled = 1;
+    if (kernel_name) *kernel_name = any_fast ? "k_lift_axis_stream+lines" : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
+    return WL_OK;
+}
+
+// 3-D (cube) lifting transform, cubes of 2^k <= 512 per side: planes and rows along the strided axes
+// (k_lift_axis_stream, rows batched over the planes), columns as short lines with the LLL corner routed to the
+// approximation buffer.  Other sizes: not handled (generic kernels).
+template <typename T>
+int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, const T *x,
+                    const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err)
+{
+    *handled = 0;
+    const int id = match_shape<T>(sc);
+    if (id < 0 || L < 1 || n0 < 8 || n0 > 512 || (n0 & (n0 - 1)) != 0 || !al16(x) || !al16(y)) return WL_OK;
+    if ((n0 >> (L - 1)) < 2) return WL_OK;
+    const int64_t N = n0 * n0 * n0;
+    Work<T> w = carve<T>(ws, N);
+    LiftAxisArgs<T> ax;
+    LiftShortArgs<T> sa;
+    for (int i = 0; i < WL_MAX_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) {
+            ax.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+            sa.c[i][k] = ax.c[i][k];
+        }
+    ax.norm1 = sa.norm1 = sc.norm1;
+    ax.norm2 = sa.norm2 = sc.norm2;
+    const int64_t y1 = n0, y2 = n0 * n0;
+    if (fw) {
+        const T *cur = x;
+        int64_t c1 = n0, c2 = n0 * n0;
+        int pp = 0;
+        for (int l = 1; l <= L; ++l) {
+            const int64_t n = n0 >> (l - 1), h = n >> 1;
+            const bool last = (l == L);
+            T *llbuf = pp ? w.B : w.A;
+            // planes (dim 3): the cube is an (n*n) x n matrix when its first two dims are dense
+            if (c1 == n) {
+                ax.src = cur; ax.lds = c2; ax.bs_src = 0; ax.dst = w.T0; ax.ldd = n * n; ax.bs_dst = 0; ax.R = n * n; ax.C = n;
+                WL_E((launch_lift_axis_id<T, 1>(id, st, ax, 1, cu_count)));
+            } else {       // (not reached: level 1 reads the dense cube, deeper levels the dense approximation buffer)
+                return WL_OK;
+            }
+            // rows (dim 2): n matrices of n x n
+            ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
+            WL_E((launch_lift_axis_id<T, 1>(id, st, ax, n, cu_count)));
+            // columns (dim 1): four (i2, i3) quadrants; only the low-low one sends its approximation on
+            sa.b = nullptr; sa.b2 = sa.b3 = 0;
+            for (int q3 = 0; q3 < 2; ++q3)
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int64_t o2 = q2 * h, o3 = q3 * h;
+                    sa.a = w.T1 + o2 * n + o3 * n * n; sa.a2 = n; sa.a3 = n * n;
+                    if (q2 == 0 && q3 == 0 && !last) { sa.o0 = llbuf; sa.o02 = h; sa.o03 = h * h; }
+                    else { sa.o0 = y + o2 * y1 + o3 * y2; sa.o02 = y1; sa.o03 = y2; }
+                    sa.o1 = y + h + o2 * y1 + o3 * y2; sa.o12 = y1; sa.o13 = y2;
+                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, h)));
+                }
+            cur = llbuf; c1 = h; c2 = h * h; pp ^= 1;
+        }
+    } else {
+        const T *llsrc = nullptr;
+        int pp = 0;
+        for (int l = L; l >= 1; --l) {
+            const int64_t n = n0 >> (l - 1), h = n >> 1;
+            T *out = (l == 1) ? y : (pp ? w.B : w.A);
+            // columns first: merged lines into T0 (dense n^3)
+            sa.o1 = nullptr; sa.o12 = sa.o13 = 0;
+            for (int q3 = 0; q3 < 2; ++q3)
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int64_t p2 = q2 * h, p3 = q3 * h;
+                    if (q2 == 0 && q3 == 0 && llsrc) { sa.a = llsrc; sa.a2 = h; sa.a3 = h * h; }
+                    else { sa.a = x + p2 * y1 + p3 * y2; sa.a2 = y1; sa.a3 = y2; }
+                    sa.b = x + h + p2 * y1 + p3 * y2; sa.b2 = y1; sa.b3 = y2;
+                    sa.o0 = w.T0 + p2 * n + p3 * n * n; sa.o02 = n; sa.o03 = n * n;
+                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, h)));
+                }
+            // rows (dim 2)
+            ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
+            WL_E((launch_lift_axis_id<T, 0>(id, st, ax, n, cu_count)));
+            // planes (dim 3); the result of level 1 goes to y (dense cube), deeper ones to the dense n^3 buffer
+            ax.src = w.T1; ax.lds = n * n; ax.bs_src = 0; ax.dst = out; ax.ldd = (l == 1) ? y2 : n * n; ax.bs_dst = 0; ax.R = n * n; ax.C = n;
+            WL_E((launch_lift_axis_id<T, 0>(id, st, ax, 1, cu_count)));
+            llsrc = out; pp ^= 1;
+        }
+    }
 #undef WL_E
 #undef WL_EL
     *handled = 1;
-    if (kernel_name) *kernel_name = "k_lift1d_stream+k_transpose";
+    if (kernel_name) *kernel_name = "k_lift_axis_stream+k_lift_short_lines";
     return WL_OK;
 }
+template int lifting_3d_fast<float>(void *, int, hipStream_t, int64_t, float *, const float *, const LiftScheme<float> &, int, int, int *,
+                                    const char **, int *);
+template int lifting_3d_fast<double>(void *, int, hipStream_t, int64_t, double *, const double *, const LiftScheme<double> &, int, int,
+                                     int *, const char **, int *);
+
 template int lifting_2d_fast<float>(void *, int, hipStream_t, int64_t, int64_t, float *, const float *, const LiftScheme<float> &,
                                     int, int, int *, const char **, int *);
 template int lifting_2d_fast<double>(void *, int, hipStream_t, int64_t, int64_t, double *, const double *,

@@ -1,0 +1,32 @@
+"""Tiny driver for profiling one entry point under rocprofv3: python tools/run_case.py {idwt2d|lift2d|dwt3d|modwt} [reps]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wavelets_jl_amd as W
+
+case = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+g = torch.Generator(device="cpu").manual_seed(7)
+db4 = W.wavelet(W.WT.db4)
+if case == "idwt2d":
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    fn = lambda: W.idwt_oop_(y, x, db4, 13)
+elif case == "lift2d":
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.dwt_oop_(y, x, sch, 13)
+elif case == "dwt3d":
+    x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
+    y = W.similar(x)
+    fn = lambda: W.dwt_oop_(y, x, db4, 9)
+elif case == "modwt":
+    x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
+    fn = lambda: W.modwt(x, db4, 8)
+else:
+    raise SystemExit("unknown case")
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()
+print(case, "done", W.last_kernel())

@@ -151,6 +151,34 @@ def test_fused_inverse_2d_kernel(gpu, W, oracle, monkeypatch, dtype, ppl):
                 assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (shape, fname, L)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_long_filter_kernels(gpu, W, oracle, dtype):
+    """12..24-tap filters (db6..db10, sym6..sym10, coif4..coif8): k_long_lines (multi-lane halo) and the 32-slot
+    ring of the axis kernels, 1-D / batched columns / 2-D, forward and inverse, bit for bit against the oracle."""
+    filters = {"db6": 12, "db7": 14, "sym8": 16, "db9": 18, "db10": 20, "coif8": 24}
+    for fname, flen in filters.items():
+        wt = W.wavelet(getattr(W.WT, fname))
+        assert len(wt.qmf) == flen
+        for shape, Ls in (((4096,), (1, 3, 12)), ((1 << 16,), (16,)), ((1000 * 8,), (2,)), ((512, 512), (1, 2)), ((1024, 2048), (3,)),
+                          ((2048, 64), (1,)), ((520, 96), (1,))):
+            if dtype == np.float64 and shape == (1024, 2048):
+                continue
+            x = rng_array(shape, dtype, flen + sum(shape))
+            for L in Ls:
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                big = int(np.prod(shape)) > 16384          # smaller blocks are finished by the LDS tail kernels alone
+                assert W.last_kernel() == "k_long_lines" or not big, (fname, shape, L, W.last_kernel())
+                assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                assert W.last_kernel() == "k_long_lines" or not big, (fname, shape, L, W.last_kernel())
+                assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
+        xm = rng_array((4096, 5), dtype, flen)
+        assert np.array_equal(host(W, W.dwtc(dev(W, xm), wt, 4)), oracle.dwtc_filter(xm, wt.qmf, 4))
+        ym = oracle.dwtc_filter(xm, wt.qmf, 4)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ym), wt, 4)), oracle.dwtc_filter(ym, wt.qmf, 4, fw=False))
+
+
 def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
     """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
     forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic

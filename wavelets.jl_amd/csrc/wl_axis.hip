@@ -53,6 +53,11 @@ __device__ __forceinline__ void a_st(T *p, const T (&v)[N])
 }
 
 // ---------------------------------------------------------------------------------------------------
+// column ring of the forward axis kernel: 16 slots up to 10 taps, 32 beyond (loads run (R-F)/2 steps ahead)
+constexpr int axis_ring(int F) { return F <= 10 ? 16 : 32; }
+// coefficient rings of the inverse axis kernel: (F-2)/2 + 1 live columns + the prefetch distance
+constexpr int axis_ring_inv(int F) { return F <= 10 ? 8 : 16; }
+
 template <typename T, int F>
 struct AxisArgs {
     const T *src; int64_t lds; int64_t bs_src;     // column stride, batch stride
@@ -67,7 +72,7 @@ struct AxisArgs {
 template <typename T, int F, int RPL>
 __global__ void __launch_bounds__(64) k_fwd_axis_stream(AxisArgs<T, F> a)
 {
-    constexpr int SH = (F - 2) / 2, R = 16, U = 8, PFD = (R - F) / 2;
+    constexpr int SH = (F - 2) / 2, R = axis_ring(F), U = R / 2, PFD = (R - F) / 2;
     const int lane = threadIdx.x;
     const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
     const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(64) k_fwd_axis_stream(AxisArgs<T, F> a)
     const int64_t C = a.C, nx = C >> 1;
     const int64_t j0 = (int64_t)chunk * a.TJ;
     const int64_t jend = (j0 + a.TJ < C) ? (j0 + a.TJ) : C;
-    const int S = (int)((jend - j0) >> 1);          // multiple of 8
+    const int S = (int)((jend - j0) >> 1);          // multiple of U
     const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + rr;
     T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + rr;
     T ring[R][RPL];
@@ -150,7 +155,7 @@ __device__ __forceinline__ void a_inv_pair(const T *sw, const T *dw, const TapsA
 template <typename T, int F, int RPL>
 __global__ void __launch_bounds__(64) k_inv_axis_stream(AxisArgs<T, F> a)
 {
-    constexpr int SH = (F - 2) / 2, R = 8;
+    constexpr int SH = (F - 2) / 2, R = axis_ring_inv(F);
     const int lane = threadIdx.x;
     const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
     const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
@@ -282,6 +287,109 @@ __global__ void __launch_bounds__(256) k_short_lines(ShortArgs<T, F> a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Long filters (12..24 taps) on contiguous lines: the 8-samples-per-lane layout of k_fwd1d_stream / k_inv1d_stream,
+// with the halo gathered from up to three lanes on either side by ds_bpermute (the DPP single-neighbour trick only
+// reaches F <= 10).  Wave tiles overlap by the halo lanes; one line per blockIdx.y.
+template <typename T, int F>
+struct LongArgs {
+    const T *a; int64_t a_ls;       // fw: src lines          inv: approximation source
+    const T *b; int64_t b_ls;       // fw: unused             inv: detail source
+    T *o0; int64_t o0_ls;           // fw: s destination      inv: dst lines
+    T *o1; int64_t o1_ls;           // fw: d destination      inv: unused
+    int64_t n;                      // line length (multiple of 8, >= 512)
+    int64_t ntiles;
+    TapsA<T, F> tp;
+};
+
+template <typename T, int F, int FW>
+__global__ void __launch_bounds__(256) k_long_lines(LongArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2;
+    constexpr int HF = (F - 2 + 7) / 8;           // forward: halo lanes on each side (F-2 samples, 8 per lane)
+    constexpr int HI = (SH + 3) / 4;              // inverse: halo lanes on each side (SH coefficients, 4 per lane)
+    constexpr int HL = FW ? HF : HI;
+    constexpr int VP = (64 - 2 * HL) * 4;         // pairs owned by a wave tile
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t nx = a.n >> 1;
+    const int64_t line = blockIdx.y;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k0 = tile * VP + (int64_t)(lane - HL) * 4;       // first pair of this lane (may wrap)
+        int64_t kw = k0;
+        if (kw < 0) kw += nx;
+        if (kw >= nx) kw -= nx;
+        const bool store = lane >= HL && lane < 64 - HL && k0 < nx;
+        if (FW) {
+            T v[8];
+            a_ld<T, 8>(a.a + line * a.a_ls + 2 * kw, v);
+            constexpr int LO = F - 2;                                   // ext[LO + e] = sample e of this lane
+            T ext[8 + 2 * (F - 2)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ext[LO + e] = v[e];
+#pragma unroll
+            for (int e = 0; e < F - 2; ++e) {
+                ext[LO + 8 + e] = __shfl_down(v[e % 8], 1 + e / 8, 64);                       // following samples
+                ext[LO - 1 - e] = __shfl_up(v[7 - (e % 8)], 1 + e / 8, 64);                   // preceding samples
+            }
+            T so[4], dO[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T sacc = a.tp.h[0] * ext[LO + 2 * q];
+#pragma unroll
+                for (int m = 1; m < F; ++m) sacc = sacc + a.tp.h[m] * ext[LO + 2 * q + m];
+                T dacc = a.tp.g[F - 1] * ext[LO + 2 * q + 1 - (F - 1)];
+#pragma unroll
+                for (int m = F - 2; m >= 0; --m) dacc = dacc + a.tp.g[m] * ext[LO + 2 * q + 1 - m];
+                so[q] = sacc;
+                dO[q] = dacc;
+            }
+            if (store) {
+                a_st<T, 4>(a.o0 + line * a.o0_ls + k0, so);
+                a_st<T, 4>(a.o1 + line * a.o1_ls + k0, dO);
+            }
+        } else {
+            T sv[4], dv[4];
+            a_ld<T, 4>(a.a + line * a.a_ls + kw, sv);
+            a_ld<T, 4>(a.b + line * a.b_ls + kw, dv);
+            // sx[i] = s[p = i - SH], dx[i] = d[p = i] relative to this lane's first pair
+            T sx[4 + SH], dx[4 + SH];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sx[SH + i] = sv[i]; dx[i] = dv[i]; }
+#pragma unroll
+            for (int e = 0; e < SH; ++e) {
+                sx[SH - 1 - e] = __shfl_up(sv[3 - (e % 4)], 1 + e / 4, 64);
+                dx[4 + e] = __shfl_down(dv[e % 4], 1 + e / 4, 64);
+            }
+            T out[8];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) a_inv_pair<T, F>(&sx[p], &dx[p], a.tp, out[2 * p], out[2 * p + 1]);
+            if (store) a_st<T, 8>(a.o0 + line * a.o0_ls + 2 * k0, out);
+        }
+    }
+}
+
+template <typename T, int F, int FW>
+static hipError_t launch_long(hipStream_t st, const Taps<T> &taps, LongArgs<T, F> a, int64_t n, int64_t nlines, int cu_count)
+{
+    constexpr int SH = (F - 2) / 2, HL = FW ? (F - 2 + 7) / 8 : (SH + 3) / 4, VP = (64 - 2 * HL) * 4;
+    a.n = n;
+    a.ntiles = ((n >> 1) + VP - 1) / VP;
+    a.tp = shrink_a<T, F>(taps);
+    if (nlines <= 0) return hipSuccess;
+    int64_t nblk = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 32;
+    if (nblk * nlines > cap) { nblk = cap / nlines; if (nblk < 1) nblk = 1; }
+    for (int64_t l0 = 0; l0 < nlines; l0 += 32768) {
+        const int64_t nb = (nlines - l0 < 32768) ? (nlines - l0) : 32768;
+        LongArgs<T, F> b = a;
+        b.a = a.a + l0 * a.a_ls; b.b = a.b ? a.b + l0 * a.b_ls : nullptr; b.o0 = a.o0 + l0 * a.o0_ls; b.o1 = a.o1 ? a.o1 + l0 * a.o1_ls : nullptr;
+        hipLaunchKernelGGL((k_long_lines<T, F, FW>), dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 static inline bool a_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool short_ok(int64_t n) { return n >= 16 && n <= 512 && (n % 8) == 0 && (64 % (n / 8)) == 0; }
 
@@ -306,7 +414,7 @@ static hipError_t launch_axis(hipStream_t st, const Taps<T> &taps, const T *src,
     a.src = src; a.lds = lds; a.bs_src = bs_src; a.dst = dst; a.ldd = ldd; a.bs_dst = bs_dst; a.R = R; a.C = C;
     a.nstrips = (int)((R + 64 * RPL - 1) / (64 * RPL));
     const int64_t units = FW ? C : (C >> 1);           // chunked quantity: input columns (fw) / output pairs (inv)
-    const int unit = FW ? 16 : 8;
+    const int unit = FW ? axis_ring(F) : axis_ring_inv(F);
     int TJ = FW ? 128 : 64;
     while (TJ > unit && (int64_t)a.nstrips * ((units + TJ - 1) / TJ) * batch < (int64_t)cu_count * 8) TJ >>= 1;
     a.TJ = TJ;
@@ -404,6 +512,84 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     });
     return ok;
 }
+
+#define WL_DISPATCH_FL(F_, ...)                              \
+    switch (F_) {                                            \
+    case 12: { constexpr int FF = 12; __VA_ARGS__; } break;  \
+    case 14: { constexpr int FF = 14; __VA_ARGS__; } break;  \
+    case 16: { constexpr int FF = 16; __VA_ARGS__; } break;  \
+    case 18: { constexpr int FF = 18; __VA_ARGS__; } break;  \
+    case 20: { constexpr int FF = 20; __VA_ARGS__; } break;  \
+    case 24: { constexpr int FF = 24; __VA_ARGS__; } break;  \
+    default: break;                                          \
+    }
+
+bool long_filter_ok(int F) { return F == 12 || F == 14 || F == 16 || F == 18 || F == 20 || F == 24; }
+
+// One forward level of `nlines` lines with a long filter: s -> sdst, d -> ddst (line strides in elements).
+template <typename T>
+bool long_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls,
+                          T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    *err = hipSuccess;
+    if (!long_filter_ok(taps.F) || n < 512 || (n % 8) != 0 || !a_al16(src) || !a_al16(sdst) || !a_al16(ddst) ||
+        (nlines > 1 && ((src_ls % VEC) != 0 || (s_ls % VEC) != 0 || (d_ls % VEC) != 0)))
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FL(taps.F, {
+        LongArgs<T, FF> a;
+        a.a = src; a.a_ls = src_ls; a.b = nullptr; a.b_ls = 0; a.o0 = sdst; a.o0_ls = s_ls; a.o1 = ddst; a.o1_ls = d_ls;
+        *err = launch_long<T, FF, 1>(st, taps, a, n, nlines, cu_count);
+        ok = true;
+    });
+    return ok;
+}
+template <typename T>
+bool long_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls,
+                          T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    *err = hipSuccess;
+    if (!long_filter_ok(taps.F) || n < 512 || (n % 8) != 0 || !a_al16(ssrc) || !a_al16(dsrc) || !a_al16(dst) ||
+        (nlines > 1 && ((s_ls % VEC) != 0 || (d_ls % VEC) != 0 || (o_ls % VEC) != 0)))
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FL(taps.F, {
+        LongArgs<T, FF> a;
+        a.a = ssrc; a.a_ls = s_ls; a.b = dsrc; a.b_ls = d_ls; a.o0 = dst; a.o0_ls = o_ls; a.o1 = nullptr; a.o1_ls = 0;
+        *err = launch_long<T, FF, 0>(st, taps, a, n, nlines, cu_count);
+        ok = true;
+    });
+    return ok;
+}
+// The strided-axis pass (dim 2 of a matrix of R contiguous rows x C columns) with a long filter.
+template <typename T>
+bool long_axis_level(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t lds, T *dst, int64_t ldd,
+                     int64_t R, int64_t C, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    *err = hipSuccess;
+    if (!long_filter_ok(taps.F) || (C % 32) != 0 || C < 32 || (R % VEC) != 0 || (lds % VEC) != 0 || (ldd % VEC) != 0 ||
+        !a_al16(src) || !a_al16(dst))
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FL(taps.F, {
+        if (fw) *err = launch_axis<T, FF, 1>(st, taps, src, lds, 0, dst, ldd, 0, R, C, 1, cu_count);
+        else *err = launch_axis<T, FF, 0>(st, taps, src, lds, 0, dst, ldd, 0, R, C, 1, cu_count);
+        ok = true;
+    });
+    return ok;
+}
+#define WL_INST_LONG(T)                                                                                                          \
+    template bool long_lines_fwd_level<T>(hipStream_t, const Taps<T> &, const T *, int64_t, T *, int64_t, T *, int64_t, int64_t, \
+                                          int64_t, int, hipError_t *);                                                          \
+    template bool long_lines_inv_level<T>(hipStream_t, const Taps<T> &, const T *, int64_t, const T *, int64_t, T *, int64_t,    \
+                                          int64_t, int64_t, int, hipError_t *);                                                 \
+    template bool long_axis_level<T>(hipStream_t, const Taps<T> &, int, const T *, int64_t, T *, int64_t, int64_t, int64_t, int, \
+                                     hipError_t *);
+WL_INST_LONG(float)
+WL_INST_LONG(double)
 
 template bool fast3d_fwd_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, float *, int64_t, int64_t,
                                       float *, const int64_t[3], float *, float *, int, hipError_t *);

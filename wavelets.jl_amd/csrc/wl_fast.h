@@ -41,6 +41,18 @@ template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
+// Long filters (12, 14, 16, 18, 20, 24 taps): one level of contiguous lines / of the strided axis of a matrix (wl_axis.hip).
+bool long_filter_ok(int F);
+template <typename T>
+bool long_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls,
+                          T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err);
+template <typename T>
+bool long_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls,
+                          T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err);
+template <typename T>
+bool long_axis_level(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t lds, T *dst, int64_t ldd,
+                     int64_t R, int64_t C, int cu_count, hipError_t *err);
+
 // 3-D lifting transform of a cube (2^k <= 512 per side) through the axis-streaming and short-line kernels.
 template <typename T>
 int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, const T *x,

@@ -1132,7 +1132,7 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
     const int wpc = env_int("WL_WAVES_PER_CU", 8);
     while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;
-    while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * 2) TJ >>= 1;
+    while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * env_int("WL_WAVES_MIN", 2)) TJ >>= 1;
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.tp = shrink<T, F>(taps);
@@ -1397,6 +1397,33 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                                                          b.full.s[1], n[0], nlines, cu_count)));
                           done = true);
             if (done && !dominant) dominant = "k_fwd1d_stream";
+        }
+        // ---- long filters (12..24 taps): line kernel with multi-lane halo, 2-D as axis pass + line pass (wl_axis.hip) ----
+        if (!done && path == 0 && long_filter_ok(F) && env_int("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1 && cur_st.s[0] == 1) {
+            hipError_t e = hipSuccess;
+            const int64_t h0 = n[0] >> 1, h1 = n[1] >> 1, ldy = b.full.s[1];
+            if (lines) {
+                T *sd = last ? y : llbuf;
+                const int64_t sls = last ? ldy : ll_st.s[1];
+                done = long_lines_fwd_level<T>(st, taps, cur, cur_st.s[1], sd, sls, y + h0, ldy, n[0], nlines, cu_count, &e);
+                WL_TRY(e);
+            } else if (two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 32) == 0 && (ldy % VEC) == 0 &&
+                       (cur_st.s[1] % VEC) == 0 && aligned16(cur) && aligned16(y) && aligned16(llbuf)) {
+                // rows (dim 2) into T0 = [s-columns | d-columns], then the columns of T0 as lines with the LL quadrant routed on
+                done = long_axis_level<T>(st, taps, 1, cur, cur_st.s[1], w.T0, n[0], n[0], n[1], cu_count, &e);
+                WL_TRY(e);
+                if (done) {
+                    T *lld = last ? y : llbuf;
+                    const int64_t ldd = last ? ldy : h0;
+                    bool ok = long_lines_fwd_level<T>(st, taps, w.T0, n[0], lld, ldd, y + h0, ldy, n[0], h1, cu_count, &e);
+                    WL_TRY(e);
+                    ok = ok && long_lines_fwd_level<T>(st, taps, w.T0 + h1 * n[0], n[0], y + h1 * ldy, ldy, y + h1 * ldy + h0, ldy, n[0], h1,
+                                                       cu_count, &e);
+                    WL_TRY(e);
+                    if (!ok) return WL_EINVAL_ARG;      // (eligibility is identical for the three launches)
+                }
+            }
+            if (done && !dominant) dominant = "k_long_lines";
         }
         // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
         if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {

@@ -808,6 +808,33 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             done = true;
             dominant = "k_inv_dim2_stream";
         }
+        // ---- long filters (12..24 taps) ----
+        if (!done && path == 0 && long_filter_ok(F) && i_env("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1) {
+            hipError_t e = hipSuccess;
+            const int64_t h0 = n[0] >> 1, h1 = n[1] >> 1, ldx = b.full.s[1];
+            if (lines) {
+                const T *ss = llsrc ? llsrc : x;
+                const int64_t sls = llsrc ? llsrc_st.s[1] : ldx;
+                done = long_lines_inv_level<T>(st, taps, ss, sls, x + h0, ldx, res, res_st.s[1], n[0], nlines, cu_count, &e);
+                WL_TRYI(e);
+            } else if (two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 32) == 0 && (ldx % VEC) == 0 &&
+                       (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) && (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % VEC) == 0))) {
+                // columns (dim 1) into T0, the approximation quadrant from the deeper reconstruction; then rows (dim 2)
+                const T *ss = llsrc ? llsrc : x;
+                const int64_t sls = llsrc ? llsrc_st.s[1] : ldx;
+                done = long_lines_inv_level<T>(st, taps, ss, sls, x + h0, ldx, w.T0, n[0], n[0], h1, cu_count, &e);
+                WL_TRYI(e);
+                if (done) {
+                    bool ok = long_lines_inv_level<T>(st, taps, x + h1 * ldx, ldx, x + h1 * ldx + h0, ldx, w.T0 + h1 * n[0], n[0], n[0], h1,
+                                                      cu_count, &e);
+                    WL_TRYI(e);
+                    ok = ok && long_axis_level<T>(st, taps, 0, w.T0, n[0], res, res_st.s[1], n[0], n[1], cu_count, &e);
+                    WL_TRYI(e);
+                    if (!ok) return WL_EINVAL_ARG;
+                }
+            }
+            if (done) dominant = "k_long_lines";
+        }
         if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
             hipError_t e3 = hipSuccess;
             done = fast3d_inv_level<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, res_st.s[1], res_st.s[2], n,

@@ -572,9 +572,11 @@ __device__ __forceinline__ void inv_column(const T (&s)[PPL], const T (&d)[PPL],
     if constexpr (SH >= 1) { constexpr int rel = 1, nb = (rel + PPL - 1) / PPL; sx[SH - 1] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
     if constexpr (SH >= 2) { constexpr int rel = 2, nb = (rel + PPL - 1) / PPL; sx[SH - 2] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
     if constexpr (SH >= 3) { constexpr int rel = 3, nb = (rel + PPL - 1) / PPL; sx[SH - 3] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
+    if constexpr (SH >= 4) { constexpr int rel = 4, nb = (rel + PPL - 1) / PPL; sx[SH - 4] = i_prev_n<T, nb>(s[nb * PPL - rel]); }
     if constexpr (SH >= 1) { constexpr int rel = PPL + 0, nb = rel / PPL; dx[PPL + 0] = i_next_n<T, nb>(d[rel - nb * PPL]); }
     if constexpr (SH >= 2) { constexpr int rel = PPL + 1, nb = rel / PPL; dx[PPL + 1] = i_next_n<T, nb>(d[rel - nb * PPL]); }
     if constexpr (SH >= 3) { constexpr int rel = PPL + 2, nb = rel / PPL; dx[PPL + 2] = i_next_n<T, nb>(d[rel - nb * PPL]); }
+    if constexpr (SH >= 4) { constexpr int rel = PPL + 3, nb = rel / PPL; dx[PPL + 3] = i_next_n<T, nb>(d[rel - nb * PPL]); }
 #pragma unroll
     for (int p = 0; p < PPL; ++p) inv_pair<T, F>(&sx[p], &dx[p], tp, out[2 * p], out[2 * p + 1]);
 }
@@ -582,8 +584,8 @@ __device__ __forceinline__ void inv_column(const T (&s)[PPL], const T (&d)[PPL],
 template <typename T, int F, int PPL>
 __global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
 {
-    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL, R = 4;
-    static_assert(SH <= 3, "ring depth");
+    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL, R = (SH <= 3) ? 4 : 8;
+    static_assert(SH <= 4, "ring depth");
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
@@ -762,8 +764,8 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             if (done) dominant = "k_inv1d_stream";
         }
         // ---- fused 2-D level: one pass over HBM ----
-        if (!done && fastF && F <= 8 && two_d && i_env("WL_NO_INV2D", 0) == 0 && n[0] >= 128 && (n[0] % 8) == 0 && n[1] >= 16 &&
-            (n[1] % 8) == 0 && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
+        if (!done && fastF && two_d && i_env("WL_NO_INV2D", 0) == 0 && n[0] >= 128 && (n[0] % 8) == 0 && n[1] >= 16 &&
+            (n[1] % 8) == 0 && (F < 10 || (n[1] % 16) == 0) && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
             (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
             // pairs per lane: 2 (8-byte loads / 16-byte stores for f32) from 256 rows, 1 below; 4 is a tuning option for f32
             int ppl = i_env("WL_INV2D_PPL", 2);
@@ -771,16 +773,16 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             else if (n[0] < 512 || sizeof(T) != 4 || ppl != 4) ppl = 2;
             if (ppl == 4) {
                 if constexpr (sizeof(T) == 4) {
-                    WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 4>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                    WL_DISPATCH_FI(F, WL_TRYI((launch_inv2d<T, FF, 4>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
                                                                        n[0], n[1], cu_count)));
                                     done = true);
                 }
             } else if (ppl == 2) {
-                WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 2>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                WL_DISPATCH_FI(F, WL_TRYI((launch_inv2d<T, FF, 2>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
                                                                    n[0], n[1], cu_count)));
                                 done = true);
             } else {
-                WL_DISPATCH_FI8(F, WL_TRYI((launch_inv2d<T, FF, 1>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
+                WL_DISPATCH_FI(F, WL_TRYI((launch_inv2d<T, FF, 1>(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res, res_st.s[1],
                                                                    n[0], n[1], cu_count)));
                                 done = true);
             }

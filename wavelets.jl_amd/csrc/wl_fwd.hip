@@ -12,6 +12,10 @@
 //                   barrier and no LDS traffic at all.  The detail column computed from a
 //                   window is d[k+(F-2)/2] (same F inputs as s[k]), which halves the halo.
 //                   HBM traffic: each level's block is read once and written once.
+//   k_fwd2d_stream2 TWO 2-D levels per launch (blocks >= 4096^2, Float32): the level-l approximation stays in an
+//                   8-slot register ring and level l+1 runs on it every second step (see the kernel).
+//   k_fwd1d_multi   up to 4 fused 1-D levels per pass over HBM through LDS tiles (lines, batched columns);
+//   k_fwd2d_multi   two 2-D levels of a small (<= 128^2) block per launch (LDS tiles with recomputed halo).
 //   k_fwd1d_stream  1-D level (also one line per blockIdx.y: batched columns / WPT segments):
 //                   8 samples per lane, halo from the two neighbouring lanes by shuffle.
 //   k_tail_fwd      all remaining levels of a small block (<= 16 Ki f32 / 8 Ki f64 elements) in
@@ -19,7 +23,8 @@
 //                   lines shorter than the filter are handled) -- removes ~2 launches per level
 //                   for the deep levels of a full-depth transform.
 //
-// All three evaluate the closed forms of wl_internal.h in the reference's summation order
+// Long filters (12..24 taps) and 3-D levels: wl_axis.hip.
+// All of them evaluate the closed forms of wl_internal.h in the reference's summation order
 // with separate multiply/add roundings: results are bit-identical to the generic kernels.
 #include "wl_fast.h"
 

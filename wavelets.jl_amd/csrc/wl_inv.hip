@@ -5,11 +5,12 @@
 //                      holds 4 approximation + 4 detail coefficients (two 16-byte loads), takes the
 //                      (F-2)/2 neighbouring coefficients from the adjacent lanes by DPP and stores 8
 //                      reconstructed samples (two 16-byte stores).
-//   k_inv_dim2_stream  the dim-2 pass of a 2-D inverse level: a wave owns 256 rows (4 per lane, 16-byte
-//                      loads/stores coalesced along dim 1) and marches along dim 2 with two 8-slot
-//                      register rings (approximation columns p-(F-2)/2..p, detail columns p..p+(F-2)/2);
-//                      no cross-lane traffic at all.
-// Levels too small for the streaming kernels use the generic kernels (wl_generic.hip).
+//   k_inv2d_stream     one whole 2-D inverse level (dim-1 + dim-2 reconstruction) in a single pass over HBM:
+//                      the default for 2-D blocks of >= 128 rows (see the comment at the kernel).
+//   k_inv_dim2_stream  the dim-2 pass alone (fallback when the fused kernel's shape conditions do not hold): a
+//                      wave owns 256 rows and marches along dim 2 with two 8-slot register rings.
+//   k_tail_inv         the deepest levels (<= 4096 elements) inside one workgroup, coefficients staged to LDS once.
+// Long filters and 3-D levels: wl_axis.hip.  Everything else: the generic kernels (wl_generic.hip).
 // Arithmetic = the closed form of filtup! (wl_internal.h): x[o] = S + D with
 //   S = sum over m descending, (o-m) even, of h[m]*s[(o-m)/2];  D = sum over m ascending, (o+m-1) even, of g[m]*d[(o+m-1)/2]
 #include "wl_fast.h"
@@ -683,15 +684,6 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
     case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
     case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
     case 10: { constexpr int FF = 10; __VA_ARGS__; } break;  \
-    default: break;                                          \
-    }
-
-#define WL_DISPATCH_FI8(F_, ...)                             \
-    switch (F_) {                                            \
-    case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
-    case 4: { constexpr int FF = 4; __VA_ARGS__; } break;    \
-    case 6: { constexpr int FF = 6; __VA_ARGS__; } break;    \
-    case 8: { constexpr int FF = 8; __VA_ARGS__; } break;    \
     default: break;                                          \
     }
 

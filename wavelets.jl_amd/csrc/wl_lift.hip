@@ -10,6 +10,8 @@
 //                    One read + one write of the level: 8 B/sample (f32).
 //   k_tail_lift      every remaining level of a line <= 16 Ki f32 / 8 Ki f64 samples inside one
 //                    workgroup with the line in LDS (any scheme, true periodic indexing).
+//   k_lift_axis_stream   one lifting level along a strided axis (dim 2 / dim 3 of square and cubic arrays) as a
+//                    register cascade; k_lift_short_lines: the dim-1 pass for lines of 2..512 samples.
 //
 // Rounding follows the reference exactly: an element whose operands do not wrap is updated as
 // x += (c1*a + c2*b [+ c3*c]) (lift_inbounds!, transforms_lifting.jl:455-483), a wrapped one as
@@ -669,32 +671,6 @@ template int lifting_lines_fast<float>(void *, int, hipStream_t, int64_t, int64_
                                        const LiftScheme<float> &, int, int, int *, const char **, int *);
 template int lifting_lines_fast<double>(void *, int, hipStream_t, int64_t, int64_t, int64_t, double *, const double *,
                                         const LiftScheme<double> &, int, int, int *, const char **, int *);
-
-// --------------------------------------------------------------------------------------------------
-// 2-D lifting (square arrays): each level is the reference's two passes -- rows (dim 2) then columns
-// (dim 1) forward, the reverse inverse (transforms_lifting.jl:158-189) -- with every pass executed
-// by the fused LINE kernel: the strided dim-2 pass becomes contiguous lines after a tiled LDS
-// transpose (same arithmetic per line => same bits).  4 streaming passes per level instead of the
-// generic path's ~14 strided ones.  Levels smaller than 512 fall back to the generic kernels.
-template <typename T>
-__global__ void __launch_bounds__(256) k_transpose(const T *__restrict__ src, int64_t lds, T *__restrict__ dst, int64_t ldd)
-{
-    __shared__ T tile[64][65];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[(i0 + tx) + (j0 + r) * lds];       // tile[j][i]
-    __syncthreads();
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) dst[(j0 + tx) + (i0 + r) * ldd] = tile[tx][r];       // dst[j + i*ldd]
-}
-
-template <typename T>
-static hipError_t launch_transpose(hipStream_t st, const T *src, int64_t lds, T *dst, int64_t ldd, int64_t n)
-{
-    hipLaunchKernelGGL((k_transpose<T>), dim3((unsigned)(n / 64), (unsigned)(n / 64)), dim3(256), 0, st, src, lds, dst, ldd);
-    return hipGetLastError();
-}
 
 template <typename T, int N>
 __device__ __forceinline__ void ldv_l(const T *p, T (&v)[N])

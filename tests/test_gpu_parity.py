@@ -575,3 +575,16 @@ def test_full_size_properties(gpu, W, oracle):
     yu = W.dwt(u.to(gpu), w2)
     assert np.array_equal(W.to_host(yu), oracle.dwt_filter(u.numpy(), w2.qmf))
     assert float(torch.linalg.vector_norm(W.idwt(yu, w2).cpu() - u)) / float(torch.linalg.vector_norm(u)) < 1e-12
+
+
+def test_differential_fuzz(gpu, W, oracle):
+    """150 random (shape, wavelet, depth, element type, entry point) cases of tools/fuzz_parity.py, bit for bit."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    r = np.random.default_rng(20260926)
+    kernels = set()
+    for _ in range(150):
+        kernels.update(fz.one_case(r))
+    assert len(kernels) >= 10, kernels          # the draw must actually spread over the kernel families

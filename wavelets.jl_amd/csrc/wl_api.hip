@@ -442,20 +442,39 @@ int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y, int64_t len, int64_t nsigna
 // every segment whose node bit is set gets one [s ; d] level.  Here one depth = one launch over
 // the box (n/2^d, 2^d) with the node bits as a per-segment mask (unset segments are copied
 // through), ping-ponging between y and a work buffer so that the last launch lands in y.
-static bool isvalidtree(int64_t n, const uint8_t *b, int64_t nb)
+// index of the last set node (-1: none); the tail of a tree vector is normally one long run of zeros
+static int64_t last_set_node(const uint8_t *b, int64_t nb)
+{
+    int64_t i = nb;
+    while (i > 0 && (reinterpret_cast<uintptr_t>(b + i) & 7) != 0) { if (b[i - 1]) return i - 1; --i; }
+    while (i >= 64) {                                   // 64 bytes per iteration, independent loads
+        uint64_t w[8];
+        std::memcpy(w, b + i - 64, 64);
+        if ((w[0] | w[1] | w[2] | w[3]) | (w[4] | w[5] | w[6] | w[7])) break;
+        i -= 64;
+    }
+    while (i > 0) { if (b[i - 1]) return i - 1; --i; }
+    return -1;
+}
+// isvalidtree (util_main.jl:301-314): the length matches and no node is set below an unset node.  Equivalent
+// statement checked here: every set node other than the root has its parent set -- O(last set node), not O(2^ns).
+static bool isvalidtree(int64_t n, const uint8_t *b, int64_t nb, int64_t *last_set)
 {
     int ns = wl_maxtransformlevels(n);
+    *last_set = -1;
     if (nb != ((int64_t)1 << ns) - 1) return false;
     if (ns == 0) return true;
-    for (int64_t i = 1; i <= ((int64_t)1 << (ns - 1)) - 1; ++i)
-        if (!b[i - 1] && (b[(i << 1) - 1] || b[i << 1])) return false;
+    const int64_t hi = last_set_node(b, nb);
+    *last_set = hi;
+    for (int64_t j = 1; j <= hi; ++j)
+        if (b[j] && !b[(j - 1) >> 1]) return false;
     return true;
 }
 
 template <typename T>
 static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
                     const Taps<T> *taps, const LiftScheme<T> *sc,
-                    const uint8_t *tree, int64_t ntree, int fw)
+                    const uint8_t *tree, int64_t ntree, int64_t last_set, int fw)
 {
     const bool lifting = (sc != nullptr);
     Extent3 full = {{n, 1, 1}};
@@ -465,11 +484,15 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
         ctx->last_kernel = "copy";
         return WL_OK;
     }
-    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)ntree + 256);
+    // only the nodes up to the last set one are ever looked at on the device (whole depths: round up to 2^(d+1) - 1)
+    int64_t ncopy = 1;
+    while (ncopy - 1 <= last_set && ncopy - 1 < ntree) ncopy <<= 1;
+    ncopy = (ncopy - 1 < ntree) ? ncopy - 1 : ntree;
+    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)ncopy + 256);
     if (rc) return rc;
     Work<T> w = carve<T>(ctx->ws, n);
     uint8_t *dtree = (uint8_t *)ctx->ws + ws_elems(n) * sizeof(T);
-    WL_HIP(ctx, hipMemcpyAsync(dtree, tree, (size_t)ntree, hipMemcpyHostToDevice, st));
+    WL_HIP(ctx, hipMemcpyAsync(dtree, tree, (size_t)ncopy, hipMemcpyHostToDevice, st));
 
     const int Lmax = wl_maxtransformlevels(n);
     // depths in processing order, skipping depths where no node is set (pure copy-through)
@@ -478,7 +501,8 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
         int d = fw ? Lmax - L : L - 1;
         int64_t first = ((int64_t)1 << d) - 1, cnt = (int64_t)1 << d;
         bool any = false;
-        for (int64_t k = 0; k < cnt && !any; ++k) any = tree[first + k] != 0;
+        if (first <= last_set)
+            for (int64_t k = 0; k < cnt && !any; ++k) any = tree[first + k] != 0;
         if (any) depths.push_back(d);
     }
     const int K = (int)depths.size();
@@ -538,15 +562,16 @@ int wl_wpt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n, con
     if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
     if (n < 1) return WL_EDIMS;
     if (y == x) return WL_EALIAS;
-    if (!isvalidtree(n, tree, ntree)) return WL_EINVAL_TREE;
+    int64_t last_set = -1;
+    if (!isvalidtree(n, tree, ntree, &last_set)) return WL_EINVAL_TREE;
     WL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WL_F32) {
         Taps<float> t; make_taps<float>(qmf, flen, t);
-        return wpt_impl<float>(ctx, st, (float *)y, (const float *)x, n, &t, nullptr, tree, ntree, fw);
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)x, n, &t, nullptr, tree, ntree, last_set, fw);
     }
     Taps<double> t; make_taps<double>(qmf, flen, t);
-    return wpt_impl<double>(ctx, st, (double *)y, (const double *)x, n, &t, nullptr, tree, ntree, fw);
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)x, n, &t, nullptr, tree, ntree, last_set, fw);
 }
 
 int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
@@ -557,19 +582,20 @@ int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
     if (!ctx || !y || (!tree && ntree > 0)) return WL_EINVAL_ARG;
     if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
     if (n < 1) return WL_EDIMS;
-    if (!isvalidtree(n, tree, ntree)) return WL_EINVAL_TREE;
+    int64_t last_set = -1;
+    if (!isvalidtree(n, tree, ntree, &last_set)) return WL_EINVAL_TREE;
     WL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WL_F32) {
         LiftScheme<float> sc;
         int rc = make_scheme<float>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
         if (rc) return rc;
-        return wpt_impl<float>(ctx, st, (float *)y, (const float *)y, n, nullptr, &sc, tree, ntree, fw);
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)y, n, nullptr, &sc, tree, ntree, last_set, fw);
     }
     LiftScheme<double> sc;
     int rc = make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
     if (rc) return rc;
-    return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, tree, ntree, fw);
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, tree, ntree, last_set, fw);
 }
 
 }  // extern "C"

@@ -353,7 +353,10 @@ def _tree_arg(n, tree_or_L):
         return Util.maketree(n, Util.maxtransformlevels(n), "full")
     if isinstance(tree_or_L, (int, np.integer)):
         return Util.maketree(n, int(tree_or_L), "full")
-    return np.ascontiguousarray(np.asarray(tree_or_L).astype(np.uint8))
+    t = np.asarray(tree_or_L)
+    if t.dtype == np.bool_:
+        t = t.view(np.uint8)                 # BitVector -> one byte per node, no copy
+    return np.ascontiguousarray(t, dtype=np.uint8)
 
 
 def _wpt_filter_call(y, x, filt, tree, fw):

@@ -220,6 +220,9 @@ struct ShortArgs {
     const T *b; int64_t b2, b3;      // fw: unused       inv: detail source
     T *o0; int64_t o02, o03;         // fw: s dest       inv: dst
     T *o1; int64_t o12, o13;         // fw: d dest       inv: unused
+    // low-low corner (lines with i2 < l2 and i3 < l3): fw: their s goes to ll instead of o0; inv: their approximation
+    // comes from ll instead of a.  ll == nullptr: no redirection.
+    T *ll; int64_t ll2, ll3; int l2; int64_t l3;
     int n;                           // line length: 8*G, G | 64
     int G, c2;
     int64_t nlines;                  // c2 * c3
@@ -239,6 +242,7 @@ __global__ void __launch_bounds__(256) k_short_lines(ShortArgs<T, F> a)
     const int64_t lc = valid ? li : 0;
     const int64_t i3 = lc / a.c2, i2 = lc - i3 * a.c2;
     const int nxt = g * G + (r + 1 == G ? 0 : r + 1), prv = g * G + (r == 0 ? G - 1 : r - 1);
+    const bool corner = a.ll != nullptr && i2 < a.l2 && i3 < a.l3;
     if (FW) {
         T v[8];
         a_ld<T, 8>(a.a + i2 * a.a2 + i3 * a.a3 + 8 * r, v);
@@ -264,12 +268,12 @@ __global__ void __launch_bounds__(256) k_short_lines(ShortArgs<T, F> a)
             dO[q] = d;
         }
         if (valid) {
-            a_st<T, 4>(a.o0 + i2 * a.o02 + i3 * a.o03 + 4 * r, so);
+            a_st<T, 4>((corner ? a.ll + i2 * a.ll2 + i3 * a.ll3 : a.o0 + i2 * a.o02 + i3 * a.o03) + 4 * r, so);
             a_st<T, 4>(a.o1 + i2 * a.o12 + i3 * a.o13 + 4 * r, dO);
         }
     } else {
         T s[4], d[4];
-        a_ld<T, 4>(a.a + i2 * a.a2 + i3 * a.a3 + 4 * r, s);
+        a_ld<T, 4>((corner ? a.ll + i2 * a.ll2 + i3 * a.ll3 : a.a + i2 * a.a2 + i3 * a.a3) + 4 * r, s);
         a_ld<T, 4>(a.b + i2 * a.b2 + i3 * a.b3 + 4 * r, d);
         T sx[4 + SH], dx[4 + SH];
 #pragma unroll
@@ -461,17 +465,14 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
         *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, n0 * n1, 0, n0 * n1, n2, 1, cu_count);
         // rows: axis 2 on n2 matrices of n0 x n1
         if (*err == hipSuccess) *err = launch_axis<T, FF, 1>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
-        // columns: short lines, four (i2, i3) quadrants; only the low-low one sends its approximation to ll
-        for (int q3 = 0; q3 < 2 && *err == hipSuccess; ++q3)
-            for (int q2 = 0; q2 < 2 && *err == hipSuccess; ++q2) {
-                ShortArgs<T, FF> s;
-                const int64_t o2 = q2 * h1, o3 = q3 * h2;
-                s.a = T1 + o2 * n0 + o3 * n0 * n1; s.a2 = n0; s.a3 = n0 * n1; s.b = nullptr; s.b2 = s.b3 = 0;
-                if (q2 == 0 && q3 == 0 && ll) { s.o0 = ll; s.o02 = h0; s.o03 = h0 * h1; }
-                else { s.o0 = y + o2 * y1 + o3 * y2; s.o02 = y1; s.o03 = y2; }
-                s.o1 = y + h0 + o2 * y1 + o3 * y2; s.o12 = y1; s.o13 = y2;
-                *err = launch_short<T, FF, 1>(st, taps, s, (int)n0, (int)h1, h2);
-            }
+        // columns: short lines; the low-low corner sends its approximation to ll
+        if (*err == hipSuccess) {
+            ShortArgs<T, FF> s;
+            s.a = T1; s.a2 = n0; s.a3 = n0 * n1; s.b = nullptr; s.b2 = s.b3 = 0;
+            s.o0 = y; s.o02 = y1; s.o03 = y2; s.o1 = y + h0; s.o12 = y1; s.o13 = y2;
+            s.ll = ll; s.ll2 = h0; s.ll3 = h0 * h1; s.l2 = (int)h1; s.l3 = h2;
+            *err = launch_short<T, FF, 1>(st, taps, s, (int)n0, (int)n1, n2);
+        }
         ok = true;
     });
     return ok;
@@ -493,17 +494,15 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
         return false;
     bool ok = false;
     WL_DISPATCH_FA(F, {
-        // columns first (transforms_filter.jl:269-273): merged lines into T0 (dense box)
-        for (int q3 = 0; q3 < 2 && *err == hipSuccess; ++q3)
-            for (int q2 = 0; q2 < 2 && *err == hipSuccess; ++q2) {
-                ShortArgs<T, FF> s;
-                const int64_t p2 = q2 * h1, p3 = q3 * h2;
-                if (q2 == 0 && q3 == 0 && llsrc) { s.a = llsrc; s.a2 = h0; s.a3 = h0 * h1; }
-                else { s.a = x + p2 * x1 + p3 * x2; s.a2 = x1; s.a3 = x2; }
-                s.b = x + h0 + p2 * x1 + p3 * x2; s.b2 = x1; s.b3 = x2;
-                s.o0 = T0 + p2 * n0 + p3 * n0 * n1; s.o02 = n0; s.o03 = n0 * n1; s.o1 = nullptr; s.o12 = s.o13 = 0;
-                *err = launch_short<T, FF, 0>(st, taps, s, (int)n0, (int)h1, h2);
-            }
+        // columns first (transforms_filter.jl:269-273): merged lines into T0 (dense box); the low-low corner takes its
+        // approximation from the deeper reconstruction
+        {
+            ShortArgs<T, FF> s;
+            s.a = x; s.a2 = x1; s.a3 = x2; s.b = x + h0; s.b2 = x1; s.b3 = x2;
+            s.o0 = T0; s.o02 = n0; s.o03 = n0 * n1; s.o1 = nullptr; s.o12 = s.o13 = 0;
+            s.ll = const_cast<T *>(llsrc); s.ll2 = h0; s.ll3 = h0 * h1; s.l2 = (int)h1; s.l3 = h2;
+            *err = launch_short<T, FF, 0>(st, taps, s, (int)n0, (int)n1, n2);
+        }
         // rows: axis 2 on n2 matrices
         if (*err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
         // planes: axis 3

@@ -905,6 +905,8 @@ struct LiftShortArgs {
     const T *b; int64_t b2, b3;      // fw: unused       inv: detail source
     T *o0; int64_t o02, o03;         // fw: s dest       inv: dst
     T *o1; int64_t o12, o13;         // fw: d dest       inv: unused
+    // low-low corner (i2 < l2, i3 < l3): fw: s goes to ll instead of o0; inv: the approximation comes from ll
+    T *ll; int64_t ll2, ll3; int l2; int64_t l3;
     int n, G, c2;
     int64_t nlines;
     T c[WL_MAX_STEPS][WL_MAX_NCOEF];
@@ -924,6 +926,7 @@ __global__ void __launch_bounds__(256) k_lift_short_lines(LiftShortArgs<T> a)
     const int64_t lc = valid ? li : 0;
     const int64_t i3 = lc / a.c2, i2 = lc - i3 * a.c2;
     const int64_t half = a.n >> 1;
+    const bool corner = a.ll != nullptr && i2 < a.l2 && i3 < a.l3;
     T s[PPL], d[PPL];
     if (FW) {
         T v[2 * PPL];
@@ -932,7 +935,7 @@ __global__ void __launch_bounds__(256) k_lift_short_lines(LiftShortArgs<T> a)
         for (int j = 0; j < PPL; ++j) { s[j] = v[2 * j]; d[j] = v[2 * j + 1]; }                 // Util.split!
     } else {
         T sv[PPL], dv[PPL];
-        ldv_l<T, PPL>(a.a + i2 * a.a2 + i3 * a.a3 + PPL * r, sv);
+        ldv_l<T, PPL>((corner ? a.ll + i2 * a.ll2 + i3 * a.ll3 : a.a + i2 * a.a2 + i3 * a.a3) + PPL * r, sv);
         ldv_l<T, PPL>(a.b + i2 * a.b2 + i3 * a.b3 + PPL * r, dv);
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { s[j] = a.norm1 * sv[j]; d[j] = a.norm2 * dv[j]; }       // normalize! (inverse first)
@@ -979,7 +982,7 @@ __global__ void __launch_bounds__(256) k_lift_short_lines(LiftShortArgs<T> a)
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { so[j] = s[j] * a.norm1; dO[j] = d[j] * a.norm2; }        // normalize!
         if (valid) {
-            stv_l<T, PPL>(a.o0 + i2 * a.o02 + i3 * a.o03 + PPL * r, so);
+            stv_l<T, PPL>((corner ? a.ll + i2 * a.ll2 + i3 * a.ll3 : a.o0 + i2 * a.o02 + i3 * a.o03) + PPL * r, so);
             stv_l<T, PPL>(a.o1 + i2 * a.o12 + i3 * a.o13 + PPL * r, dO);
         }
     } else {
@@ -1088,11 +1091,11 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     a.a = w.T0 + h * n; a.o0 = y + h * ldy; a.o0_ls = ldy; a.o1 = y + h * ldy + h; a.o1_ls = ldy;
                     launch_lines_id<T, 1>(id, st, a, h, cu_count); WL_EL();
                 } else {
-                    sa.b = nullptr; sa.b2 = sa.b3 = 0; sa.a3 = sa.o03 = sa.o13 = 0;
-                    sa.a = w.T0; sa.a2 = n; sa.o0 = lld; sa.o02 = ldd; sa.o1 = y + h; sa.o12 = ldy;
-                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, 1)));
-                    sa.a = w.T0 + h * n; sa.o0 = y + h * ldy; sa.o02 = ldy; sa.o1 = y + h * ldy + h; sa.o12 = ldy;
-                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, 1)));
+                    // every column of T0 in one launch; columns [0, h) send their approximation to the next level's buffer
+                    sa.b = nullptr; sa.b2 = sa.b3 = 0; sa.a3 = sa.o03 = sa.o13 = sa.ll3 = 0;
+                    sa.a = w.T0; sa.a2 = n; sa.o0 = y; sa.o02 = ldy; sa.o1 = y + h; sa.o12 = ldy;
+                    sa.ll = last ? (T *)nullptr : llbuf; sa.ll2 = h; sa.l2 = (int)h; sa.l3 = 1;
+                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)n, 1)));
                 }
             } else {
                 Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
@@ -1126,13 +1129,10 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     a.a = x + h * ldy; a.a_ls = ldy; a.b = x + h * ldy + h; a.b_ls = ldy; a.o0 = w.T0 + h * n;
                     launch_lines_id<T, 0>(id, st, a, h, cu_count); WL_EL();
                 } else {
-                    sa.o1 = nullptr; sa.o12 = sa.o13 = 0; sa.a3 = sa.b3 = sa.o03 = 0;
-                    sa.o0 = w.T0; sa.o02 = n;
-                    if (llsrc) { sa.a = llsrc; sa.a2 = ll_ls; } else { sa.a = x; sa.a2 = ldy; }
-                    sa.b = x + h; sa.b2 = ldy;
-                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, 1)));
-                    sa.a = x + h * ldy; sa.a2 = ldy; sa.b = x + h * ldy + h; sa.b2 = ldy; sa.o0 = w.T0 + h * n;
-                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, 1)));
+                    sa.o1 = nullptr; sa.o12 = sa.o13 = 0; sa.a3 = sa.b3 = sa.o03 = sa.ll3 = 0;
+                    sa.o0 = w.T0; sa.o02 = n; sa.a = x; sa.a2 = ldy; sa.b = x + h; sa.b2 = ldy;
+                    sa.ll = const_cast<T *>(llsrc); sa.ll2 = ll_ls; sa.l2 = (int)h; sa.l3 = 1;
+                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)n, 1)));
                 }
                 // rows (dim 2): streaming pass along the strided axis straight into the result
                 ax.src = w.T0; ax.lds = n; ax.bs_src = 0; ax.dst = out; ax.ldd = ldo; ax.bs_dst = 0; ax.R = n; ax.C = n;
@@ -1196,17 +1196,12 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
             // rows (dim 2): n matrices of n x n
             ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
             WL_E((launch_lift_axis_id<T, 1>(id, st, ax, n, cu_count)));
-            // columns (dim 1): four (i2, i3) quadrants; only the low-low one sends its approximation on
+            // columns (dim 1): the low-low corner sends its approximation on to the next level's buffer
             sa.b = nullptr; sa.b2 = sa.b3 = 0;
-            for (int q3 = 0; q3 < 2; ++q3)
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int64_t o2 = q2 * h, o3 = q3 * h;
-                    sa.a = w.T1 + o2 * n + o3 * n * n; sa.a2 = n; sa.a3 = n * n;
-                    if (q2 == 0 && q3 == 0 && !last) { sa.o0 = llbuf; sa.o02 = h; sa.o03 = h * h; }
-                    else { sa.o0 = y + o2 * y1 + o3 * y2; sa.o02 = y1; sa.o03 = y2; }
-                    sa.o1 = y + h + o2 * y1 + o3 * y2; sa.o12 = y1; sa.o13 = y2;
-                    WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)h, h)));
-                }
+            sa.a = w.T1; sa.a2 = n; sa.a3 = n * n;
+            sa.o0 = y; sa.o02 = y1; sa.o03 = y2; sa.o1 = y + h; sa.o12 = y1; sa.o13 = y2;
+            sa.ll = last ? (T *)nullptr : llbuf; sa.ll2 = h; sa.ll3 = h * h; sa.l2 = (int)h; sa.l3 = h;
+            WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)n, n)));
             cur = llbuf; c1 = h; c2 = h * h; pp ^= 1;
         }
     } else {
@@ -1215,17 +1210,12 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
         for (int l = L; l >= 1; --l) {
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
-            // columns first: merged lines into T0 (dense n^3)
+            // columns first: merged lines into T0 (dense n^3); the low-low corner reads the deeper reconstruction
             sa.o1 = nullptr; sa.o12 = sa.o13 = 0;
-            for (int q3 = 0; q3 < 2; ++q3)
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int64_t p2 = q2 * h, p3 = q3 * h;
-                    if (q2 == 0 && q3 == 0 && llsrc) { sa.a = llsrc; sa.a2 = h; sa.a3 = h * h; }
-                    else { sa.a = x + p2 * y1 + p3 * y2; sa.a2 = y1; sa.a3 = y2; }
-                    sa.b = x + h + p2 * y1 + p3 * y2; sa.b2 = y1; sa.b3 = y2;
-                    sa.o0 = w.T0 + p2 * n + p3 * n * n; sa.o02 = n; sa.o03 = n * n;
-                    WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)h, h)));
-                }
+            sa.a = x; sa.a2 = y1; sa.a3 = y2; sa.b = x + h; sa.b2 = y1; sa.b3 = y2;
+            sa.o0 = w.T0; sa.o02 = n; sa.o03 = n * n;
+            sa.ll = const_cast<T *>(llsrc); sa.ll2 = h; sa.ll3 = h * h; sa.l2 = (int)h; sa.l3 = h;
+            WL_E((launch_lift_short_id<T, 0>(id, st, sa, (int)n, (int)n, n)));
             // rows (dim 2)
             ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
             WL_E((launch_lift_axis_id<T, 0>(id, st, ax, n, cu_count)));

@@ -446,6 +446,204 @@ __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftSchem
 }
 
 // --------------------------------------------------------------------------------------------------
+// LDS tail for SQUARE 2-D blocks (n0 <= 64): every remaining level of the 2-D lifting transform inside one workgroup
+// (any scheme).  Forward: per level rows (dim 2) then columns (dim 1), each as split -> steps -> normalize on all
+// lines at once; inverse: the coefficient corner is staged once, per level columns then rows.  W holds the lines
+// of the current pass contiguously ([s ; d] per line) so the step loops are conflict-free.
+template <typename T>
+struct LiftTail2DArgs {
+    const T *src; int64_t lds;      // fw: block to transform; inv: coefficient array (its n0 x n0 corner)
+    T *y; int64_t ldy;              // fw: coefficient array; inv: reconstruction of the shallowest level done here
+    int n0;                         // fw: block size; inv: OUTPUT size of the shallowest level done here
+    int nlev;
+    int ld;                         // LDS leading dimension (n0 | 1)
+    int cap;                        // elements per LDS buffer
+};
+
+// e -> (e / d, e % d) without the emulated integer division when d is a power of two (the usual case)
+__device__ __forceinline__ void l_split_idx(int e, int d, int &q, int &r)
+{
+    if ((d & (d - 1)) == 0) { const int lg = 31 - __clz(d); q = e >> lg; r = e & (d - 1); }
+    else { q = e / d; r = e - q * d; }
+}
+
+// all lifting steps on `nlines` lines of [s(half) ; d(half)] stored contiguously in w (line l at w + l*2*half)
+template <typename T>
+__device__ __forceinline__ void tail_lift_steps_lines(T *w, int half, int nlines, const LiftScheme<T> &sc, int tid, int nthr, bool multi)
+{
+    const int m = 2 * half;
+    for (int st = 0; st < sc.nsteps; ++st) {
+        const LiftStep<T> &sp = sc.step[st];
+        const int nc = sp.nc, shift = sp.shift, toff = sp.is_update ? half : 0, ooff = sp.is_update ? 0 : half;
+        const T c0 = sp.c[0], c1 = sp.c[1], c2 = sp.c[2];
+        for (int e = tid; e < half * nlines; e += nthr) {
+            int l, j;
+            l_split_idx(e, half, l, j);
+            T *tgt = w + l * m + toff;
+            const T *op = w + l * m + ooff;
+            const int j0 = j - shift;
+            const bool inb = (j0 >= 0) && (j0 + nc - 1 <= half - 1);
+            T x = tgt[j];
+            if (inb) {
+                T acc = c0 * op[j0];
+                if (nc > 1) acc = acc + c1 * op[j0 + 1];
+                if (nc > 2) acc = acc + c2 * op[j0 + 2];
+                x = x + acc;
+            } else {
+                for (int k = 0; k < nc; ++k) {
+                    int i = j0 + k;
+                    while (i < 0) i += half;
+                    while (i >= half) i -= half;
+                    x = x + (k == 0 ? c0 : (k == 1 ? c1 : c2)) * op[i];
+                }
+            }
+            tgt[j] = x;
+        }
+        tail_sync(multi);
+    }
+}
+
+template <typename T, int FW>
+__global__ void __launch_bounds__(1024) k_tail_lift2d(LiftTail2DArgs<T> a, LiftScheme<T> sc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);       // the block (leading dimension ld)
+    T *W = P + a.cap;                             // work lines
+    T *Q = W + a.cap;                             // inverse only: columns-pass result
+    const int tid = threadIdx.x;
+    int nthr = blockDim.x;
+    bool multi = nthr > 64;
+    const int ld = a.ld;
+    for (int e = tid; e < a.n0 * a.n0; e += nthr) {
+        int j, i;
+        l_split_idx(e, a.n0, j, i);
+        P[i + j * ld] = a.src[i + (int64_t)j * a.lds];
+    }
+    tail_sync_vm(multi);
+    if (FW) {
+        int m = a.n0;
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int h = m >> 1;
+            const bool last = (lev == a.nlev - 1);
+            if (multi && m * m <= 256) {              // hand the rest to wave 0
+                if (tid >= 64) return;
+                multi = false; nthr = 64;
+            }
+            // rows (dim 2): line = row i, W[i*m + p] = P[i, 2p], W[i*m + h + p] = P[i, 2p+1]
+            for (int e = tid; e < m * h; e += nthr) {
+                int p, i;
+                l_split_idx(e, m, p, i);
+                W[i * m + p] = P[i + (2 * p) * ld];
+                W[i * m + h + p] = P[i + (2 * p + 1) * ld];
+            }
+            tail_sync(multi);
+            tail_lift_steps_lines<T>(W, h, m, sc, tid, nthr, multi);
+            for (int e = tid; e < m * h; e += nthr) {
+                int p, i;
+                l_split_idx(e, m, p, i);
+                P[i + p * ld] = W[i * m + p] * sc.norm1;
+                P[i + (h + p) * ld] = W[i * m + h + p] * sc.norm2;
+            }
+            tail_sync(multi);
+            // columns (dim 1): line = column j, W[j*m + p] = P[2p, j], W[j*m + h + p] = P[2p+1, j]
+            for (int e = tid; e < m * h; e += nthr) {
+                int j, p;
+                l_split_idx(e, h, j, p);
+                W[j * m + p] = P[2 * p + j * ld];
+                W[j * m + h + p] = P[2 * p + 1 + j * ld];
+            }
+            tail_sync(multi);
+            tail_lift_steps_lines<T>(W, h, m, sc, tid, nthr, multi);
+            for (int e = tid; e < m * h; e += nthr) {
+                int j, p;
+                l_split_idx(e, h, j, p);
+                const T sv = W[j * m + p] * sc.norm1, dv = W[j * m + h + p] * sc.norm2;
+                a.y[h + p + (int64_t)j * a.ldy] = dv;
+                if (j < h && !last) P[p + j * ld] = sv;
+                else a.y[p + (int64_t)j * a.ldy] = sv;
+            }
+            tail_sync(multi);
+            m = h;
+        }
+    } else {
+        int m = a.n0 >> (a.nlev - 1);
+        const bool have_multi = multi;
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const int h = m >> 1;
+            const bool last = (lev == a.nlev - 1);
+            // small levels come first: wave 0 works alone until the level is big enough, the others wait at the barriers
+            const bool solo = have_multi && m * m <= 256;
+            const bool act = !solo || tid < 64;
+            const int nt = solo ? 64 : nthr;
+            const bool mm = have_multi && !solo;
+            if (act) {
+                // columns (dim 1) first: W[j*m + p] = norm1 * P[p, j], W[j*m + h + p] = norm2 * P[h + p, j]
+                for (int e = tid; e < m * h; e += nt) {
+                    int j, p;
+                l_split_idx(e, h, j, p);
+                    W[j * m + p] = sc.norm1 * P[p + j * ld];
+                    W[j * m + h + p] = sc.norm2 * P[h + p + j * ld];
+                }
+                tail_sync(mm);
+                tail_lift_steps_lines<T>(W, h, m, sc, tid, nt, mm);
+                for (int e = tid; e < m * h; e += nt) {
+                    int j, p;
+                l_split_idx(e, h, j, p);
+                    Q[2 * p + j * ld] = W[j * m + p];
+                    Q[2 * p + 1 + j * ld] = W[j * m + h + p];
+                }
+                tail_sync(mm);
+                // rows (dim 2): W[i*m + p] = norm1 * Q[i, p], W[i*m + h + p] = norm2 * Q[i, h + p]
+                for (int e = tid; e < m * h; e += nt) {
+                    int p, i;
+                l_split_idx(e, m, p, i);
+                    W[i * m + p] = sc.norm1 * Q[i + p * ld];
+                    W[i * m + h + p] = sc.norm2 * Q[i + (h + p) * ld];
+                }
+                tail_sync(mm);
+                tail_lift_steps_lines<T>(W, h, m, sc, tid, nt, mm);
+                for (int e = tid; e < m * h; e += nt) {
+                    int p, i;
+                l_split_idx(e, m, p, i);
+                    const T v0 = W[i * m + p], v1 = W[i * m + h + p];
+                    if (last) { a.y[i + (int64_t)(2 * p) * a.ldy] = v0; a.y[i + (int64_t)(2 * p + 1) * a.ldy] = v1; }
+                    else { P[i + (2 * p) * ld] = v0; P[i + (2 * p + 1) * ld] = v1; }
+                }
+                tail_sync(mm);
+            }
+            const bool next_solo = have_multi && (4 * m * m) <= 256;
+            if (solo && !next_solo && !last) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            m <<= 1;
+        }
+    }
+}
+
+template <typename T, int FW>
+static hipError_t launch_tail_lift2d(hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, int n0, int nlev)
+{
+    LiftTail2DArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.n0 = n0; a.nlev = nlev;
+    a.ld = n0 | 1;
+    a.cap = (a.ld * n0 + 15) & ~15;
+    const size_t shmem = (size_t)(FW ? 2 : 3) * a.cap * sizeof(T);
+    static unsigned char attr_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift2d<T, FW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = 1;
+    }
+    const int work = n0 * n0;
+    int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
+    if (const char *e = std::getenv("WL_LIFT_TAIL_THREADS")) { if (*e && std::atoi(e) >= 64) threads = std::atoi(e); }
+    hipLaunchKernelGGL((k_tail_lift2d<T, FW>), dim3(1), dim3(threads), shmem, st, a, sc);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
 static int l_env(const char *name, int dflt)
 {
     const char *s = std::getenv(name);
@@ -1077,6 +1275,11 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             T *llbuf = pp ? w.B : w.A;
             T *lld = last ? y : llbuf;
             const int64_t ldd = last ? ldy : h;
+            if (n <= 64 && l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {        // every remaining level inside one workgroup
+                WL_E((launch_tail_lift2d<T, 1>(st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
+                any_fast = true;
+                break;
+            }
             if (lines_ok(n) || short_lift_ok(n)) {
                 any_fast = true;
                 // rows (dim 2): one streaming pass along the strided axis, T0 = [s-columns | d-columns]
@@ -1114,7 +1317,21 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
         const T *llsrc = nullptr;
         int64_t ll_ls = 0;
         int pp = 0;
-        for (int l = L; l >= 1; --l) {
+        int l_start = L;
+        if (l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {
+            int l_lo = L + 1;                       // shallowest level whose output still fits the LDS tail
+            while (l_lo > 1 && (n0 >> (l_lo - 2)) <= 64) --l_lo;
+            if (l_lo <= L) {
+                const int64_t n = n0 >> (l_lo - 1);
+                T *out = (l_lo == 1) ? y : (pp ? w.B : w.A);
+                const int64_t ldo = (l_lo == 1) ? ldy : n;
+                WL_E((launch_tail_lift2d<T, 0>(st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
+                any_fast = true;
+                llsrc = out; ll_ls = ldo; pp ^= 1;
+                l_start = l_lo - 1;
+            }
+        }
+        for (int l = l_start; l >= 1; --l) {
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;

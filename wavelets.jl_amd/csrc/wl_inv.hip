@@ -85,6 +85,46 @@ __device__ __forceinline__ void inv_pair(const T *sw, const T *dw, const TapsI<T
     xo = So + Do;
 }
 
+template <typename T, int N>
+__device__ __forceinline__ void ldn(const T *p, T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stn(T *p, const T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+template <typename T, int NB>
+__device__ __forceinline__ T i_prev_n(T v)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v = i_prev(v);
+    return v;
+}
+template <typename T, int NB>
+__device__ __forceinline__ T i_next_n(T v)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v = i_next(v);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int F>
 struct Inv1DArgs {
@@ -485,6 +525,95 @@ static hipError_t launch_inv1d(hipStream_t st, const Taps<T> &taps, const T *ssr
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TWO inverse levels of a line per launch: the level-l reconstruction (4 samples per lane) stays in registers and
+// is consumed, together with the level-(l-1) details, by the second reconstruction (8 samples per lane).  Traffic
+// for the two levels: read n, write n (level by level: 3n) and half the launches.  Halos by DPP lane shifts:
+// ceil(SH/2) lanes for level l, ceil(SH/4) more on the approximation side for level l-1.
+template <typename T, int F>
+struct Inv1D2Args {
+    const T *s2; int64_t s2_ls;     // approximation of the deeper level (n/4 per line)
+    const T *d2; int64_t d2_ls;     // details of the deeper level (n/4)
+    const T *d1; int64_t d1_ls;     // details of the shallower level (n/2)
+    T *dst; int64_t o_ls;           // output lines (n)
+    int64_t n;                      // OUTPUT line length (multiple of 16, >= 1024)
+    int64_t ntiles;
+    TapsI<T, F> tp;
+};
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256) k_inv1d_stream2(Inv1D2Args<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2;
+    constexpr int H2 = (SH + 1) / 2, H1 = (SH + 3) / 4;
+    constexpr int HL = H2 + H1, HR = H2 > H1 ? H2 : H1;
+    constexpr int VP2 = (64 - HL - HR) * 2;          // deeper-level pairs owned by a wave tile
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t nx2 = a.n >> 2;
+    const T *s2 = a.s2 + (int64_t)blockIdx.y * a.s2_ls;
+    const T *d2 = a.d2 + (int64_t)blockIdx.y * a.d2_ls;
+    const T *d1 = a.d1 + (int64_t)blockIdx.y * a.d1_ls;
+    T *dst = a.dst + (int64_t)blockIdx.y * a.o_ls;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k2 = tile * VP2 + (int64_t)(lane - HL) * 2;
+        int64_t kw = k2;
+        if (kw < 0) kw += nx2;
+        if (kw >= nx2) kw -= nx2;
+        T sv[2], dv[2], d1v[4];
+        ldn<T, 2>(s2 + kw, sv);
+        ldn<T, 2>(d2 + kw, dv);
+        ldn<T, 4>(d1 + 2 * kw, d1v);
+        // deeper level: pairs kw, kw+1 -> a1[0..3]
+        T sx2[2 + SH], dx2[2 + SH];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { sx2[SH + i] = sv[i]; dx2[i] = dv[i]; }
+        if constexpr (SH >= 1) { sx2[SH - 1] = i_prev_n<T, 1>(sv[1]); dx2[2] = i_next_n<T, 1>(dv[0]); }
+        if constexpr (SH >= 2) { sx2[SH - 2] = i_prev_n<T, 1>(sv[0]); dx2[3] = i_next_n<T, 1>(dv[1]); }
+        if constexpr (SH >= 3) { sx2[SH - 3] = i_prev_n<T, 2>(sv[1]); dx2[4] = i_next_n<T, 2>(dv[0]); }
+        if constexpr (SH >= 4) { sx2[SH - 4] = i_prev_n<T, 2>(sv[0]); dx2[5] = i_next_n<T, 2>(dv[1]); }
+        T a1[4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) inv_pair<T, F>(&sx2[p], &dx2[p], a.tp, a1[2 * p], a1[2 * p + 1]);
+        // shallower level: pairs 2kw .. 2kw+3 -> 8 samples
+        T sx1[4 + SH], dx1[4 + SH];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sx1[SH + i] = a1[i]; dx1[i] = d1v[i]; }
+        if constexpr (SH >= 1) { sx1[SH - 1] = i_prev_n<T, 1>(a1[3]); dx1[4] = i_next_n<T, 1>(d1v[0]); }
+        if constexpr (SH >= 2) { sx1[SH - 2] = i_prev_n<T, 1>(a1[2]); dx1[5] = i_next_n<T, 1>(d1v[1]); }
+        if constexpr (SH >= 3) { sx1[SH - 3] = i_prev_n<T, 1>(a1[1]); dx1[6] = i_next_n<T, 1>(d1v[2]); }
+        if constexpr (SH >= 4) { sx1[SH - 4] = i_prev_n<T, 1>(a1[0]); dx1[7] = i_next_n<T, 1>(d1v[3]); }
+        T out[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) inv_pair<T, F>(&sx1[p], &dx1[p], a.tp, out[2 * p], out[2 * p + 1]);
+        if (lane >= HL && lane < 64 - HR && k2 < nx2) stn<T, 8>(dst + 4 * k2, out);
+    }
+}
+
+template <typename T, int F>
+static hipError_t launch_inv1d2(hipStream_t st, const Taps<T> &taps, const T *s2, int64_t s2_ls, const T *d2, int64_t d2_ls,
+                                const T *d1, int64_t d1_ls, T *dst, int64_t o_ls, int64_t n, int64_t nlines, int cu_count)
+{
+    constexpr int SH = (F - 2) / 2, H2 = (SH + 1) / 2, H1 = (SH + 3) / 4, HL = H2 + H1, HR = H2 > H1 ? H2 : H1;
+    constexpr int VP2 = (64 - HL - HR) * 2;
+    Inv1D2Args<T, F> a;
+    a.s2 = s2; a.s2_ls = s2_ls; a.d2 = d2; a.d2_ls = d2_ls; a.d1 = d1; a.d1_ls = d1_ls; a.dst = dst; a.o_ls = o_ls; a.n = n;
+    a.ntiles = ((n >> 2) + VP2 - 1) / VP2;
+    a.tp = shrink_i<T, F>(taps);
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    const int64_t slab = i_env("WL_SLAB_LINES", 32768);
+    for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
+        const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
+        Inv1D2Args<T, F> b = a;
+        b.s2 = a.s2 + l0 * a.s2_ls; b.d2 = a.d2 + l0 * a.d2_ls; b.d1 = a.d1 + l0 * a.d1_ls; b.dst = a.dst + l0 * a.o_ls;
+        hipLaunchKernelGGL((k_inv1d_stream2<T, F>), dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, b);
+    }
+    return hipGetLastError();
+}
+
 template <typename T, int F>
 static hipError_t launch_inv_dim2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t lds, T *dst, int64_t ldd,
                                   int64_t ms, int64_t ns, int cu_count)
@@ -521,46 +650,6 @@ struct Inv2DArgs {
     int nstrips, nchunks;
     TapsI<T, F> tp;
 };
-
-template <typename T, int N>
-__device__ __forceinline__ void ldn(const T *p, T (&v)[N])
-{
-    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
-    typedef T V __attribute__((ext_vector_type(C)));
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        V t = *reinterpret_cast<const V *>(p + c * C);
-#pragma unroll
-        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
-    }
-}
-template <typename T, int N>
-__device__ __forceinline__ void stn(T *p, const T (&v)[N])
-{
-    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
-    typedef T V __attribute__((ext_vector_type(C)));
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        V t;
-#pragma unroll
-        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
-        *reinterpret_cast<V *>(p + c * C) = t;
-    }
-}
-template <typename T, int NB>
-__device__ __forceinline__ T i_prev_n(T v)
-{
-#pragma unroll
-    for (int i = 0; i < NB; ++i) v = i_prev(v);
-    return v;
-}
-template <typename T, int NB>
-__device__ __forceinline__ T i_next_n(T v)
-{
-#pragma unroll
-    for (int i = 0; i < NB; ++i) v = i_next(v);
-    return v;
-}
 
 // dim-1 reconstruction of one column: the lane's PPL approximation / detail coefficients -> 2*PPL samples
 template <typename T, int F, int PPL>
@@ -746,6 +835,27 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         Strides3 res_st = (l == 1) ? b.full : box_st;
         bool done = false;
 
+        // ---- lines: two levels (l and l-1) per launch ----
+        if (fastF && lines && l >= 2 && i_env("WL_NO_INV1D2", 0) == 0 && n[0] >= 512 && (n[0] % 8) == 0 && b.full.s[0] == 1 &&
+            i_al16(x) && i_al16(y) && (nlines == 1 || ((b.full.s[1] % VEC) == 0 && (!llsrc || (llsrc_st.s[1] % VEC) == 0)))) {
+            int64_t n1[3];
+            level_box(b, l - 1, n1);                        // output extents of the shallower level: n1[0] = 2 n[0]
+            T *res1 = (l - 1 == 1) ? y : (pp ? w.B : w.A);
+            const int64_t r_ls = (l - 1 == 1) ? b.full.s[1] : n1[0];
+            const T *ss = llsrc ? llsrc : x;
+            const int64_t sls = llsrc ? llsrc_st.s[1] : b.full.s[1];
+            if (i_al16(ss) && i_al16(res1)) {
+                WL_DISPATCH_FI(F, WL_TRYI((launch_inv1d2<T, FF>(st, taps, ss, sls, x + (n[0] >> 1), b.full.s[1], x + n[0], b.full.s[1],
+                                                                res1, r_ls, n1[0], nlines, cu_count)));
+                               done = true);
+            }
+            if (done) {
+                dominant = "k_inv1d_stream2";
+                llsrc = res1; llsrc_st = dense_strides(n1); pp ^= 1;
+                --l;                                         // two levels consumed
+                continue;
+            }
+        }
         if (fastF && lines && n[0] >= 512 && (n[0] % 8) == 0 && b.full.s[0] == 1 && i_al16(x) && i_al16(y) &&
             (nlines == 1 || (b.full.s[1] % VEC) == 0)) {
             const T *ss = llsrc ? llsrc : x;

@@ -90,6 +90,32 @@ __device__ __forceinline__ void stN(T *p, const T (&v)[N])
     }
 }
 
+template <typename T, int N>
+__device__ __forceinline__ void ldv_l(const T *p, T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t = *reinterpret_cast<const V *>(p + c * C);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void stv_l(T *p, const T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
 template <typename T, int ID, int FW>
 __global__ void __launch_bounds__(256) k_lift1d_stream(Lift1DArgs<T> a)
 {
@@ -307,6 +333,60 @@ __global__ void __launch_bounds__(256) k_lift1d_fwd3(Lift3Args<T> a)
             a.y[line * a.y_ls + (n >> 3) + (k0 >> 2)] = d3[0] * a.norm2;
             a.sdst[line * a.s_ls + (k0 >> 2)] = s3[0] * a.norm1;
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Three INVERSE lifting levels per pass over HBM (mirror of k_lift1d_fwd3): the lane starts from one pair of the
+// deepest level, reconstructs 2 then 4 approximations in registers, merges in the details of the two shallower
+// levels on the way and stores 8 samples.  Traffic: read n, write n for three levels (level by level: 3.5 n).
+template <typename T>
+struct LiftInv3Args {
+    const T *s3; int64_t s3_ls;     // approximation of the deepest of the three levels (n/8 per line)
+    const T *x; int64_t x_ls;       // coefficient lines: d3 at x[n/8 + k], d2 at x[n/4 + k], d1 at x[n/2 + k]
+    T *dst; int64_t o_ls;           // output lines (n samples)
+    int64_t n;                      // OUTPUT line length
+    int64_t ntiles;
+    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;                 // already inverted by make_scheme
+};
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(256) k_lift1d_inv3(LiftInv3Args<T> a)
+{
+    constexpr int ML = 4, VP3 = 64 - 2 * ML;          // deepest-level pairs owned by a wave tile (one per lane)
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t n = a.n, h3 = n >> 3;
+    const int64_t line = blockIdx.y;
+    const T *x = a.x + line * a.x_ls;
+    for (int64_t tile = wave; tile < a.ntiles; tile += nwaves) {
+        const int64_t k3 = tile * VP3 + (lane - ML);
+        int64_t kw = k3;
+        if (kw < 0) kw += h3;
+        if (kw >= h3) kw -= h3;
+        T s3[1], d3[1], d2[2], d1[4];
+        s3[0] = a.norm1 * a.s3[line * a.s3_ls + kw];
+        d3[0] = a.norm2 * x[h3 + kw];
+        ldv_l<T, 2>(x + 2 * h3 + 2 * kw, d2);
+        ldv_l<T, 4>(x + 4 * h3 + 4 * kw, d1);
+        lift_steps_lane<T, ID, 1>(s3, d3, a.c, kw, h3);
+        T s2[2], d2n[2];
+        s2[0] = a.norm1 * s3[0]; s2[1] = a.norm1 * d3[0];                 // merge!, then normalize! of the next level
+#pragma unroll
+        for (int j = 0; j < 2; ++j) d2n[j] = a.norm2 * d2[j];
+        lift_steps_lane<T, ID, 2>(s2, d2n, a.c, 2 * kw, 2 * h3);
+        T s1[4], d1n[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { s1[2 * j] = a.norm1 * s2[j]; s1[2 * j + 1] = a.norm1 * d2n[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d1n[j] = a.norm2 * d1[j];
+        lift_steps_lane<T, ID, 4>(s1, d1n, a.c, 4 * kw, 4 * h3);
+        T out[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { out[2 * j] = s1[j]; out[2 * j + 1] = d1n[j]; }
+        if (lane >= ML && lane < 64 - ML && k3 < h3) stv_l<T, 8>(a.dst + line * a.o_ls + 8 * k3, out);
     }
 }
 
@@ -702,6 +782,26 @@ static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) 
 
 // Forward or inverse lifting transform of `nlines` lines (1-D vector: nlines = 1; batched columns).
 // Returns 1 in *handled when the whole transform was enqueued by the fast kernels.
+// inverse shapes only (IDs 1, 3, 5); false = not an inverse shape
+template <typename T>
+static bool launch_inv3_id(int id, hipStream_t st, const LiftInv3Args<T> &a, int64_t nlines, int cu_count)
+{
+    if (id != 1 && id != 3 && id != 5) return false;
+    int64_t gx = (a.ntiles + 3) / 4;
+    const int64_t cap = (int64_t)cu_count * 8;
+    if (gx > cap) gx = cap;
+    for (int64_t l0 = 0; l0 < nlines; l0 += 32768) {
+        const int64_t nl = (nlines - l0 < 32768) ? (nlines - l0) : 32768;
+        LiftInv3Args<T> b = a;
+        b.s3 = a.s3 + l0 * a.s3_ls; b.x = a.x + l0 * a.x_ls; b.dst = a.dst + l0 * a.o_ls;
+        const dim3 grid((unsigned)gx, (unsigned)nl), block(256);
+        if (id == 1) hipLaunchKernelGGL((k_lift1d_inv3<T, 1>), grid, block, 0, st, b);
+        else if (id == 3) hipLaunchKernelGGL((k_lift1d_inv3<T, 3>), grid, block, 0, st, b);
+        else hipLaunchKernelGGL((k_lift1d_inv3<T, 5>), grid, block, 0, st, b);
+    }
+    return true;
+}
+
 template <typename T>
 int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
                        T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
@@ -836,6 +936,35 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             l = l_lo - 1;
         }
         for (; l >= 1; --l) {
+            // three levels (l, l-1, l-2) per launch while the output of level l-2 is a long line
+            if (l >= 3 && l_env("WL_NO_LIFT_INV3", 0) == 0) {
+                const int64_t n3 = n >> (l - 3);                 // output length of level l-2
+                if (n3 >= 4096 && (n3 % 64) == 0 && (nlines == 1 || ((ld % VEC) == 0 && (ll_ls % VEC) == 0))) {
+                    const bool to_y3 = (l - 2 == 1);
+                    T *out3 = to_y3 ? y : (pp ? w.B : w.A);
+                    const bool stage3 = to_y3 && (y == x);       // in place: the details of y are still being read
+                    LiftInv3Args<T> q;
+                    for (int i = 0; i < WL_MAX_STEPS; ++i)
+                        for (int k = 0; k < WL_MAX_NCOEF; ++k) q.c[i][k] = a.c[i][k];
+                    q.norm1 = a.norm1; q.norm2 = a.norm2;
+                    q.s3 = llsrc; q.s3_ls = ll_ls; q.x = x; q.x_ls = ld;
+                    q.dst = stage3 ? w.W : out3; q.o_ls = stage3 ? n3 : (to_y3 ? ld : n3);
+                    q.n = n3; q.ntiles = ((n3 >> 3) + 55) / 56;
+                    if (launch_inv3_id<T>(id, st, q, nlines, cu_count)) {
+                        WL_CHECK_LAUNCH();
+                        if (stage3) {
+                            Extent3 e = {{n3, nlines, 1}};
+                            Strides3 s0 = {{1, n3, n3 * nlines}}, s1 = {{1, ld, ld * nlines}};
+                            hipError_t e2 = generic_copy_box<T>(st, w.W, s0, y, s1, e);
+                            if (e2 != hipSuccess) { if (hip_err) *hip_err = (int)e2; return WL_EHIP; }
+                        }
+                        dom = "k_lift1d_inv3";
+                        llsrc = out3; ll_ls = n3; pp ^= 1;
+                        l -= 2;
+                        continue;
+                    }
+                }
+            }
             const int64_t nl = n >> (l - 1), hl = nl >> 1;
             const bool to_y = (l == 1);
             T *out = to_y ? y : (pp ? w.B : w.A);
@@ -869,32 +998,6 @@ template int lifting_lines_fast<float>(void *, int, hipStream_t, int64_t, int64_
                                        const LiftScheme<float> &, int, int, int *, const char **, int *);
 template int lifting_lines_fast<double>(void *, int, hipStream_t, int64_t, int64_t, int64_t, double *, const double *,
                                         const LiftScheme<double> &, int, int, int *, const char **, int *);
-
-template <typename T, int N>
-__device__ __forceinline__ void ldv_l(const T *p, T (&v)[N])
-{
-    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
-    typedef T V __attribute__((ext_vector_type(C)));
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        V t = *reinterpret_cast<const V *>(p + c * C);
-#pragma unroll
-        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
-    }
-}
-template <typename T, int N>
-__device__ __forceinline__ void stv_l(T *p, const T (&v)[N])
-{
-    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
-    typedef T V __attribute__((ext_vector_type(C)));
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        V t;
-#pragma unroll
-        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
-        *reinterpret_cast<V *>(p + c * C) = t;
-    }
-}
 
 // --------------------------------------------------------------------------------------------------
 // One lifting level along a STRIDED axis (the dim-2 pass of a 2-D level) without transposes: lanes own 16 bytes of

@@ -1326,9 +1326,12 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             }
         }
         // ---- LDS-resident tail: finishes every remaining level in one launch ----
+        // (batches of many lines: one workgroup per line is only efficient for short lines -- longer ones take
+        //  another pass of the multi-level tile kernel first)
+        const int64_t line_cap = (lines && nlines >= 32 && fastF) ? env_int("WL_TAIL_LINES_CAP", 512) : tail_cap<T>();
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
-            if (blk <= tail_cap<T>() && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
+            if (blk <= (two_d ? (int64_t)tail_cap<T>() : line_cap) && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
                 if (two_d)
                     WL_TRY(launch_tail<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
                 else   // one workgroup per line
@@ -1339,7 +1342,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         }
         bool done = false;
         // ---- 1-D multi-level tile kernel: up to 4 levels per pass over HBM ----
-        if (fastF && lines && env_int("WL_NO_MULTI", 0) == 0 && n[0] > tail_cap<T>() && (n[0] % (8 * VEC)) == 0 &&
+        if (fastF && lines && env_int("WL_NO_MULTI", 0) == 0 && n[0] > line_cap && (n[0] % (8 * VEC)) == 0 &&
             cur_st.s[0] == 1 && aligned16(cur) && aligned16(y) &&
             (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0))) {
             int NL = L - l + 1;

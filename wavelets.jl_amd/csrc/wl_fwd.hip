@@ -1137,7 +1137,7 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
     const int wpc = env_int("WL_WAVES_PER_CU", 8);
     while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;
-    while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * env_int("WL_WAVES_MIN", 2)) TJ >>= 1;
+    while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * env_int("WL_WAVES_MIN", 8)) TJ >>= 1;
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.tp = shrink<T, F>(taps);

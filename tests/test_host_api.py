@@ -118,3 +118,27 @@ def test_bench_refuses_to_run_without_gpu():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "no CPU path" in (p.stderr + p.stdout)
+
+
+def test_threshold_and_modwt_host_logic(W):
+    """Host-side mirror of Threshold / MODWT: types, defaults, argument contract -- and no CPU path."""
+    import math
+    import torch
+    assert isinstance(W.DEFAULT_TH, W.HardTH) and W.DEFAULT_WAVELET.name == "sym5" and len(W.DEFAULT_WAVELET.qmf) == 10
+    vs = W.VisuShrink(256)
+    assert isinstance(vs.th, W.HardTH) and vs.t == math.sqrt(2 * math.log(256))         # denoising.jl:14-17
+    vs2 = W.VisuShrink(W.SoftTH(), 1.5)
+    assert isinstance(vs2.th, W.SoftTH) and vs2.t == 1.5
+    # nspin2circ: CartesianIndices order, first dimension fastest (denoising.jl:112-121)
+    assert W.nspin2circ(8, 1) == [0] and W.nspin2circ(8, 8) == [7]
+    assert [W.nspin2circ((2, 3), i) for i in range(1, 7)] == [[0, 0], [1, 0], [0, 1], [1, 1], [0, 2], [1, 2]]
+    assert W.maxmodwttransformlevels(129) == 7 and W.maxmodwttransformlevels(128) == 7 and W.maxmodwttransformlevels(127) == 6
+    codes = [t.code for t in (W.HardTH(), W.SoftTH(), W.SemiSoftTH(), W.SteinTH(), W.PosTH(), W.NegTH())]
+    assert codes == [0, 1, 2, 3, 4, 5]                                                   # enum wl_thtype
+    x = torch.zeros(16)
+    for call in (lambda: W.threshold(x, W.HardTH(), 1.0), lambda: W.denoise(x), lambda: W.modwt(x, W.wavelet(W.WT.db2)),
+                 lambda: W.mad_(x), lambda: W.noisest(x), lambda: W.imodwt(torch.zeros(16, 3), W.wavelet(W.WT.db2))):
+        with pytest.raises(W.HIPError):
+            call()
+    with pytest.raises(TypeError):
+        W.modwt(x, W.wavelet(W.WT.cdf97, W.WT.Lifting))                                  # MethodError in the reference

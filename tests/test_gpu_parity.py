@@ -588,3 +588,39 @@ def test_differential_fuzz(gpu, W, oracle):
     for _ in range(150):
         kernels.update(fz.one_case(r))
     assert len(kernels) >= 10, kernels          # the draw must actually spread over the kernel families
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_unaligned_views(gpu, W, oracle, dtype):
+    """Arrays that start 4/8 bytes into an allocation (views): the 16-byte fast paths must step aside, results stay
+    bit-identical (filter, lifting, batched columns, modwt, threshold!)."""
+    import torch
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    db4, sch = W.wavelet(W.WT.db4), W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    for n, L in ((4096, 12), (1 << 16, 5)):
+        x = rng_array((n,), dtype, n)
+        buf = torch.empty(n + 3, dtype=td, device=gpu)
+        xv = buf[1:1 + n]
+        xv.copy_(torch.from_numpy(x))
+        assert xv.data_ptr() % 16 != 0
+        out = torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
+        W.dwt_(out, xv, db4, L)
+        assert np.array_equal(host(W, out), oracle.dwt_filter(x, db4.qmf, L))
+        W.idwt_(out, xv, db4, L)
+        assert np.array_equal(host(W, out), oracle.dwt_filter(x, db4.qmf, L, fw=False))
+        assert np.array_equal(host(W, W.dwt(xv, sch, L)), oracle.dwt_lifting(x, sch, L))
+        t = buf[1:1 + n].clone()
+        assert np.array_equal(host(W, W.modwt(xv, db4, 3)), oracle.modwt(x, db4.qmf, 3))
+        tv = torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
+        tv.copy_(xv)
+        W.threshold_(tv, W.SoftTH(), 0.3)
+        assert np.array_equal(host(W, tv), oracle.threshold(x, "soft", 0.3))
+        W.dwt_(tv, sch, L)                                    # in place on the view
+    # 2-D view with an odd leading offset
+    a = rng_array((512, 64), dtype, 9)
+    big = torch.empty(512 * 64 + 5, dtype=td, device=gpu)
+    av = big[1:1 + 512 * 64].view(64, 512).t()               # Julia layout, data pointer 4/8 bytes off
+    av.copy_(torch.from_numpy(a))
+    assert W.is_julia_layout(av) and av.data_ptr() % 16 != 0
+    assert np.array_equal(host(W, W.dwt(av, db4, 3)), oracle.dwt_filter(a, db4.qmf, 3))
+    assert np.array_equal(host(W, W.dwtc(av, db4, 4)), oracle.dwtc_filter(a, db4.qmf, 4))

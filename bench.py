@@ -39,7 +39,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--levels", type=int, default=None, help="override L (default: maxtransformlevels)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -25,6 +25,9 @@ namespace wl {
 // ---- scheme shapes known at compile time (coefficients stay run-time data) -----------------------
 // direction-adjusted order (as produced by make_scheme): step i = {is_update, nc, shift}
 struct StepShape { int upd, nc, sh; };
+// the shape-specialised kernels never have more steps than this; their argument blocks carry only these coefficients
+// (keeping kernel arguments small matters: launches with > 256 bytes of arguments were seen to stall the enqueue path)
+constexpr int LIFT_FAST_STEPS = 4;
 template <int ID> struct Shape;
 // cdf9/7 forward and inverse have the same shape sequence read in opposite order
 template <> struct Shape<0> { static constexpr int NS = 4; static constexpr StepShape S[4] = {{1, 2, 0}, {0, 2, 1}, {1, 2, 0}, {0, 2, 1}}; };   // cdf9/7 fw
@@ -60,7 +63,7 @@ struct Lift1DArgs {
     T *o1; int64_t o1_ls;           // fw: ddst           inv: unused
     int64_t n;                      // line length (multiple of 8, >= 512)
     int64_t ntiles;
-    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;
 };
 
@@ -248,7 +251,7 @@ __device__ __forceinline__ T lane_operand(const T (&op)[PPL], int off)
 }
 
 template <typename T, int ID, int PPL>
-__device__ __forceinline__ void lift_steps_lane(T (&s)[PPL], T (&d)[PPL], const T (&c)[WL_MAX_STEPS][WL_MAX_NCOEF],
+__device__ __forceinline__ void lift_steps_lane(T (&s)[PPL], T (&d)[PPL], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF],
                                                 int64_t kfirst, int64_t half)
 {
     typedef Shape<ID> SH;
@@ -289,7 +292,7 @@ struct Lift3Args {
     T *sdst; int64_t s_ls;          // approximation after three levels
     int64_t n;
     int64_t ntiles;
-    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;
 };
 
@@ -347,7 +350,7 @@ struct LiftInv3Args {
     T *dst; int64_t o_ls;           // output lines (n samples)
     int64_t n;                      // OUTPUT line length
     int64_t ntiles;
-    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;                 // already inverted by make_scheme
 };
 
@@ -802,6 +805,19 @@ static bool launch_inv3_id(int id, hipStream_t st, const LiftInv3Args<T> &a, int
     return true;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device) and costs tens of microseconds:
+// raise the limit to the LDS size once per device instead of on every call
+static hipError_t lift_max_lds_once(const void *fn, unsigned char (&done)[64])
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done[dev] = 1;
+    return e;
+}
+
 template <typename T>
 int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
                        T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
@@ -838,7 +854,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } } while (0)
 
     Lift1DArgs<T> a;
-    for (int i = 0; i < WL_MAX_STEPS; ++i)
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
         for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
     a.norm1 = sc.norm1; a.norm2 = sc.norm2;
 
@@ -857,7 +873,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
                 const bool last3 = (l + 2 == L);
                 T *llbuf3 = pp ? w.B : w.A;
                 Lift3Args<T> a3;
-                for (int i = 0; i < WL_MAX_STEPS; ++i)
+                for (int i = 0; i < LIFT_FAST_STEPS; ++i)
                     for (int k = 0; k < WL_MAX_NCOEF; ++k) a3.c[i][k] = a.c[i][k];
                 a3.norm1 = a.norm1; a3.norm2 = a.norm2;
                 a3.src = cur; a3.src_ls = cur_ls; a3.y = y; a3.y_ls = ld; a3.d1 = y + hl; a3.d1_ls = ld;
@@ -898,8 +914,8 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             t.src = cur; t.src_item = cur_ls; t.y = y; t.y_item = ld; t.ll = nullptr; t.ll_item = 0;
             t.n0 = (int)nl; t.nlev = L - l_tail + 1; t.cap = (int)((nl + 15) & ~15);
             const size_t shmem = 2 * (size_t)t.cap * sizeof(T);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            static unsigned char attr_fw[64] = {0};
+            hipError_t e = lift_max_lds_once(reinterpret_cast<const void *>(&k_tail_lift<T, 1>), attr_fw);
             if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }
             int threads = nl >= 4096 ? 1024 : (nl >= 512 ? 256 : 64);
             hipLaunchKernelGGL((k_tail_lift<T, 1>), dim3((unsigned)nlines), dim3(threads), shmem, st, t, sc);
@@ -925,8 +941,8 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             t.y = out; t.y_item = to_y ? ld : nout;
             t.n0 = (int)nout; t.nlev = l_hi - l_lo + 1; t.cap = (int)((nout + 15) & ~15);
             const size_t shmem = 2 * (size_t)t.cap * sizeof(T);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift<T, 0>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            static unsigned char attr_inv[64] = {0};
+            hipError_t e = lift_max_lds_once(reinterpret_cast<const void *>(&k_tail_lift<T, 0>), attr_inv);
             if (e != hipSuccess) { if (hip_err) *hip_err = (int)e; return WL_EHIP; }
             int threads = nout >= 4096 ? 1024 : (nout >= 512 ? 256 : 64);
             hipLaunchKernelGGL((k_tail_lift<T, 0>), dim3((unsigned)nlines), dim3(threads), shmem, st, t, sc);
@@ -944,7 +960,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
                     T *out3 = to_y3 ? y : (pp ? w.B : w.A);
                     const bool stage3 = to_y3 && (y == x);       // in place: the details of y are still being read
                     LiftInv3Args<T> q;
-                    for (int i = 0; i < WL_MAX_STEPS; ++i)
+                    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
                         for (int k = 0; k < WL_MAX_NCOEF; ++k) q.c[i][k] = a.c[i][k];
                     q.norm1 = a.norm1; q.norm2 = a.norm2;
                     q.s3 = llsrc; q.s3_ls = ll_ls; q.x = x; q.x_ls = ld;
@@ -1055,7 +1071,7 @@ struct LiftAxisArgs {
     int64_t R, C;                                  // rows (contiguous), axis length
     int TP;                                        // output pairs per chunk (multiple of 8)
     int nstrips, nchunks;
-    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;
 };
 
@@ -1210,7 +1226,7 @@ struct LiftShortArgs {
     T *ll; int64_t ll2, ll3; int l2; int64_t l3;
     int n, G, c2;
     int64_t nlines;
-    T c[WL_MAX_STEPS][WL_MAX_NCOEF];
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;
 };
 
@@ -1356,7 +1372,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     Lift1DArgs<T> a;
     LiftAxisArgs<T> ax;
     LiftShortArgs<T> sa;
-    for (int i = 0; i < WL_MAX_STEPS; ++i)
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
         for (int k = 0; k < WL_MAX_NCOEF; ++k) {
             a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
             ax.c[i][k] = a.c[i][k];
@@ -1490,7 +1506,7 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
     Work<T> w = carve<T>(ws, N);
     LiftAxisArgs<T> ax;
     LiftShortArgs<T> sa;
-    for (int i = 0; i < WL_MAX_STEPS; ++i)
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
         for (int k = 0; k < WL_MAX_NCOEF; ++k) {
             ax.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
             sa.c[i][k] = ax.c[i][k];

@@ -350,11 +350,15 @@ class GLS:
     def flatten(self):
         """(is_update[int32], ncoef[int32], shift[int32], coefs[float64]) in table order -- the
         form the C ABI takes (include/wavelets_mi355x.h: wl_dwt_lifting)."""
+        cached = getattr(self, "_flat", None)          # a scheme is immutable: flatten once, not on every transform call
+        if cached is not None:
+            return cached
         iu = np.array([1 if isinstance(s.steptype, UpdateStep) else 0 for s in self.step], dtype=np.int32)
         nc = np.array([len(s) for s in self.step], dtype=np.int32)
         sh = np.array([s.param.shift for s in self.step], dtype=np.int32)
         cf = np.concatenate([s.param.coef for s in self.step]).astype(np.float64) if self.step else np.zeros(0)
-        return iu, nc, sh, cf
+        self._flat = (iu, nc, sh, cf)
+        return self._flat
 
 
 # ---- wavelet(...) (wt_main.jl:262-264) ---------------------------------------------------------

@@ -1,6 +1,6 @@
 """Differential fuzzing of the HIP path against the CPU oracle: random shapes (with odd factors), filters, lifting
 schemes, depths, element types and entry points; every result must be bit-identical.  Usage:
-    python tools/fuzz_parity.py [ncases] [seed]        (needs an MI355X; test infrastructure, not product code)"""
+    python tests/fuzz_parity.py [ncases] [seed]        (needs an MI355X; test infrastructure, not product code)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

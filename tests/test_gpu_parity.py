@@ -578,9 +578,9 @@ def test_full_size_properties(gpu, W, oracle):
 
 
 def test_differential_fuzz(gpu, W, oracle):
-    """150 random (shape, wavelet, depth, element type, entry point) cases of tools/fuzz_parity.py, bit for bit."""
+    """150 random (shape, wavelet, depth, element type, entry point) cases of tests/fuzz_parity.py, bit for bit."""
     import importlib.util, os
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     r = np.random.default_rng(20260926)

@@ -70,12 +70,22 @@ k_generic_fwd_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
             dst[o0 + (2 * k + 1) * dst_st.s[axis]] = p[(2 * k + 1) * sa];
             continue;
         }
-        // scaling branch: m ascending
-        T s = taps.h[0] * p[pmod(2 * k, nax) * sa];
-        for (int m = 1; m < F; ++m) s = s + taps.h[m] * p[pmod(2 * k + m, nax) * sa];
-        // detail branch: m descending
-        T dd = taps.g[F - 1] * p[pmod(2 * k + 1 - (F - 1), nax) * sa];
-        for (int m = F - 2; m >= 0; --m) dd = dd + taps.g[m] * p[pmod(2 * k + 1 - m, nax) * sa];
+        // both branches walk the line upwards one sample per tap: one modulo for the start, then a conditional wrap
+        // (64-bit % is an emulated division on the GPU; a line shorter than the filter simply wraps several times)
+        // scaling branch: m ascending, samples 2k, 2k+1, ...
+        int64_t idx = 2 * k;                                  // < nax
+        T s = taps.h[0] * p[idx * sa];
+        for (int m = 1; m < F; ++m) {
+            if (++idx == nax) idx = 0;
+            s = s + taps.h[m] * p[idx * sa];
+        }
+        // detail branch: m descending, samples 2k+1-(F-1), ..., 2k+1
+        idx = pmod(2 * k + 1 - (F - 1), nax);
+        T dd = taps.g[F - 1] * p[idx * sa];
+        for (int m = F - 2; m >= 0; --m) {
+            if (++idx == nax) idx = 0;
+            dd = dd + taps.g[m] * p[idx * sa];
+        }
 
         int64_t off_s = 0, off_d = 0;
         if (ll != nullptr && in_low_corner(c, axis, lo)) {
@@ -125,23 +135,30 @@ k_generic_inv_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
         const T *pd = src + base + nx * sst.s[axis];
         const int64_t sd = sst.s[axis];
 
+        // S: m descending over the taps with (o - m) even, coefficient index (o - m)/2 going up by one per term;
+        // D: m ascending over the taps with (o + m - 1) even, index (o + m - 1)/2 going up by one per term.
+        // One modulo for the start of S (it may be negative), conditional wraps afterwards.
         T S = (T)0, D = (T)0;
-        bool first = true;
-        for (int m = F - 1; m >= 0; --m) {
-            if (((o - m) & 1) == 0) {
-                int64_t k = pmod((o - m) / 2, nx);       // (o-m) even => exact
-                T term = taps.h[m] * ps[k * ss];
-                S = first ? term : (S + term);
-                first = false;
+        {
+            int m = (((F - 1 - o) & 1) == 0) ? F - 1 : F - 2;
+            if (m >= 0) {
+                int64_t k = pmod((o - m) / 2, nx);            // (o - m) even => exact
+                S = taps.h[m] * ps[k * ss];
+                for (m -= 2; m >= 0; m -= 2) {
+                    if (++k == nx) k = 0;
+                    S = S + taps.h[m] * ps[k * ss];
+                }
             }
         }
-        first = true;
-        for (int m = 0; m < F; ++m) {
-            if (((o + m - 1) & 1) == 0) {
-                int64_t k = pmod((o + m - 1) / 2, nx);
-                T term = taps.g[m] * pd[k * sd];
-                D = first ? term : (D + term);
-                first = false;
+        {
+            int m = (o & 1) ? 0 : 1;
+            if (m < F) {
+                int64_t k = (o + m - 1) / 2;                  // in [0, nx)
+                D = taps.g[m] * pd[k * sd];
+                for (m += 2; m < F; m += 2) {
+                    if (++k == nx) k = 0;
+                    D = D + taps.g[m] * pd[k * sd];
+                }
             }
         }
         int64_t off = 0;

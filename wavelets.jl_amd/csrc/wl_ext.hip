@@ -438,6 +438,105 @@ int ensure_aux(wl_ctx *ctx)
     return WL_OK;
 }
 
+// Small arrays (<= 8192 elements, e.g. the noise estimate of a 2-D array: the lower half of one column): the whole
+// median / mad! in ONE workgroup with the keys in LDS -- the multi-launch radix select above is launch-bound there.
+template <typename T>
+__device__ typename KeyOf<T>::U lds_select(const typename KeyOf<T>::U *keys, int n, unsigned long long k, unsigned int *hist,
+                                             unsigned long long *sh)
+{
+    typedef typename KeyOf<T>::U U;
+    constexpr int NB = KeyOf<T>::BYTES;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) { sh[0] = 0; sh[1] = k; }
+    for (int pass = 0; pass < NB; ++pass) {
+        const int shift = 8 * (NB - 1 - pass);
+        for (int b = tid; b < 256; b += nthr) hist[b] = 0;
+        __syncthreads();
+        const U prefix = (U)sh[0];
+        for (int i = tid; i < n; i += nthr) {
+            const U key = keys[i];
+            if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(unsigned)((key >> shift) & 0xff)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long kk = sh[1], cum = 0;
+            int b = 0;
+            for (; b < 255; ++b) {
+                if (kk < cum + hist[b]) break;
+                cum += hist[b];
+            }
+            sh[1] = kk - cum;
+            sh[0] = sh[0] | (((unsigned long long)b) << shift);
+        }
+        __syncthreads();
+    }
+    const U r = (U)sh[0];
+    __syncthreads();                // the next call re-initialises sh
+    return r;
+}
+template <typename T>
+__device__ T lds_median(typename KeyOf<T>::U *keys, int n, unsigned int *hist, unsigned long long *sh, unsigned int nan_count)
+{
+    typedef typename KeyOf<T>::U U;
+    const unsigned long long k1 = (unsigned long long)(n / 2), k0 = (n & 1) ? k1 : k1 - 1;
+    const U p0 = lds_select<T>(keys, n, k0, hist, sh);
+    const U p1 = (k1 == k0) ? p0 : lds_select<T>(keys, n, k1, hist, sh);
+    const T a = KeyOf<T>::val(p0, 0), b = KeyOf<T>::val(p1, 0);
+    T m = (p0 != p1) ? (a / 2 + b / 2) : a;
+    if (nan_count) m = (T)NAN;
+    return m;
+}
+// do_mad = 0: result = median(v) (v untouched);  1: mad!(v): v[i] = abs(v[i] - median(v)), result = median of that
+template <typename T>
+__global__ void __launch_bounds__(1024) k_mad_lds(T *v, int n, int do_mad, SelState *s)
+{
+    typedef typename KeyOf<T>::U U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    U *keys = reinterpret_cast<U *>(smem_raw);
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long sh[2];
+    __shared__ unsigned int nans;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) nans = 0;
+    __syncthreads();
+    unsigned int mynan = 0;
+    for (int i = tid; i < n; i += nthr) {
+        const T x = v[i];
+        if (x != x) ++mynan;
+        keys[i] = KeyOf<T>::key(x, 0);
+    }
+    if (mynan) atomicAdd(&nans, mynan);
+    __syncthreads();
+    T m = lds_median<T>(keys, n, hist, sh, nans);
+    if (do_mad) {
+        __syncthreads();
+        for (int i = tid; i < n; i += nthr) {
+            const T d = KeyOf<T>::val(keys[i], 0) - m;
+            const T ad = d < 0 ? -d : d;
+            v[i] = ad;
+            keys[i] = KeyOf<T>::key(ad, 0);
+        }
+        __syncthreads();
+        m = lds_median<T>(keys, n, hist, sh, nans);
+    }
+    if (tid == 0) s->result = (double)m;
+}
+constexpr int64_t kMadLdsMax = 8192;
+
+template <typename T>
+int mad_small(wl_ctx *ctx, hipStream_t st, T *v, int64_t n, int do_mad, double *result_host)
+{
+    int rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    SelState *s = (SelState *)ctx->aux;
+    const int threads = n >= 2048 ? 1024 : (n >= 256 ? 256 : 64);
+    hipLaunchKernelGGL((k_mad_lds<T>), dim3(1), dim3(threads), (size_t)n * sizeof(typename KeyOf<T>::U), st, v, (int)n, do_mad, s);
+    WL_HIP(ctx, hipGetLastError());
+    WL_HIP(ctx, hipMemcpyAsync(result_host, &s->result, sizeof(double), hipMemcpyDeviceToHost, st));
+    WL_HIP(ctx, hipStreamSynchronize(st));
+    return WL_OK;
+}
+
 // enqueue the selection of ranks k0 <= k1 (0-based) of v[0..n); leaves prefix[] resolved in the state
 template <typename T>
 int select_ranks(wl_ctx *ctx, hipStream_t st, const T *v, int64_t n, unsigned long long k0, unsigned long long k1, int absmode)
@@ -621,6 +720,9 @@ int wl_median(wl_ctx *ctx, int dtype, const void *v, int64_t n, double *result, 
     if (!v || !result) return WL_EINVAL_ARG;
     if (n < 1) return WL_EDIMS;
     hipStream_t st = (hipStream_t)stream;
+    if (n <= kMadLdsMax)        // (the kernel does not write v when do_mad == 0)
+        return dtype == WL_F32 ? mad_small<float>(ctx, st, (float *)const_cast<void *>(v), n, 0, result)
+                               : mad_small<double>(ctx, st, (double *)const_cast<void *>(v), n, 0, result);
     return dtype == WL_F32 ? median_impl<float>(ctx, st, (const float *)v, n, result, (float *)nullptr)
                            : median_impl<double>(ctx, st, (const double *)v, n, result, (double *)nullptr);
 }
@@ -634,6 +736,8 @@ int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *str
     rc = ensure_aux(ctx);
     if (rc != WL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (n <= kMadLdsMax)
+        return dtype == WL_F32 ? mad_small<float>(ctx, st, (float *)y, n, 1, result) : mad_small<double>(ctx, st, (double *)y, n, 1, result);
     void *mdev = (char *)ctx->aux + 4096;          // the first median, in the element type
     const unsigned nb = ext_blocks(n, 4, ctx->cu_count);
     if (dtype == WL_F32) {

@@ -301,12 +301,17 @@ def test_lifting_cubes_fast_vs_generic(gpu, W, oracle):
             assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (n, sname, L, "inv")
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tp", ["64", "24", ""])
-def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, monkeypatch, tp):
-    """k_lift_axis_stream (the dim-2 pass of a 2-D lifting level as a register cascade along the strided axis):
-    every chunk length, every scheme shape, forward and inverse, bit for bit against the oracle."""
+def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, monkeypatch, tp, fused):
+    """2-D lifting levels: k_lift2d_fwd / k_lift2d_inv (both passes of a level in one kernel: register cascade along
+    dim 2 + DPP lifting across the lanes along dim 1) and, with the fused kernels switched off, k_lift_axis_stream +
+    the line kernels: every chunk length, every scheme shape, forward and inverse, bit for bit against the oracle."""
     if tp:
         monkeypatch.setenv("WL_LIFT_TP", tp)
+    if not fused:
+        monkeypatch.setenv("WL_NO_LIFT2D_FUSED", "1")
+    expect = "k_lift2d" if fused else "k_lift_axis_stream"
     for n, Ls in ((512, (1, 3)), (1024, (2,)), (576, (1,)), (2048, (1, 11))):
         for dtype in (np.float32, np.float64):
             if n == 2048 and dtype == np.float64:
@@ -317,10 +322,19 @@ def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, monkeypatch, tp):
                 for L in Ls:
                     ye = oracle.dwt_lifting(x, sch, L)
                     y = host(W, W.dwt(dev(W, x), sch, L))
-                    assert "k_lift_axis_stream" in W.last_kernel()
+                    assert expect in W.last_kernel(), W.last_kernel()
                     assert np.array_equal(y, ye), (n, sname, L, dtype, np.abs(y - ye).max())
+                    xe = oracle.dwt_lifting(ye, sch, L, fw=False)
                     xr = host(W, W.idwt(dev(W, ye), sch, L))
-                    assert np.array_equal(xr, oracle.dwt_lifting(ye, sch, L, fw=False)), (n, sname, L, dtype, "inv")
+                    assert expect in W.last_kernel(), W.last_kernel()
+                    assert np.array_equal(xr, xe), (n, sname, L, dtype, "inv")
+                    if n == 512:            # in place: level 1 must not read what it is overwriting
+                        t = dev(W, x)
+                        W.dwt_(t, sch, L)
+                        assert np.array_equal(host(W, t), ye), (n, sname, L, dtype, "fwd in place")
+                        t = dev(W, ye)
+                        W.idwt_(t, sch, L)
+                        assert np.array_equal(host(W, t), xe), (n, sname, L, dtype, "inv in place")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

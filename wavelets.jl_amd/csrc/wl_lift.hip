@@ -1169,6 +1169,261 @@ __global__ void __launch_bounds__(64) k_lift_axis_stream(LiftAxisArgs<T> a)
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// One whole 2-D lifting level in a single pass over HBM (forward): the dim-2 pass is the register cascade of
+// k_lift_axis_stream (lanes own 4 consecutive rows, the wave marches along the columns); every finished column pair
+// (its s-column and its d-column) is then lifted along dim 1 ACROSS the lanes (2 row pairs per lane, neighbours by
+// DPP exactly as in k_lift1d_stream) and scattered to the four quadrants.  Strips overlap by one lane on each side.
+template <typename T>
+struct Lift2DArgs {
+    const T *src; int64_t lds;      // fw: block to transform          inv: coefficient array
+    T *y; int64_t ldy;              // fw: coefficient array           inv: result block
+    T *ll; int64_t ldl;             // fw: approximation quadrant destination (nullptr: y)   inv: approximation source (nullptr: src)
+    int64_t n0, n1;
+    int TP, nstrips, nchunks;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
+{
+    typedef Shape<ID> SH;
+    typedef Cascade<ID> CS;
+    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 1;
+    constexpr int VR = (64 - 2 * ML) * RPL;
+    static_assert(PF >= 2, "ring too small for this scheme");
+    const int lane = threadIdx.x;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
+    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t h0 = a.n0 >> 1, h1 = a.n1 >> 1;
+    const int64_t gi = (int64_t)strip * VR + (int64_t)(lane - ML) * RPL;      // first row of this lane (may wrap)
+    int64_t row = gi;
+    if (row < 0) row += a.n0;
+    if (row >= a.n0) row -= a.n0;
+    const bool valid = lane >= ML && lane < 64 - ML && gi < a.n0;
+    const int64_t kfirst = row >> 1, k0 = gi >> 1;
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
+    const T *base = a.src + row;
+    T rs[R][RPL], rd[R][RPL];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
+    const int64_t tau0 = p0 - VM;
+    auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
+        if (i < 0) { i %= h1; if (i < 0) i += h1; }
+        else if (i >= h1) i %= h1;
+        return i;
+    };
+    auto load_pair = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
+        const int64_t iw = wrapi(tau);
+        ldv_l<T, RPL>(base + (2 * iw) * a.lds, rs[slot]);
+        ldv_l<T, RPL>(base + (2 * iw + 1) * a.lds, rd[slot]);
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c) load_pair(tau0 + c, c % R);
+    T *const llp = a.ll ? a.ll : a.y;
+    const int64_t ldl = a.ll ? a.ldl : a.ldy;
+    auto step = [&](const int64_t t, const int u) __attribute__((always_inline)) {
+        const int64_t tau = tau0 + t;
+        load_pair(tau + PF, (u + PF) % R);
+#pragma unroll
+        for (int k = 0; k < SH::NS; ++k) {
+            const int upd = SH::S[k].upd, nc = SH::S[k].nc, ak = -SH::S[k].sh, Dk = CS::TAB.D[k];
+            const int slot = ((u - Dk) % R + R) % R;
+            const int64_t iw = wrapi(tau - Dk);
+            const bool inb = (iw + ak >= 0) && (iw + ak + nc - 1 <= h1 - 1);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                T o[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                    if (kk < nc) o[kk] = upd ? rs[((u - Dk + ak + kk) % R + R) % R][q] : rd[((u - Dk + ak + kk) % R + R) % R][q];
+                const T x = upd ? rd[slot][q] : rs[slot][q];
+                T acc = a.c[k][0] * o[0];
+                if (nc > 1) acc = acc + a.c[k][1] * o[1];
+                if (nc > 2) acc = acc + a.c[k][2] * o[2];
+                const T xin = x + acc;
+                T xb = x + a.c[k][0] * o[0];
+                if (nc > 1) xb = xb + a.c[k][1] * o[1];
+                if (nc > 2) xb = xb + a.c[k][2] * o[2];
+                const T res = inb ? xin : xb;
+                if (upd) rd[slot][q] = res; else rs[slot][q] = res;
+            }
+        }
+        const int64_t io = tau - DL;
+        if (io >= p0 && io < pend) {                      // uniform across the wave: the DPP exchanges below need every lane
+            const int slot = ((u - DL) % R + R) % R;
+            // dim-2 normalize!, then the dim-1 level on both columns (split -> steps -> normalize)
+            T s1[2], d1[2], s2[2], d2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] = rs[slot][2 * j] * a.norm1; d1[j] = rs[slot][2 * j + 1] * a.norm1;
+                s2[j] = rd[slot][2 * j] * a.norm2; d2[j] = rd[slot][2 * j + 1] * a.norm2;
+            }
+            lift_steps_lane<T, ID, 2>(s1, d1, a.c, kfirst, h0);
+            lift_steps_lane<T, ID, 2>(s2, d2, a.c, kfirst, h0);
+            if (valid) {
+                T o[2];
+                o[0] = s1[0] * a.norm1; o[1] = s1[1] * a.norm1;
+                stv_l<T, 2>(llp + k0 + io * ldl, o);
+                o[0] = d1[0] * a.norm2; o[1] = d1[1] * a.norm2;
+                stv_l<T, 2>(a.y + h0 + k0 + io * a.ldy, o);
+                o[0] = s2[0] * a.norm1; o[1] = s2[1] * a.norm1;
+                stv_l<T, 2>(a.y + k0 + (h1 + io) * a.ldy, o);
+                o[0] = d2[0] * a.norm2; o[1] = d2[1] * a.norm2;
+                stv_l<T, 2>(a.y + h0 + k0 + (h1 + io) * a.ldy, o);
+            }
+        }
+    };
+    const int64_t nstep = (pend - p0) + VM + DL;
+    for (int64_t t0 = 0; t0 < nstep; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u);
+    }
+}
+
+// The inverse: per step the raw coefficient column pair (left-half column p: approximation rows + detail rows, and
+// right-half column p) is loaded four steps ahead, both columns are reconstructed along dim 1 across the lanes
+// (normalize -> steps -> merge), and the results enter the dim-2 inverse cascade as its (s, d) pair.
+template <typename T, int ID>
+__global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
+{
+    typedef Shape<ID> SH;
+    typedef Cascade<ID> CS;
+    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = 4, ML = 1;
+    constexpr int VR = (64 - 2 * ML) * RPL;
+    static_assert(R - DL + CS::TAB.AMIN - 1 >= 1, "ring too small for this scheme");
+    const int lane = threadIdx.x;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
+    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t h0 = a.n0 >> 1, h1 = a.n1 >> 1;
+    const int64_t gi = (int64_t)strip * VR + (int64_t)(lane - ML) * RPL;
+    int64_t row = gi;
+    if (row < 0) row += a.n0;
+    if (row >= a.n0) row -= a.n0;
+    const bool valid = lane >= ML && lane < 64 - ML && gi < a.n0;
+    const int64_t kw = row >> 1;                           // this lane's first row pair (wrapped)
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
+    // left-half columns take their approximation rows from ll when given
+    const T *ls_base = (a.ll ? a.ll : a.src) + kw;
+    const int64_t ls_ld = a.ll ? a.ldl : a.lds;
+    const T *ld_base = a.src + h0 + kw;
+    const T *rs_base = a.src + h1 * a.lds + kw;
+    const T *rd_base = rs_base + h0;
+    T rs[R][RPL], rd[R][RPL];                              // dim-2 cascade rings (dim-1-reconstructed columns)
+    T qLs[R][2], qLd[R][2], qRs[R][2], qRd[R][2];          // raw coefficient columns in flight (slot = pair index mod R)
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
+    const int64_t tau0 = p0 - VM;
+    auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
+        if (i < 0) { i %= h1; if (i < 0) i += h1; }
+        else if (i >= h1) i %= h1;
+        return i;
+    };
+    auto load_raw = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
+        const int64_t iw = wrapi(tau);
+        ldv_l<T, 2>(ls_base + iw * ls_ld, qLs[slot]);
+        ldv_l<T, 2>(ld_base + iw * a.lds, qLd[slot]);
+        ldv_l<T, 2>(rs_base + iw * a.lds, qRs[slot]);
+        ldv_l<T, 2>(rd_base + iw * a.lds, qRd[slot]);
+    };
+#pragma unroll
+    for (int c = 0; c < PF; ++c) load_raw(tau0 + c, c % R);
+    auto step = [&](const int64_t t, const int u) __attribute__((always_inline)) {
+        const int64_t tau = tau0 + t;
+        // dim-1 reconstruction of the two raw columns of pair tau -> the cascade's (s, d) pair, dim-2 normalize! applied
+        {
+            T s1[2], d1[2], s2[2], d2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] = a.norm1 * qLs[u][j]; d1[j] = a.norm2 * qLd[u][j];
+                s2[j] = a.norm1 * qRs[u][j]; d2[j] = a.norm2 * qRd[u][j];
+            }
+            lift_steps_lane<T, ID, 2>(s1, d1, a.c, kw, h0);
+            lift_steps_lane<T, ID, 2>(s2, d2, a.c, kw, h0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                rs[u][2 * j] = a.norm1 * s1[j]; rs[u][2 * j + 1] = a.norm1 * d1[j];          // merge!, then normalize! of dim 2
+                rd[u][2 * j] = a.norm2 * s2[j]; rd[u][2 * j + 1] = a.norm2 * d2[j];
+            }
+        }
+        load_raw(tau + PF, (u + PF) % R);
+#pragma unroll
+        for (int k = 0; k < SH::NS; ++k) {
+            const int upd = SH::S[k].upd, nc = SH::S[k].nc, ak = -SH::S[k].sh, Dk = CS::TAB.D[k];
+            const int slot = ((u - Dk) % R + R) % R;
+            const int64_t iw = wrapi(tau - Dk);
+            const bool inb = (iw + ak >= 0) && (iw + ak + nc - 1 <= h1 - 1);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                T o[3] = {(T)0, (T)0, (T)0};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                    if (kk < nc) o[kk] = upd ? rs[((u - Dk + ak + kk) % R + R) % R][q] : rd[((u - Dk + ak + kk) % R + R) % R][q];
+                const T x = upd ? rd[slot][q] : rs[slot][q];
+                T acc = a.c[k][0] * o[0];
+                if (nc > 1) acc = acc + a.c[k][1] * o[1];
+                if (nc > 2) acc = acc + a.c[k][2] * o[2];
+                const T xin = x + acc;
+                T xb = x + a.c[k][0] * o[0];
+                if (nc > 1) xb = xb + a.c[k][1] * o[1];
+                if (nc > 2) xb = xb + a.c[k][2] * o[2];
+                const T res = inb ? xin : xb;
+                if (upd) rd[slot][q] = res; else rs[slot][q] = res;
+            }
+        }
+        const int64_t io = tau - DL;
+        if (valid && io >= p0 && io < pend) {
+            const int slot = ((u - DL) % R + R) % R;
+            stv_l<T, RPL>(a.y + gi + (2 * io) * a.ldy, rs[slot]);
+            stv_l<T, RPL>(a.y + gi + (2 * io + 1) * a.ldy, rd[slot]);
+        }
+    };
+    const int64_t nstep = (pend - p0) + VM + DL;
+    for (int64_t t0 = 0; t0 < nstep; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) step(t0 + u, u);
+    }
+}
+
+template <typename T, int ID>
+static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_count)
+{
+    constexpr int VR = 62 * 4;
+    a.nstrips = (int)((a.n0 + VR - 1) / VR);
+    const int64_t h1 = a.n1 >> 1;
+    int TP = 64;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 8) TP >>= 1;
+    const char *e = std::getenv("WL_LIFT_TP");
+    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    a.TP = TP;
+    a.nchunks = (int)((h1 + TP - 1) / TP);
+    hipLaunchKernelGGL((k_lift2d_inv<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int ID>
+static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_count)
+{
+    constexpr int VR = 62 * 4;
+    a.nstrips = (int)((a.n0 + VR - 1) / VR);
+    const int64_t h1 = a.n1 >> 1;
+    int TP = 64;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 8) TP >>= 1;
+    const char *e = std::getenv("WL_LIFT_TP");
+    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    a.TP = TP;
+    a.nchunks = (int)((h1 + TP - 1) / TP);
+    hipLaunchKernelGGL((k_lift2d_fwd<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 template <typename T, int ID, int FW, int RPL>
 static hipError_t launch_lift_axis_r(hipStream_t st, LiftAxisArgs<T> a, int64_t batch, int cu_count)
 {
@@ -1382,7 +1637,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     a.norm2 = ax.norm2 = sa.norm2 = sc.norm2;
     Strides3 full = {{1, ldy, ldy * n0}};
     auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
-    bool any_fast = false;
+    bool any_fast = false, fused = false;
 
     if (fw) {
         const T *cur = x;
@@ -1398,6 +1653,21 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 WL_E((launch_tail_lift2d<T, 1>(st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
                 any_fast = true;
                 break;
+            }
+            if (lines_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
+                al16(cur) && al16(llbuf) && cur != y) {      // (in place, level 1 reads y while writing it: two passes via T0)
+                // both passes of the level in one kernel: read the block once, write the four quadrants once
+                Lift2DArgs<T> q2;
+                for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                    for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = a.c[i][k];
+                q2.norm1 = a.norm1; q2.norm2 = a.norm2;
+                q2.src = cur; q2.lds = cur_ls; q2.y = y; q2.ldy = ldy; q2.ll = last ? (T *)nullptr : llbuf; q2.ldl = h; q2.n0 = n; q2.n1 = n;
+                if (id == 0) WL_E((launch_lift2d_fwd<T, 0>(st, q2, cu_count)));
+                else if (id == 2) WL_E((launch_lift2d_fwd<T, 2>(st, q2, cu_count)));
+                else WL_E((launch_lift2d_fwd<T, 4>(st, q2, cu_count)));
+                any_fast = true; fused = true;
+                cur = llbuf; cur_ls = h; pp ^= 1;
+                continue;
             }
             if (lines_ok(n) || short_lift_ok(n)) {
                 any_fast = true;
@@ -1454,6 +1724,20 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
+            if (lines_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
+                (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {   // (in place, level 1 writes y while reading it)
+                Lift2DArgs<T> q2;
+                for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                    for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = a.c[i][k];
+                q2.norm1 = a.norm1; q2.norm2 = a.norm2;
+                q2.src = x; q2.lds = ldy; q2.y = out; q2.ldy = ldo; q2.ll = const_cast<T *>(llsrc); q2.ldl = ll_ls; q2.n0 = n; q2.n1 = n;
+                if (id == 1) WL_E((launch_lift2d_inv<T, 1>(st, q2, cu_count)));
+                else if (id == 3) WL_E((launch_lift2d_inv<T, 3>(st, q2, cu_count)));
+                else WL_E((launch_lift2d_inv<T, 5>(st, q2, cu_count)));
+                any_fast = true; fused = true;
+                llsrc = out; ll_ls = ldo; pp ^= 1;
+                continue;
+            }
             if (lines_ok(n) || short_lift_ok(n)) {
                 any_fast = true;
                 // columns: merged column j -> T0[:, j]
@@ -1487,7 +1771,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
         }
     }
     *handled = 1;
-    if (kernel_name) *kernel_name = any_fast ? "k_lift_axis_stream+lines" : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
+    if (kernel_name) *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : "k_lift_axis_stream+lines") : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
     return WL_OK;
 }
 

@@ -1637,6 +1637,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     a.norm2 = ax.norm2 = sa.norm2 = sc.norm2;
     Strides3 full = {{1, ldy, ldy * n0}};
     auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
+    auto fused_ok = [](int64_t n) { return n >= 128 && (n % 8) == 0; };     // k_lift2d_*: a lane's 4 rows wrap at most once
     bool any_fast = false, fused = false;
 
     if (fw) {
@@ -1654,7 +1655,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 any_fast = true;
                 break;
             }
-            if (lines_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
+            if (fused_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
                 al16(cur) && al16(llbuf) && cur != y) {      // (in place, level 1 reads y while writing it: two passes via T0)
                 // both passes of the level in one kernel: read the block once, write the four quadrants once
                 Lift2DArgs<T> q2;
@@ -1724,7 +1725,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
-            if (lines_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
+            if (fused_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
                 (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {   // (in place, level 1 writes y while reading it)
                 Lift2DArgs<T> q2;
                 for (int i = 0; i < LIFT_FAST_STEPS; ++i)

@@ -463,10 +463,14 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
     WL_DISPATCH_FA(F, {
         // planes: axis 3 on the (n0*n1) x n2 matrix
         *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, n0 * n1, 0, n0 * n1, n2, 1, cu_count);
+        // rows + columns of every plane in ONE launch when the planes are big enough for the fused 2-D level kernel
+        bool planes = false;
+        if (*err == hipSuccess && std::getenv("WL_NO_PLANES") == nullptr)
+            planes = fwd2d_planes<T>(st, taps, T0, y, y1, y2, ll, n0, n1, n2, (int)h2, cu_count, err);
         // rows: axis 2 on n2 matrices of n0 x n1
-        if (*err == hipSuccess) *err = launch_axis<T, FF, 1>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
+        if (!planes && *err == hipSuccess) *err = launch_axis<T, FF, 1>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
         // columns: short lines; the low-low corner sends its approximation to ll
-        if (*err == hipSuccess) {
+        if (!planes && *err == hipSuccess) {
             ShortArgs<T, FF> s;
             s.a = T1; s.a2 = n0; s.a3 = n0 * n1; s.b = nullptr; s.b2 = s.b3 = 0;
             s.o0 = y; s.o02 = y1; s.o03 = y2; s.o1 = y + h0; s.o12 = y1; s.o13 = y2;
@@ -494,9 +498,13 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
         return false;
     bool ok = false;
     WL_DISPATCH_FA(F, {
+        // columns + rows of every plane in ONE launch when the planes are big enough for the fused 2-D inverse kernel
+        bool planes = false;
+        if (std::getenv("WL_NO_PLANES") == nullptr)
+            planes = inv2d_planes<T>(st, taps, x, x1, x2, llsrc, T1, n0, n1, n2, (int)h2, cu_count, err);
         // columns first (transforms_filter.jl:269-273): merged lines into T0 (dense box); the low-low corner takes its
         // approximation from the deeper reconstruction
-        {
+        if (!planes && *err == hipSuccess) {
             ShortArgs<T, FF> s;
             s.a = x; s.a2 = x1; s.a3 = x2; s.b = x + h0; s.b2 = x1; s.b3 = x2;
             s.o0 = T0; s.o02 = n0; s.o03 = n0 * n1; s.o1 = nullptr; s.o12 = s.o13 = 0;
@@ -504,7 +512,7 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
             *err = launch_short<T, FF, 0>(st, taps, s, (int)n0, (int)n1, n2);
         }
         // rows: axis 2 on n2 matrices
-        if (*err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
+        if (!planes && *err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
         // planes: axis 3
         if (*err == hipSuccess) *err = launch_axis<T, FF, 0>(st, taps, T1, n0 * n1, 0, out, o2, 0, n0 * n1, n2, 1, cu_count);
         ok = true;

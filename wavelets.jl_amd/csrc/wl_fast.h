@@ -53,6 +53,14 @@ template <typename T>
 bool long_axis_level(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t lds, T *dst, int64_t ldd,
                      int64_t R, int64_t C, int cu_count, hipError_t *err);
 
+// The fused 2-D level kernels on a batch of planes (two of the three passes of a 3-D level in one launch).
+template <typename T>
+bool fwd2d_planes(hipStream_t st, const Taps<T> &taps, const T *src, T *y, int64_t y1, int64_t y2, T *ll, int64_t n0, int64_t n1,
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err);
+template <typename T>
+bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err);
+
 // 3-D lifting transform of a cube (2^k <= 512 per side) through the axis-streaming and short-line kernels.
 template <typename T>
 int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, const T *x,

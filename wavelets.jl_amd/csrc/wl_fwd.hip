@@ -263,6 +263,9 @@ struct Fwd2DArgs {
     int TJ;                         // input columns per chunk (even)
     int nt;                         // bit 2: walk this XCD's range backwards
     int nstrips, nchunks;
+    // batch of independent blocks (blockIdx.y; the planes of a 3-D level): element strides; only the first nll
+    // blocks send their approximation quadrant to ll, the others write it into y
+    int64_t bs_src, bs_y, bs_ll; int nll;
     TapsF<T, F> tp;
 };
 
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
     const int64_t j0 = (int64_t)chunk * a.TJ;
     const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
     const int S = (int)((jend - j0) >> 1);
-    const T *base = a.src + row;
+    const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + row;
 
     // Column ring of R = 16 register slots: input column c (relative to j0) lives in slot c % R.
     // Step t consumes columns 2t .. 2t+F-1 and refills the two slots freed by step t-1 with
@@ -320,9 +323,10 @@ __global__ void __launch_bounds__(64) k_fwd2d_stream(Fwd2DArgs<T, F> a)
         vload<T, RPL>(base + jc * a.lds, ring[c]);
     }
 
-    T *const yl = a.y + ko;
-    T *const llp = (a.ll != nullptr) ? (a.ll + ko) : yl;
-    const int64_t ldl = (a.ll != nullptr) ? a.ldll : a.ldy;
+    T *const yl = a.y + (int64_t)blockIdx.y * a.bs_y + ko;
+    const bool to_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
+    T *const llp = to_ll ? (a.ll + (int64_t)blockIdx.y * a.bs_ll + ko) : yl;
+    const int64_t ldl = to_ll ? a.ldll : a.ldy;
     const int64_t kbase = j0 >> 1;
 
     // u = t % U is a compile-time constant at every call site
@@ -1124,17 +1128,19 @@ static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src,
 
 template <typename T, int F, int RPL>
 static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1, const T *src, int64_t lds,
-                                 T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+                                 T *y, int64_t ldy, T *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
+                                 int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1)
 {
     constexpr int VR = 64 * RPL - 16;
     Fwd2DArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
+    a.bs_src = bs_src; a.bs_y = bs_y; a.bs_ll = bs_ll; a.nll = nll;
     a.nstrips = (int)((ms + VR - 1) / VR);
     a.nt = (!lvl1 && env_int("WL_REVERSE", 1)) ? 4 : 0;
     int TJ = env_int("WL_TJ", 128);
     // smaller levels: trade chunk length for parallelism (>= ~8 waves per CU while chunks stay >= 32
     // columns, >= 2 per CU down to 16 columns); every chunk length stays a multiple of 16
-    auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
+    auto nwaves = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj) * nbatch; };
     const int wpc = env_int("WL_WAVES_PER_CU", 8);
     while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;
     while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * env_int("WL_WAVES_MIN", 8)) TJ >>= 1;
@@ -1143,8 +1149,8 @@ static hipError_t launch_fwd2d_r(hipStream_t st, const Taps<T> &taps, bool lvl1,
     a.tp = shrink<T, F>(taps);
     const unsigned wpb = 1;      // waves per workgroup (4-wave workgroups measured no faster)
     const unsigned nwg = ((unsigned)(a.nstrips * a.nchunks) + wpb - 1) / wpb;
-    if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg), dim3(64 * wpb), 0, st, a);
-    else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg), dim3(64 * wpb), 0, st, a);
+    if (lvl1) hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 1>), dim3(nwg, (unsigned)nbatch), dim3(64 * wpb), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd2d_stream<T, F, RPL, 0>), dim3(nwg, (unsigned)nbatch), dim3(64 * wpb), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1485,6 +1491,30 @@ template bool fast_lines_fwd_level<float>(hipStream_t, const Taps<float> &, cons
                                           int64_t, int64_t, int64_t, int, hipError_t *);
 template bool fast_lines_fwd_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, double *, int64_t,
                                            double *, int64_t, int64_t, int64_t, int, hipError_t *);
+
+// The fused 2-D level kernel on a batch of independent planes (the dim-2 + dim-1 passes of a 3-D level): plane p of
+// `src` (n0 x n1, dense, stride n0*n1) -> plane p of y (strides y1, y2); the first nll planes send their approximation
+// quadrant to plane p of ll (dense h0 x h1), the others write it into y.
+template <typename T>
+bool fwd2d_planes(hipStream_t st, const Taps<T> &taps, const T *src, T *y, int64_t y1, int64_t y2, T *ll, int64_t n0, int64_t n1,
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    if ((F % 2) != 0 || F > 10 || n0 < 64 * VEC || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 ||
+        !aligned16(src) || !aligned16(y) || (ll && !aligned16(ll)) || nplanes > 65535)
+        return false;
+    bool ok = false;
+    WL_DISPATCH_F(F, *err = launch_fwd2d_r<T, FF, VEC>(st, taps, false, src, n0, y, y1, ll, n0 >> 1, n0, n1, cu_count, nplanes, n0 * n1, y2,
+                                                        (n0 >> 1) * (n1 >> 1), nll);
+                  ok = true);
+    return ok;
+}
+template bool fwd2d_planes<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, float *, int64_t, int64_t,
+                                  int64_t, int, int, hipError_t *);
+template bool fwd2d_planes<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, double *, int64_t,
+                                   int64_t, int64_t, int, int, hipError_t *);
 
 template int filter_fwd_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);

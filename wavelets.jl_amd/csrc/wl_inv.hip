@@ -648,6 +648,9 @@ struct Inv2DArgs {
     int64_t n0, n1;                 // OUTPUT block extents
     int TP;                         // output column pairs per chunk (multiple of 4)
     int nstrips, nchunks;
+    // batch of independent blocks (blockIdx.y; the planes of a 3-D level): element strides; only the first nll
+    // blocks take their approximation quadrant from ll
+    int64_t bs_x, bs_ll, bs_dst; int nll;
     TapsI<T, F> tp;
 };
 
@@ -692,10 +695,12 @@ __global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
     const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
     const int S = (int)(pend - p0);                  // multiple of 4
     // left-half columns: approximation rows from ll (when given), detail rows from x; right half: both from x
-    const T *ls_base = (a.ll ? a.ll : a.x) + kw;
-    const int64_t ls_ld = a.ll ? a.ldl : a.ldx;
-    const T *ld_base = a.x + h0 + kw;
-    const T *rs_base = a.x + h1 * a.ldx + kw;
+    const T *xb = a.x + (int64_t)blockIdx.y * a.bs_x;
+    const bool from_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
+    const T *ls_base = (from_ll ? a.ll + (int64_t)blockIdx.y * a.bs_ll : xb) + kw;
+    const int64_t ls_ld = from_ll ? a.ldl : a.ldx;
+    const T *ld_base = xb + h0 + kw;
+    const T *rs_base = xb + h1 * a.ldx + kw;
     const T *rd_base = rs_base + h0;
     T rLs[R][PPL], rLd[R][PPL], rRs[R][PPL], rRd[R][PPL];      // raw columns in flight
     T iS[R][2 * PPL], iD[R][2 * PPL];                           // dim-1-reconstructed columns
@@ -720,7 +725,7 @@ __global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
     }
 #pragma unroll
     for (int c = 0; c < R; ++c) load_raw(c, c);
-    T *out = a.dst + 2 * k0;
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + 2 * k0;
     auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
         inv_column<T, F, PPL>(rLs[u], rLd[u], a.tp, iS[u]);
         inv_column<T, F, PPL>(rRs[u], rRd[u], a.tp, iD[u]);
@@ -750,19 +755,21 @@ __global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
 
 template <typename T, int F, int PPL>
 static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
-                               T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+                               T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count,
+                               int64_t nbatch = 1, int64_t bs_x = 0, int64_t bs_ll = 0, int64_t bs_dst = 0, int nll = 1)
 {
     constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL;
     Inv2DArgs<T, F> a;
     a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
+    a.bs_x = bs_x; a.bs_ll = bs_ll; a.bs_dst = bs_dst; a.nll = nll;
     const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
     a.nstrips = (int)((h0 + VP - 1) / VP);
     int TP = i_env("WL_INV2D_TP", 64);
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 16) TP >>= 1;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 16) TP >>= 1;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     a.tp = shrink_i<T, F>(taps);
-    hipLaunchKernelGGL((k_inv2d_stream<T, F, PPL>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_inv2d_stream<T, F, PPL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -987,6 +994,30 @@ template bool fast_lines_inv_level<float>(hipStream_t, const Taps<float> &, cons
                                           float *, int64_t, int64_t, int64_t, int, hipError_t *);
 template bool fast_lines_inv_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, const double *, int64_t,
                                            double *, int64_t, int64_t, int64_t, int, hipError_t *);
+
+// The fused 2-D inverse level kernel on a batch of planes (the dim-1 + dim-2 passes of a 3-D inverse level): plane p of
+// x (strides x1, x2; the first nll planes take their approximation quadrant from plane p of ll, dense h0 x h1)
+// -> plane p of dst (dense n0 x n1).
+template <typename T>
+bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int F = taps.F;
+    *err = hipSuccess;
+    if ((F % 2) != 0 || F > 10 || n0 < 256 || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 ||
+        !i_al16(x) || !i_al16(dst) || (ll && !i_al16(ll)) || nplanes > 65535)
+        return false;
+    bool ok = false;
+    WL_DISPATCH_FI(F, *err = launch_inv2d<T, FF, 2>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, nplanes, x2,
+                                                     (n0 >> 1) * (n1 >> 1), n0 * n1, nll);
+                   ok = true);
+    return ok;
+}
+template bool inv2d_planes<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *, int64_t,
+                                  int64_t, int64_t, int, int, hipError_t *);
+template bool inv2d_planes<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *, int64_t,
+                                   int64_t, int64_t, int, int, hipError_t *);
 
 template int filter_inv_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);

@@ -1181,6 +1181,8 @@ struct Lift2DArgs {
     T *ll; int64_t ldl;             // fw: approximation quadrant destination (nullptr: y)   inv: approximation source (nullptr: src)
     int64_t n0, n1;
     int TP, nstrips, nchunks;
+    // batch of independent blocks (blockIdx.y: the planes of a 3-D level); only the first nll blocks use ll
+    int64_t bs_src, bs_y, bs_ll; int nll;
     T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
     T norm1, norm2;
 };
@@ -1205,7 +1207,7 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
     const int64_t kfirst = row >> 1, k0 = gi >> 1;
     const int64_t p0 = (int64_t)chunk * a.TP;
     const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
-    const T *base = a.src + row;
+    const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + row;
     T rs[R][RPL], rd[R][RPL];
 #pragma unroll
     for (int i = 0; i < R; ++i)
@@ -1224,8 +1226,10 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
     };
 #pragma unroll
     for (int c = 0; c < PF; ++c) load_pair(tau0 + c, c % R);
-    T *const llp = a.ll ? a.ll : a.y;
-    const int64_t ldl = a.ll ? a.ldl : a.ldy;
+    T *const yb = a.y + (int64_t)blockIdx.y * a.bs_y;
+    const bool to_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
+    T *const llp = to_ll ? a.ll + (int64_t)blockIdx.y * a.bs_ll : yb;
+    const int64_t ldl = to_ll ? a.ldl : a.ldy;
     auto step = [&](const int64_t t, const int u) __attribute__((always_inline)) {
         const int64_t tau = tau0 + t;
         load_pair(tau + PF, (u + PF) % R);
@@ -1270,11 +1274,11 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
                 o[0] = s1[0] * a.norm1; o[1] = s1[1] * a.norm1;
                 stv_l<T, 2>(llp + k0 + io * ldl, o);
                 o[0] = d1[0] * a.norm2; o[1] = d1[1] * a.norm2;
-                stv_l<T, 2>(a.y + h0 + k0 + io * a.ldy, o);
+                stv_l<T, 2>(yb + h0 + k0 + io * a.ldy, o);
                 o[0] = s2[0] * a.norm1; o[1] = s2[1] * a.norm1;
-                stv_l<T, 2>(a.y + k0 + (h1 + io) * a.ldy, o);
+                stv_l<T, 2>(yb + k0 + (h1 + io) * a.ldy, o);
                 o[0] = d2[0] * a.norm2; o[1] = d2[1] * a.norm2;
-                stv_l<T, 2>(a.y + h0 + k0 + (h1 + io) * a.ldy, o);
+                stv_l<T, 2>(yb + h0 + k0 + (h1 + io) * a.ldy, o);
             }
         }
     };
@@ -1309,11 +1313,14 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
     const int64_t p0 = (int64_t)chunk * a.TP;
     const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
     // left-half columns take their approximation rows from ll when given
-    const T *ls_base = (a.ll ? a.ll : a.src) + kw;
-    const int64_t ls_ld = a.ll ? a.ldl : a.lds;
-    const T *ld_base = a.src + h0 + kw;
-    const T *rs_base = a.src + h1 * a.lds + kw;
+    const T *xb = a.src + (int64_t)blockIdx.y * a.bs_src;
+    const bool from_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
+    const T *ls_base = (from_ll ? a.ll + (int64_t)blockIdx.y * a.bs_ll : xb) + kw;
+    const int64_t ls_ld = from_ll ? a.ldl : a.lds;
+    const T *ld_base = xb + h0 + kw;
+    const T *rs_base = xb + h1 * a.lds + kw;
     const T *rd_base = rs_base + h0;
+    T *const yb = a.y + (int64_t)blockIdx.y * a.bs_y;
     T rs[R][RPL], rd[R][RPL];                              // dim-2 cascade rings (dim-1-reconstructed columns)
     T qLs[R][2], qLd[R][2], qRs[R][2], qRd[R][2];          // raw coefficient columns in flight (slot = pair index mod R)
 #pragma unroll
@@ -1381,8 +1388,8 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
         const int64_t io = tau - DL;
         if (valid && io >= p0 && io < pend) {
             const int slot = ((u - DL) % R + R) % R;
-            stv_l<T, RPL>(a.y + gi + (2 * io) * a.ldy, rs[slot]);
-            stv_l<T, RPL>(a.y + gi + (2 * io + 1) * a.ldy, rd[slot]);
+            stv_l<T, RPL>(yb + gi + (2 * io) * a.ldy, rs[slot]);
+            stv_l<T, RPL>(yb + gi + (2 * io + 1) * a.ldy, rd[slot]);
         }
     };
     const int64_t nstep = (pend - p0) + VM + DL;
@@ -1393,34 +1400,34 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 }
 
 template <typename T, int ID>
-static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_count)
+static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_count, int64_t nbatch = 1)
 {
     constexpr int VR = 62 * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 8) TP >>= 1;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
     const char *e = std::getenv("WL_LIFT_TP");
     if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    hipLaunchKernelGGL((k_lift2d_inv<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_lift2d_inv<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
 template <typename T, int ID>
-static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_count)
+static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_count, int64_t nbatch = 1)
 {
     constexpr int VR = 62 * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 8) TP >>= 1;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
     const char *e = std::getenv("WL_LIFT_TP");
     if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    hipLaunchKernelGGL((k_lift2d_fwd<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_lift2d_fwd<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1663,6 +1670,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = a.c[i][k];
                 q2.norm1 = a.norm1; q2.norm2 = a.norm2;
                 q2.src = cur; q2.lds = cur_ls; q2.y = y; q2.ldy = ldy; q2.ll = last ? (T *)nullptr : llbuf; q2.ldl = h; q2.n0 = n; q2.n1 = n;
+                q2.bs_src = q2.bs_y = q2.bs_ll = 0; q2.nll = 1;
                 if (id == 0) WL_E((launch_lift2d_fwd<T, 0>(st, q2, cu_count)));
                 else if (id == 2) WL_E((launch_lift2d_fwd<T, 2>(st, q2, cu_count)));
                 else WL_E((launch_lift2d_fwd<T, 4>(st, q2, cu_count)));
@@ -1732,6 +1740,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = a.c[i][k];
                 q2.norm1 = a.norm1; q2.norm2 = a.norm2;
                 q2.src = x; q2.lds = ldy; q2.y = out; q2.ldy = ldo; q2.ll = const_cast<T *>(llsrc); q2.ldl = ll_ls; q2.n0 = n; q2.n1 = n;
+                q2.bs_src = q2.bs_y = q2.bs_ll = 0; q2.nll = 1;
                 if (id == 1) WL_E((launch_lift2d_inv<T, 1>(st, q2, cu_count)));
                 else if (id == 3) WL_E((launch_lift2d_inv<T, 3>(st, q2, cu_count)));
                 else WL_E((launch_lift2d_inv<T, 5>(st, q2, cu_count)));
@@ -1814,6 +1823,20 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
             } else {       // (not reached: level 1 reads the dense cube, deeper levels the dense approximation buffer)
                 return WL_OK;
             }
+            if (n >= 128 && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0) {
+                // rows + columns of every plane in one launch (fused 2-D level kernel batched over the planes)
+                Lift2DArgs<T> q2;
+                for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                    for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = ax.c[i][k];
+                q2.norm1 = ax.norm1; q2.norm2 = ax.norm2;
+                q2.src = w.T0; q2.lds = n; q2.y = y; q2.ldy = y1; q2.ll = last ? (T *)nullptr : llbuf; q2.ldl = h; q2.n0 = n; q2.n1 = n;
+                q2.bs_src = n * n; q2.bs_y = y2; q2.bs_ll = h * h; q2.nll = (int)h;
+                if (id == 0) WL_E((launch_lift2d_fwd<T, 0>(st, q2, cu_count, n)));
+                else if (id == 2) WL_E((launch_lift2d_fwd<T, 2>(st, q2, cu_count, n)));
+                else WL_E((launch_lift2d_fwd<T, 4>(st, q2, cu_count, n)));
+                cur = llbuf; c1 = h; c2 = h * h; pp ^= 1;
+                continue;
+            }
             // rows (dim 2): n matrices of n x n
             ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
             WL_E((launch_lift_axis_id<T, 1>(id, st, ax, n, cu_count)));
@@ -1831,6 +1854,21 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
         for (int l = L; l >= 1; --l) {
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
+            bool planes = false;
+            if (n >= 128 && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0) {
+                // columns + rows of every plane in one launch
+                Lift2DArgs<T> q2;
+                for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                    for (int k = 0; k < WL_MAX_NCOEF; ++k) q2.c[i][k] = ax.c[i][k];
+                q2.norm1 = ax.norm1; q2.norm2 = ax.norm2;
+                q2.src = x; q2.lds = y1; q2.y = w.T1; q2.ldy = n; q2.ll = const_cast<T *>(llsrc); q2.ldl = h; q2.n0 = n; q2.n1 = n;
+                q2.bs_src = y2; q2.bs_y = n * n; q2.bs_ll = h * h; q2.nll = (int)h;
+                if (id == 1) WL_E((launch_lift2d_inv<T, 1>(st, q2, cu_count, n)));
+                else if (id == 3) WL_E((launch_lift2d_inv<T, 3>(st, q2, cu_count, n)));
+                else WL_E((launch_lift2d_inv<T, 5>(st, q2, cu_count, n)));
+                planes = true;
+            }
+            if (!planes) {
             // columns first: merged lines into T0 (dense n^3); the low-low corner reads the deeper reconstruction
             sa.o1 = nullptr; sa.o12 = sa.o13 = 0;
             sa.a = x; sa.a2 = y1; sa.a3 = y2; sa.b = x + h; sa.b2 = y1; sa.b3 = y2;
@@ -1840,6 +1878,7 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
             // rows (dim 2)
             ax.src = w.T0; ax.lds = n; ax.bs_src = n * n; ax.dst = w.T1; ax.ldd = n; ax.bs_dst = n * n; ax.R = n; ax.C = n;
             WL_E((launch_lift_axis_id<T, 0>(id, st, ax, n, cu_count)));
+            }
             // planes (dim 3); the result of level 1 goes to y (dense cube), deeper ones to the dense n^3 buffer
             ax.src = w.T1; ax.lds = n * n; ax.bs_src = 0; ax.dst = out; ax.ldd = (l == 1) ? y2 : n * n; ax.bs_dst = 0; ax.R = n * n; ax.C = n;
             WL_E((launch_lift_axis_id<T, 0>(id, st, ax, 1, cu_count)));

@@ -142,3 +142,23 @@ def test_threshold_and_modwt_host_logic(W):
             call()
     with pytest.raises(TypeError):
         W.modwt(x, W.wavelet(W.WT.cdf97, W.WT.Lifting))                                  # MethodError in the reference
+
+
+def test_util_helpers(W):
+    """src/Util mirror: dyadic indexing, up/downsampling, wcount, the test signals (test/util.jl style checks)."""
+    assert W.dyadicdetailindex(3, 2) == 10 and list(W.dyadicdetailrange(2)) == [5, 6, 7, 8] and list(W.dyadicscalingrange(2)) == [1, 2, 3, 4]
+    assert W.dyadicdetailn(5) == 32 and W.maxdyadiclevel(64) == 5 and W.tl2dyadiclevel(64, 2) == 4 and W.dyadiclevel2tl(64, 4) == 2
+    assert np.array_equal(W.mirror([1.0, 2.0, 3.0, 4.0]), [1.0, -2.0, 3.0, -4.0])
+    x = np.array([1.0, 2.0, 3.0])
+    assert np.array_equal(W.upsample(x), [1, 0, 2, 0, 3, 0]) and np.array_equal(W.upsample(x, 1), [0, 1, 0, 2, 0, 3])
+    y = np.arange(1.0, 9.0)
+    assert np.array_equal(W.downsample(y), [1, 3, 5, 7]) and np.array_equal(W.downsample(y, 1), [2, 4, 6, 8])
+    assert np.array_equal(W.downsample(W.upsample(x)), x)
+    v = np.array([5.0, -0.1, 0.3, -2.0, 0.0, 0.2, 1.0, -1.0])
+    assert W.wcount(v) == 8 and W.wcount(v, 0.25) == 5 and W.wcount(v, 0.25, level=1) == 4 and W.wcount(v.reshape(2, 4), 1.0) == 4
+    for ft in ("Blocks", "Bumps", "HeaviSine", "Doppler"):
+        f = W.testfunction(256, ft)
+        assert f.shape == (256,) and f.dtype == np.float64 and np.all(np.isfinite(f))
+    assert W.testfunction(4, "Doppler")[0] == 0.0 and abs(W.testfunction(1024, "Blocks").max() - 5.2) < 1e-12
+    with pytest.raises(ValueError):
+        W.testfunction(8, "nope")

@@ -13,7 +13,9 @@ from . import wt as WT
 from . import util as Util
 from .wt import wavelet, OrthoFilter, GLS
 from .util import (maxtransformlevels, sufficientpoweroftwo, detailindex, detailrange, detailn,
-                   ndyadicscales, maketree, isvalidtree, iscube, isdyadic)
+                   ndyadicscales, maketree, isvalidtree, iscube, isdyadic,
+                   dyadicdetailindex, dyadicdetailrange, dyadicscalingrange, dyadicdetailn, maxdyadiclevel, tl2dyadiclevel,
+                   dyadiclevel2tl, mirror, upsample, downsample, wcount, testfunction)
 from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwtc, dwtc_, idwtc_, wpt, iwpt, wpt_, iwpt_,
                          to_device, to_host, similar, julia_layout, is_julia_layout,
                          reserve_workspace, set_kernel_path, last_kernel,
@@ -28,6 +30,8 @@ __all__ = [
     "dwt", "idwt", "dwt_", "idwt_", "dwt_oop_", "idwt_oop_", "dwtc", "idwtc", "dwtc_", "idwtc_", "wpt", "iwpt", "wpt_", "iwpt_",
     "maxtransformlevels", "sufficientpoweroftwo", "detailindex", "detailrange", "detailn",
     "ndyadicscales", "maketree", "isvalidtree", "iscube", "isdyadic",
+    "dyadicdetailindex", "dyadicdetailrange", "dyadicscalingrange", "dyadicdetailn", "maxdyadiclevel", "tl2dyadiclevel",
+    "dyadiclevel2tl", "mirror", "upsample", "downsample", "wcount", "testfunction",
     "to_device", "to_host", "similar", "julia_layout", "is_julia_layout",
     "reserve_workspace", "set_kernel_path", "last_kernel",
     "DimensionMismatch", "ArgumentError", "HIPError",

@@ -91,3 +91,92 @@ def isvalidtree(x, b) -> bool:
         if not b[i - 1] and (b[2 * i - 1] or b[2 * i]):
             return False
     return True
+
+
+# ---- dyadic indexing (dyadic.jl:3-20; 1-based indices / ranges as in the reference) ---------------------
+def dyadicdetailindex(j: int, i: int) -> int:
+    return 2 ** j + i
+
+
+def dyadicdetailrange(j: int) -> range:
+    return range(2 ** j + 1, 2 ** (j + 1) + 1)
+
+
+def dyadicscalingrange(j: int) -> range:
+    return range(1, 2 ** j + 1)
+
+
+def dyadicdetailn(j: int) -> int:
+    return 2 ** j
+
+
+def maxdyadiclevel(x) -> int:
+    return ndyadicscales(x) - 1
+
+
+def tl2dyadiclevel(x, L: int) -> int:
+    n = len(x) if hasattr(x, "__len__") else int(x)
+    return ndyadicscales(n) - int(L)
+
+
+dyadiclevel2tl = tl2dyadiclevel
+
+
+# ---- small vector helpers (util_main.jl:30-81); numpy arrays or device tensors ---------------------------
+def mirror(f):
+    """f .* (-1).^(0:length(f)-1)"""
+    f = np.asarray(f)
+    return f * (-1.0) ** np.arange(len(f))
+
+
+def upsample(x, sw: int = 0):
+    """zero-stuffing: y[2i + sw] = x[i] (0-based i)"""
+    assert sw in (0, 1)
+    if hasattr(x, "new_zeros"):            # torch tensor (host or device)
+        y = x.new_zeros(2 * x.shape[0])
+    else:
+        x = np.asarray(x)
+        y = np.zeros(2 * len(x), dtype=x.dtype)
+    y[1 - 1 + sw::2] = x
+    return y
+
+
+def downsample(x, sw: int = 0):
+    """y[i] = x[2i + sw] (0-based i)"""
+    assert sw in (0, 1)
+    assert len(x) % 2 == 0
+    return x[sw::2].clone() if hasattr(x, "clone") else np.asarray(x)[sw::2].copy()
+
+
+def wcount(x, t=0, level: int = -1) -> int:
+    """number of coefficients with abs(x) >= t, for vectors excluding the levels below `level` (level -1 is x[1])"""
+    assert level >= -1
+    if getattr(x, "ndim", 1) == 1 and level >= 0:
+        x = x[2 ** level:]
+    if hasattr(x, "abs") and hasattr(x, "device"):
+        return int((x.abs() >= t).sum().item())
+    return int((np.abs(np.asarray(x)) >= t).sum())
+
+
+def testfunction(n: int, ft: str) -> np.ndarray:
+    """The Donoho-Johnstone test signals sampled at t = 0, 1/n, ..., (n-1)/n (util_main.jl:378-420), Float64."""
+    assert n >= 1
+    t = np.arange(n, dtype=np.float64) / n
+    if ft in ("Blocks", "Bumps"):
+        tj = np.array([0.1, 0.13, 0.15, 0.23, 0.25, 0.4, 0.44, 0.65, 0.76, 0.78, 0.81])
+        f = np.zeros(n)
+        if ft == "Blocks":
+            hj = [4, -5, 3, -4, 5, -4.2, 2.1, 4.3, -3.1, 2.1, -4.2]
+            for h, tk in zip(hj, tj):                      # accumulated term by term, in the reference's order
+                f = f + h * (1 + np.sign(t - tk)) / 2
+        else:
+            hj = [4, 5, 3, 4, 5, 4.2, 2.1, 4.3, 3.1, 5.1, 4.2]
+            wj = [0.005, 0.005, 0.006, 0.01, 0.01, 0.03, 0.01, 0.01, 0.005, 0.008, 0.005]
+            for h, tk, wk in zip(hj, tj, wj):
+                f = f + h / (1 + np.abs((t - tk) / wk)) ** 4
+        return f
+    if ft == "HeaviSine":
+        return 4 * np.sin(4 * np.pi * t) - np.sign(t - 0.3) - np.sign(0.72 - t)
+    if ft == "Doppler":
+        return np.sqrt(t * (1 - t)) * np.sin(2 * np.pi * 1.05 / (t + 0.05))
+    raise ValueError("unknown test function")          # ArgumentError in the reference

@@ -3,7 +3,9 @@
  *
  * MI355X-native (CDNA4 / gfx950, hand-written HIP) backend for the one data-parallel
  * hot path of JuliaDSP/Wavelets.jl v0.10.1: the periodic orthogonal filter-bank
- * DWT/IDWT and the lifting DWT/IDWT behind dwt / idwt / dwt! / idwt! / wpt! / iwpt!.
+ * DWT/IDWT and the lifting DWT/IDWT behind dwt / idwt / dwt! / idwt! / wpt! / iwpt!,
+ * plus the callers on either side of that path: modwt / imodwt,
+ * threshold!, the median / mad! noise estimate and the array helpers of denoise.
  *
  * The reference has NO native interface (it is 100 % Julia): the seam this ABI
  * plugs into is the internal `_dwt!` / `_wpt!` method table that the public API

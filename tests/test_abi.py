@@ -53,3 +53,15 @@ def test_no_device_is_loud(W):
     out = C.c_void_p()
     assert lib.wl_ctx_create(0, C.byref(out)) == -13      # WL_ENODEVICE, never a CPU fallback
     assert not out.value
+
+
+def test_c_program_links_and_runs(W, tmp_path):
+    """A C99 program (tests/abi_demo.c) built with plain gcc against the header and the shared library."""
+    exe = str(tmp_path / "abi_demo")
+    libdir = os.path.dirname(W._lib.LIB_PATH)
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_demo.c"),
+                        "-L", libdir, "-lwavelets_mi355x", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout.decode(), r.stderr.decode())
+    assert b"abi_demo:" in r.stdout

@@ -1,5 +1,6 @@
-// wl_fast.h -- forward filter-bank level loop with fast-path dispatch (wl_fwd.hip).
-// Every fast kernel must produce results bit-identical to the generic kernels.
+// wl_fast.h -- entry points of the fast-path translation units (wl_fwd.hip, wl_inv.hip, wl_lift.hip, wl_axis.hip) used by
+// the ABI layer (wl_api.hip) and by each other.  Every fast kernel must produce results bit-identical to the generic
+// kernels (wl_generic.hip).
 #pragma once
 #include "wl_internal.h"
 

@@ -48,6 +48,9 @@ static bool shape_matches(int nsteps, const int *upd, const int *nc, const int *
 
 __device__ __forceinline__ int l_dpp_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ int l_dpp_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int l_dpp_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float l_partner(float v) { return __int_as_float(l_dpp_partner(__float_as_int(v))); }
+__device__ __forceinline__ double l_partner(double v) { return __hiloint2double(l_dpp_partner(__double2hiint(v)), l_dpp_partner(__double2loint(v))); }
 __device__ __forceinline__ float l_next(float v) { return __int_as_float(l_dpp_next(__float_as_int(v))); }
 __device__ __forceinline__ float l_prev(float v) { return __int_as_float(l_dpp_prev(__float_as_int(v))); }
 __device__ __forceinline__ double l_next(double v) { return __hiloint2double(l_dpp_next(__double2hiint(v)), l_dpp_next(__double2loint(v))); }
@@ -1192,7 +1195,7 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
-    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 1;
+    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 2;   // even margin: lane pairs store together
     constexpr int VR = (64 - 2 * ML) * RPL;
     static_assert(PF >= 2, "ring too small for this scheme");
     const int lane = threadIdx.x;
@@ -1269,16 +1272,31 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
             }
             lift_steps_lane<T, ID, 2>(s1, d1, a.c, kfirst, h0);
             lift_steps_lane<T, ID, 2>(s2, d2, a.c, kfirst, h0);
+            // lane pairs (2i, 2i+1) own rows k0..k0+1 and k0+2..k0+3 of the same four sub-band columns: they swap
+            // halves so that the even lane stores 4 rows of LL and HL (left column), the odd lane 4 rows of LH and HH
+            const bool odd = (lane & 1) != 0;
+            T ll_[2], hl_[2], lh_[2], hh_[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ll_[j] = s1[j] * a.norm1; hl_[j] = d1[j] * a.norm2;
+                lh_[j] = s2[j] * a.norm1; hh_[j] = d2[j] * a.norm2;
+            }
+            T o0[4], o1[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const T ra = l_partner(odd ? ll_[j] : lh_[j]);      // even gets the partner's LL, odd the partner's LH
+                const T rb = l_partner(odd ? hl_[j] : hh_[j]);
+                o0[j] = odd ? ra : ll_[j];      o0[2 + j] = odd ? lh_[j] : ra;
+                o1[j] = odd ? rb : hl_[j];      o1[2 + j] = odd ? hh_[j] : rb;
+            }
             if (valid) {
-                T o[2];
-                o[0] = s1[0] * a.norm1; o[1] = s1[1] * a.norm1;
-                stv_l<T, 2>(llp + k0 + io * ldl, o);
-                o[0] = d1[0] * a.norm2; o[1] = d1[1] * a.norm2;
-                stv_l<T, 2>(yb + h0 + k0 + io * a.ldy, o);
-                o[0] = s2[0] * a.norm1; o[1] = s2[1] * a.norm1;
-                stv_l<T, 2>(yb + k0 + (h1 + io) * a.ldy, o);
-                o[0] = d2[0] * a.norm2; o[1] = d2[1] * a.norm2;
-                stv_l<T, 2>(yb + h0 + k0 + (h1 + io) * a.ldy, o);
+                if (!odd) {
+                    stv_l<T, 4>(llp + k0 + io * ldl, o0);                      // LL rows k0..k0+3
+                    stv_l<T, 4>(yb + h0 + k0 + io * a.ldy, o1);                // HL
+                } else {
+                    stv_l<T, 4>(yb + (k0 - 2) + (h1 + io) * a.ldy, o0);        // LH rows k0-2..k0+1
+                    stv_l<T, 4>(yb + h0 + (k0 - 2) + (h1 + io) * a.ldy, o1);   // HH
+                }
             }
         }
     };
@@ -1418,7 +1436,7 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
 template <typename T, int ID>
 static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_count, int64_t nbatch = 1)
 {
-    constexpr int VR = 62 * 4;
+    constexpr int VR = 60 * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;

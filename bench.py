@@ -119,11 +119,11 @@ def main():
     for _ in range(args.steps):
         y = fn(x)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0               # this rank's K steps, start aligned by the barrier above
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, dist, device)
+    dt = sharding.max_over_ranks(dt, dist, device)   # the job is as slow as its slowest rank
     kernel = W.last_kernel()
     ms_per_step = dt / args.steps * 1e3
     value = world * nsamples / (dt / args.steps) / 1e6          # whole-job Msamples/s
@@ -139,6 +139,10 @@ def main():
     torch.cuda.synchronize()
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
 
+    # cross-rank correctness token: sum over all ranks of each rank's coefficient sum, one 8-byte all-reduce
+    # over RCCL after the timed region (single rank: its own sum)
+    checksum = sharding.sum_over_ranks(float(yout.sum(dtype=torch.float64).item()), dist, device)
+
     out = {
         "metric": "Msamples/s, 2-D db4 dwt 8192x8192 f32" if args.workload == "c3" else "Msamples/s, " + label,
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,6 +151,7 @@ def main():
         "config": {"workload": label, "L": int(L), "arrays": world, "parallelism": f"{world} independent arrays, one per GPU",
                    "kernel": kernel, "kernel_path": "generic" if args.path else "fast"},
         "achieved_hbm_GBps_algorithmic": round(gbps, 1), "precondition_steps": precondition,
+        "checksum_all_ranks": checksum,
         "device_ms_per_step": round(dev_ms_per_step, 5),
     }
 
@@ -158,10 +163,19 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_leg(W, args.workload, wt, L)
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line on stdout: RCCL writes its banner through C stdio, which is fully
+        # buffered on a pipe and would otherwise be flushed after Python's line at exit
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def secondary_leg(W, device):

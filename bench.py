@@ -109,11 +109,16 @@ def main():
     # millisecond of load to ramp, and the ROCm runtime has a one-off enqueue stall the first time the host runs a few
     # hundred launches ahead -- neither belongs to the steady-state throughput this line reports
     precondition = max(0, 300 - args.warmup)
-    for _ in range(precondition + args.warmup):
+    for _ in range(precondition):
         y = fn(x)
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        dist.barrier()                      # all ranks start the warm-up (and with it the timed steps) together
+    torch.cuda.synchronize()
+    # the W warm-up steps run AFTER the barrier: an RCCL barrier idles the GPU for about a millisecond, long enough
+    # for the clocks to drop again, and the timed steps must not start cold
+    for _ in range(args.warmup):
+        y = fn(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -638,3 +638,25 @@ def test_unaligned_views(gpu, W, oracle, dtype):
     assert W.is_julia_layout(av) and av.data_ptr() % 16 != 0
     assert np.array_equal(host(W, W.dwt(av, db4, 3)), oracle.dwt_filter(a, db4.qmf, 3))
     assert np.array_equal(host(W, W.dwtc(av, db4, 4)), oracle.dwtc_filter(a, db4.qmf, 4))
+
+
+def test_whole_c5_batch_on_one_gpu(gpu, W):
+    """BASELINE config C5 in full (65536 signals x 2^16 samples = 2^32 Float32 elements, 16 GiB) on ONE GPU: 64-bit
+    indexing beyond 2^32 elements, slab launches (gridDim.y <= 65535), per-column agreement with the 1-D transform
+    (bit-exact, columns on both sides of the slab boundary) and the round trip.  Needs ~120 GB of HBM."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 130 * 2 ** 30:
+        pytest.skip("needs ~120 GB of free HBM")
+    wt = W.wavelet(W.WT.db4)
+    n, ns = 1 << 16, 65536
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.empty(ns, n, dtype=torch.float32, device=gpu).normal_(generator=g).t()
+    assert x.numel() == 2 ** 32
+    y = W.dwtc(x, wt, 16)
+    for j in (0, 1, 32767, 32768, 65534, 65535):
+        assert torch.equal(W.dwt(x[:, j].contiguous(), wt, 16), y[:, j]), j
+    xr = W.idwtc(y, wt, 16)
+    assert (xr - x).abs().max().item() < 1e-4
+    del x, y, xr
+    torch.cuda.empty_cache()

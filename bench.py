@@ -160,6 +160,8 @@ def main():
         "device_ms_per_step": round(dev_ms_per_step, 5),
     }
 
+    if rank == 0 and world == 1 and not batched:
+        out["pipelined"] = pipelined_leg(W, x, wt, L, args)
     if rank == 0:
         out["roofline"] = roofline_leg(W, x, wt, batched, esize, args, kernel)
     if rank == 0 and world == 1 and args.workload == "c3" and not args.no_secondary:
@@ -181,6 +183,31 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def pipelined_leg(W, x, wt, L, args, nstreams=4):
+    """Reported beside `value`, never instead of it: the same K transforms issued round-robin on `nstreams` HIP streams
+    (one library context and one output array per stream, same resident input).  Independent transforms -- a sequence of
+    images -- overlap the latency-bound small levels of one with the bandwidth-bound first kernel of the next; `value`
+    above stays the strictly sequential single-stream figure the metric is defined on."""
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    outs = [W.similar(x) for _ in range(nstreams)]
+    for s, y in zip(streams, outs):
+        with torch.cuda.stream(s):
+            for _ in range(30):
+                W.dwt_oop_(y, x, wt, L)
+    torch.cuda.synchronize()
+    steps = max(args.steps, 100)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % nstreams]):
+            W.dwt_oop_(outs[i % nstreams], x, wt, L)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del outs
+    torch.cuda.empty_cache()
+    return {"streams": nstreams, "steps": steps, "ms_per_step": round(ms, 5), "value": round(x.numel() / ms / 1e3, 1), "unit": "Msamples/s",
+            "achieved_hbm_GBps_algorithmic": round(2 * x.numel() * x.element_size() / ms / 1e6, 1)}
 
 
 def secondary_leg(W, device):

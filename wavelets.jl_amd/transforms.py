@@ -83,6 +83,16 @@ def _context(device: torch.device):
     return h, C.c_void_p(stream)
 
 
+def destroy_contexts():
+    """Destroy every library context this process created (one per device and stream, each owning a grow-only device
+    workspace) -- e.g. after a burst of work on temporary streams.  New contexts are created on demand."""
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    for h in list(_CTX.values()):
+        lib.wl_ctx_destroy(h)
+    _CTX.clear()
+
+
 def last_kernel(device=None) -> str:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     h, _ = _context(dev)

@@ -16,17 +16,24 @@ using AMDGPU: ROCArray, ROCVector, ROCMatrix, AMDGPU
 
 const LIB = get(ENV, "WAVELETS_MI355X_LIB", "libwavelets_mi355x.so")
 const DT = Dict(Float32 => Cint(0), Float64 => Cint(1))
-const CTX = Dict{Int,Ptr{Cvoid}}()          # one context per device (per task/stream in real use)
+# One context per (device, stream): a wl_ctx owns a workspace that kernels queued on its stream are still using, so two
+# tasks (= two HIP streams in AMDGPU.jl) must never share one.  Independent transforms issued from several tasks then
+# overlap on the GPU (the small levels of one hide behind the first kernel of the next).
+const CTX = Dict{Tuple{Int,UInt},Ptr{Cvoid}}()
+const CTX_LOCK = ReentrantLock()
 
+stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))     # hipStream_t of the current task
 function ctx()
     dev = AMDGPU.device_id(AMDGPU.device()) - 1
-    get!(CTX, dev) do
-        r = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:wl_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), dev, r))
-        r[]
+    key = (dev, UInt(stream()))
+    lock(CTX_LOCK) do
+        get!(CTX, key) do
+            r = Ref{Ptr{Cvoid}}(C_NULL)
+            check(ccall((:wl_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), dev, r))
+            r[]
+        end
     end
 end
-stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))     # hipStream_t of the current task
 
 # status -> the exception the reference throws (transforms_filter.jl:25-34, transforms_lifting.jl:131-139)
 function check(rc::Cint)

@@ -5,7 +5,6 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
 import oracle
 import wavelets_jl_amd as W
 

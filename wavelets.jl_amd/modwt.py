@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .transforms import (ArgumentError, DimensionMismatch, HIPError, _check, _context, _dtype_code, _f64p, _prep_in,
-                         is_julia_layout, julia_layout)
+                         julia_layout)
 from .wt import OrthoFilter
 
 

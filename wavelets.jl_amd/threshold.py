@@ -20,7 +20,7 @@ from . import util as Util
 from . import wt as WT
 from .transforms import (ArgumentError, DimensionMismatch, HIPError, _check, _context, _dims, _dtype_code, _prep_in,
                          dwt, dwt_oop_, idwt, idwt_, idwt_oop_, is_julia_layout, julia_layout, similar)
-from .wt import GLS, OrthoFilter, wavelet
+from .wt import GLS, wavelet
 
 
 # ---- threshold types (threshold_main.jl:8-17) --------------------------------------------------

@@ -27,7 +27,8 @@
  *    is retained.
  *  - Every call is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
  *    default stream) and returns without synchronising.  A wl_ctx owns a grow-only
- *    device workspace and is NOT thread-safe: use one context per stream.
+ *    device workspace and is NOT thread-safe: use one context per stream.  Calls run on
+ *    the context's device and leave the caller's current HIP device unchanged.
  *  - Return value: 0 (WL_OK) or a negative wl_status.  Nothing throws or aborts.
  *    The Julia glue maps the codes to the exceptions the reference throws
  *    (transforms_filter.jl:25-34): WL_EDIMS -> DimensionMismatch, WL_EINVAL_* /
@@ -215,6 +216,13 @@ WL_API int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *s
 WL_API int wl_ctx_set_path(wl_ctx *ctx, int path);
 /* Name of the dominant kernel used by the last transform call on this context.          */
 WL_API const char *wl_last_kernel(const wl_ctx *ctx);
+/* Tuning / test switches of this context (the library reads no environment variable).
+ * key: e.g. "WL_FUSE2_MIN", "WL_TJ", "WL_NO_INV2D" (DESIGN.md section 5 lists them with their
+ * defaults); keys shorter than 32 characters, at most 32 per context; unknown keys are stored
+ * and ignored.  No option changes a result: they pick between kernel families that are
+ * bit-identical by construction, which is what the tests use them to prove.                */
+WL_API int wl_ctx_set_option(wl_ctx *ctx, const char *key, int64_t value);
+WL_API int wl_ctx_clear_options(wl_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,14 @@ def gpu(W):
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(autouse=True)
+def _reset_library_options(request):
+    """Options set with W.set_option() inside a test never leak into the next one."""
+    yield
+    if "W" in request.fixturenames:
+        request.getfixturevalue("W").clear_options()
+
+
 def golden(name):
     return np.loadtxt(os.path.join(GOLDEN, name))
 

@@ -132,11 +132,11 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
 
 @pytest.mark.parametrize("ppl", ["2", "4"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_fused_inverse_2d_kernel(gpu, W, oracle, monkeypatch, dtype, ppl):
+def test_fused_inverse_2d_kernel(gpu, W, oracle, dtype, ppl):
     """k_inv2d_stream (dim-1 + dim-2 reconstruction of a 2-D level in one pass): bit for bit against the oracle;
     partial strips / chunks, non-square blocks, both lane widths, approximation taken from x (L = 1) and from the
     deeper reconstruction (L > 1)."""
-    monkeypatch.setenv("WL_INV2D_PPL", ppl)
+    W.set_option("WL_INV2D_PPL", int(ppl))
     for shape, Ls in (((512, 512), (1, 2, 9)), ((1024, 2048), (1, 3)), ((2048, 512), (2, 9)), ((528, 96), (1, 4)),
                       ((4096, 16), (1,)), ((1000, 24), (1, 3)), ((128, 128), (1, 7)), ((256, 64), (1, 2)), ((136, 24), (1, 3)),
                       ((264, 528), (1, 3))):
@@ -179,11 +179,12 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.idwtc(dev(W, ym), wt, 4)), oracle.dwtc_filter(ym, wt.qmf, 4, fw=False))
 
 
-def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
+def test_fused_level_pair_kernel(gpu, W, oracle):
     """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
     forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic
     kernels (odd/even L, non-square blocks, partial strips and chunks, every supported filter length)."""
-    monkeypatch.setenv("WL_FUSE2_MIN", "0")
+    W.set_option("WL_FUSE2_MIN", 0)
+    W.set_option("WL_LDS2D", 0)          # (the LDS-exchange kernel, tested below, takes these shapes by default)
     for shape, Ls in (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (4, 9)), ((528, 96), (2, 4)),
                       ((4096, 64), (2,))):
         x = rng_array(shape, np.float32, sum(shape))
@@ -199,10 +200,33 @@ def test_fused_level_pair_kernel(gpu, W, oracle, monkeypatch):
     assert np.array_equal(y, oracle.dwt_filter(x, W.wavelet(W.WT.db4).qmf, 3))
 
 
-def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle, monkeypatch):
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("pair", [1, 0])
+def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
+    """k_fwd2d_lds (one or two fused 2-D levels, dim-1 pass through an LDS exchange): every workgroup shape
+    (mode 0 = exact tiling with the halo helper wave where the row count allows it, 1..4 = overlapped strips of
+    1..4 waves), every supported filter length, odd/even depths, non-square blocks, partial strips and chunks,
+    row counts that are not multiples of a strip -- bit for bit against the oracle."""
+    W.set_option("WL_LDS_MODE", mode)
+    W.set_option("WL_FUSE2", pair)
+    W.set_option("WL_LDS_PAIR_MIN", 0)
+    shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4, 9)), ((528, 96), (1, 2, 4)), ((4096, 64), (1, 2)),
+              ((256, 256), (1, 2)), ((1000, 64), (1, 2, 3)), ((272, 64), (1,)), ((768, 1024), (2, 3)), ((1280, 128), (1, 2)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape) + mode)
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_lds", (shape, L, W.last_kernel())
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                assert np.array_equal(y, ye), (shape, fname, L, mode, pair, float(np.abs(y - ye).max()))
+
+
+def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle):
     """Seeded random sweep over shapes that sit on the eligibility boundaries of the fast kernels
     (strip/tile/chunk multiples, alignment, wrap) -- forward and inverse, against the oracle."""
-    monkeypatch.setenv("WL_FUSE2_MIN", "0")
+    W.set_option("WL_FUSE2_MIN", int(0))
     rs = np.random.default_rng(2024)
     filters = ["haar", "db2", "db3", "db4", "db5", "sym4", "coif2"]
     n1d = [504, 512, 520, 1000, 1024, 2040, 4088, 16384, 16392, 20480, 32768, 49152, 65536 + 64]
@@ -303,14 +327,14 @@ def test_lifting_cubes_fast_vs_generic(gpu, W, oracle):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tp", ["64", "24", ""])
-def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, monkeypatch, tp, fused):
+def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, tp, fused):
     """2-D lifting levels: k_lift2d_fwd / k_lift2d_inv (both passes of a level in one kernel: register cascade along
     dim 2 + DPP lifting across the lanes along dim 1) and, with the fused kernels switched off, k_lift_axis_stream +
     the line kernels: every chunk length, every scheme shape, forward and inverse, bit for bit against the oracle."""
     if tp:
-        monkeypatch.setenv("WL_LIFT_TP", tp)
+        W.set_option("WL_LIFT_TP", int(tp))
     if not fused:
-        monkeypatch.setenv("WL_NO_LIFT2D_FUSED", "1")
+        W.set_option("WL_NO_LIFT2D_FUSED", int(1))
     expect = "k_lift2d" if fused else "k_lift_axis_stream"
     for n, Ls in ((512, (1, 3)), (1024, (2,)), (576, (1,)), (2048, (1, 11))):
         for dtype in (np.float32, np.float64):
@@ -486,10 +510,10 @@ def test_dwtc_bitexact(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.idwtc(dev(W, ye), sch, Lmax)), oracle.dwtc_lifting(ye, sch, Lmax, fw=False))
 
 
-def test_many_lines_slab_launches(gpu, W, oracle, monkeypatch):
+def test_many_lines_slab_launches(gpu, W, oracle):
     """gridDim.y is capped at 65535, so batches are launched in slabs of lines; WL_SLAB_LINES=5 forces
     several slabs on a small batch (24 and 7 lines)."""
-    monkeypatch.setenv("WL_SLAB_LINES", "5")
+    W.set_option("WL_SLAB_LINES", int(5))
     wt = W.wavelet(W.WT.db4)
     sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
     for n, ns in (((1 << 15), 24), ((1 << 16), 7)):

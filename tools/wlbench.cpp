@@ -1,0 +1,160 @@
+// wlbench -- torch-free timing harness over the C ABI (profiling runs on the GPU box start in
+// milliseconds instead of waiting for `import torch`).  Not product code.
+//
+//   wlbench [key=value ...]
+//     n0=8192 n1=8192 n2=1   array extents (Julia order, n0 fastest); nd = number of extents > 1 ... or nd=
+//     L=13                   levels (0 => maxtransformlevels over the transformed dims)
+//     filt=db4|db2|haar|sym5|db6   orthogonal filter (taps below are wt.py's values)
+//     dtype=f32|f64
+//     fw=1                   1 forward, 0 inverse
+//     reps=50 warm=20
+//     mode=seq|each          seq: one event pair around all reps;  each: one pair per call (avg/med/min)
+//     check=1                print a checksum of y
+//     opt=KEY:VAL,...        wl_ctx_set_option pairs
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../include/wavelets_mi355x.h"
+
+#define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { fprintf(stderr, "hip error %d (%s) at line %d\n", (int)e__, hipGetErrorString(e__), __LINE__); return 2; } } while (0)
+
+static const std::map<std::string, std::vector<double>> kTaps = {
+    {"haar", {0.7071067811865476, 0.7071067811865476}},
+    {"db2", {0.4829629131445342, 0.8365163037378079, 0.2241438680420133, -0.12940952255126045}},
+    {"db3", {0.3326705529500827, 0.8068915093110927, 0.45987750211849154, -0.13501102001025467, -0.08544127388202664, 0.03522629188570957}},
+    {"db4", {0.23037781330889648, 0.7148465705529157, 0.6308807679298589, -0.027983769416860003, -0.18703481171909309, 0.030841381835560722, 0.03288301166688518, -0.010597401785069035}},
+    {"sym5", {0.019538882735386898, -0.02110183402492983, -0.17532808990810747, 0.016602105764424325, 0.633978963456949, 0.7234076904038076, 0.1993975339769955, -0.03913424930258344, 0.0295194909260734, 0.02733306834516448}},
+    {"db6", {0.11154074335010944, 0.4946238903984531, 0.7511339080210953, 0.31525035170919813, -0.22626469396543938, -0.12976686756726197, 0.09750160558732307, 0.027522865530305647, -0.031582039317485995, 0.0005538422011614999, 0.004777257510945508, -0.0010773010853084798}},
+    {"db8", {0.05441584224310398, 0.3128715909142999, 0.6756307362972896, 0.5853546836542072, -0.015829105256348633, -0.2840155429615473, 0.00047248457391376, 0.1287474266204779, -0.017369301001807197, -0.04408825393079476, 0.013981027917398216, 0.008746094047405775, -0.004870352993451561, -0.0003917403733769489, 0.0006754494064505684, -0.00011747678412476926}},
+};
+
+__global__ void k_fill(float *p, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (float)((double)(z >> 11) * (1.0 / 9007199254740992.0)) - 0.5f;
+    }
+}
+__global__ void k_fill64(double *p, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    std::map<std::string, std::string> kv = {{"n0", "8192"}, {"n1", "8192"}, {"n2", "1"}, {"L", "0"}, {"filt", "db4"}, {"dtype", "f32"},
+                                             {"fw", "1"}, {"reps", "50"}, {"warm", "20"}, {"mode", "seq"}, {"check", "1"}, {"opt", ""},
+                                             {"path", "0"}};
+    for (int i = 1; i < argc; ++i) {
+        const char *eq = strchr(argv[i], '=');
+        if (!eq) { fprintf(stderr, "bad arg %s\n", argv[i]); return 1; }
+        kv[std::string(argv[i], eq - argv[i])] = eq + 1;
+    }
+    int64_t dims[3] = {atoll(kv["n0"].c_str()), atoll(kv["n1"].c_str()), atoll(kv["n2"].c_str())};
+    int nd = dims[2] > 1 ? 3 : (dims[1] > 1 ? 2 : 1);
+    if (kv.count("nd")) nd = atoi(kv["nd"].c_str());
+    const int dtype = kv["dtype"] == "f64" ? WL_F64 : WL_F32;
+    const size_t es = dtype == WL_F64 ? 8 : 4;
+    int L = atoi(kv["L"].c_str());
+    if (L == 0) {
+        L = 99;
+        for (int d = 0; d < nd; ++d) L = std::min(L, wl_maxtransformlevels(dims[d]));
+    }
+    const int fw = atoi(kv["fw"].c_str()), reps = atoi(kv["reps"].c_str()), warm = atoi(kv["warm"].c_str());
+    auto it = kTaps.find(kv["filt"]);
+    if (it == kTaps.end()) { fprintf(stderr, "unknown filter\n"); return 1; }
+    const std::vector<double> &qmf = it->second;
+    const size_t N = (size_t)dims[0] * dims[1] * dims[2];
+
+    wl_ctx *ctx = nullptr;
+    int rc = wl_ctx_create(0, &ctx);
+    if (rc) { fprintf(stderr, "wl_ctx_create: %s\n", wl_strerror(rc)); return 2; }
+    wl_ctx_set_path(ctx, atoi(kv["path"].c_str()));
+#ifdef WL_HAVE_OPTIONS
+    {
+        std::string o = kv["opt"];
+        size_t p = 0;
+        while (p < o.size()) {
+            size_t c = o.find(',', p);
+            if (c == std::string::npos) c = o.size();
+            std::string item = o.substr(p, c - p);
+            size_t col = item.find(':');
+            if (col != std::string::npos) {
+                int r = wl_ctx_set_option(ctx, item.substr(0, col).c_str(), atoll(item.substr(col + 1).c_str()));
+                if (r) fprintf(stderr, "option %s: %s\n", item.c_str(), wl_strerror(r));
+            }
+            p = c + 1;
+        }
+    }
+#endif
+    void *x = nullptr, *y = nullptr;
+    CK(hipMalloc(&x, N * es));
+    CK(hipMalloc(&y, N * es));
+    if (dtype == WL_F32) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float *)x, N, 42u);
+    else hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, (double *)x, N, 42u);
+    CK(hipMemset(y, 0, N * es));
+    rc = wl_ctx_reserve(ctx, wl_workspace_bytes(dtype, nd, dims, L));
+    if (rc) { fprintf(stderr, "reserve: %s\n", wl_strerror(rc)); return 2; }
+    CK(hipDeviceSynchronize());
+    auto call = [&]() { return wl_dwt_filter(ctx, dtype, y, x, nd, dims, qmf.data(), (int)qmf.size(), L, fw, nullptr); };
+    for (int i = 0; i < warm; ++i) {
+        rc = call();
+        if (rc) { fprintf(stderr, "wl_dwt_filter: %s (hip %d)\n", wl_strerror(rc), wl_last_hip_error(ctx)); return 2; }
+    }
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    double avg = 0, med = 0, mn = 0;
+    if (kv["mode"] == "each") {
+        std::vector<float> v;
+        for (int i = 0; i < reps; ++i) {
+            CK(hipEventRecord(e0, nullptr));
+            call();
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            v.push_back(ms);
+        }
+        std::sort(v.begin(), v.end());
+        for (float f : v) avg += f;
+        avg /= v.size(); med = v[v.size() / 2]; mn = v[0];
+    } else {
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) call();
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        avg = med = mn = ms / reps;
+    }
+    double sum = 0;
+    if (atoi(kv["check"].c_str())) {
+        std::vector<char> h(std::min<size_t>(N, (size_t)1 << 22) * es);
+        CK(hipMemcpy(h.data(), y, h.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size() / es; ++i) sum += dtype == WL_F64 ? ((double *)h.data())[i] : (double)((float *)h.data())[i];
+    }
+    const double alg = 2.0 * N * es;
+    printf("{\"n\": [%lld, %lld, %lld], \"nd\": %d, \"L\": %d, \"filt\": \"%s\", \"dtype\": \"%s\", \"fw\": %d, \"mode\": \"%s\", \"reps\": %d, "
+           "\"avg_us\": %.2f, \"med_us\": %.2f, \"min_us\": %.2f, \"alg_TBps\": %.3f, \"frac8\": %.4f, \"kernel\": \"%s\", \"opt\": \"%s\", \"sum\": %.9g}\n",
+           (long long)dims[0], (long long)dims[1], (long long)dims[2], nd, L, kv["filt"].c_str(), kv["dtype"].c_str(), fw, kv["mode"].c_str(), reps,
+           avg * 1e3, med * 1e3, mn * 1e3, alg / (avg * 1e-3) / 1e12, alg / (avg * 1e-3) / 8e12, wl_last_kernel(ctx), kv["opt"].c_str(), sum);
+    wl_ctx_destroy(ctx);
+    return 0;
+}

@@ -46,6 +46,8 @@ SIGNATURES = {
     "wl_last_hip_error": (C.c_int, [_vp]),
     "wl_ctx_set_path": (C.c_int, [_vp, C.c_int]),
     "wl_last_kernel": (C.c_char_p, [_vp]),
+    "wl_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "wl_ctx_clear_options": (C.c_int, [_vp]),
     "wl_dwt_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, _f64p, C.c_int, C.c_int, C.c_int, _vp]),
     "wl_dwt_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64p, C.c_int, _i32p, _i32p, _i32p, _f64p,
                                  C.c_double, C.c_double, C.c_int, C.c_int, _vp]),

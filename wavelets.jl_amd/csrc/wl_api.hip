@@ -13,6 +13,8 @@ using namespace wl;
 
 #include "wl_ctx.h"
 
+thread_local const wl::Opts *wl::tl_opts = nullptr;
+
 int wl_ensure_ws(wl_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return WL_OK;
@@ -285,7 +287,6 @@ int wl_ctx_create(int device, wl_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WL_ENODEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return WL_ENODEVICE;
-    if (hipSetDevice(device) != hipSuccess) return WL_ENODEVICE;
     wl_ctx *c = new (std::nothrow) wl_ctx();
     if (!c) return WL_ENOMEM;
     c->device = device;
@@ -297,9 +298,12 @@ int wl_ctx_create(int device, wl_ctx **out)
 int wl_ctx_destroy(wl_ctx *ctx)
 {
     if (!ctx) return WL_EINVAL_ARG;
-    if (ctx->ws || ctx->aux) (void)hipDeviceSynchronize();
-    if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->aux) (void)hipFree(ctx->aux);
+    {
+        CallScope scope(ctx);                  // free on the context's device, leave the caller's device current
+        if (ctx->ws || ctx->aux) (void)hipDeviceSynchronize();
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        if (ctx->aux) (void)hipFree(ctx->aux);
+    }
     delete ctx;
     return WL_OK;
 }
@@ -316,12 +320,14 @@ size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L)
 int wl_ctx_reserve(wl_ctx *ctx, size_t bytes)
 {
     if (!ctx) return WL_EINVAL_ARG;
+    WL_SCOPE(ctx);
     return ensure_ws(ctx, bytes);
 }
 
 int wl_stream_sync(wl_ctx *ctx, void *stream)
 {
     if (!ctx) return WL_EINVAL_ARG;
+    WL_SCOPE(ctx);
     WL_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return WL_OK;
 }
@@ -335,6 +341,25 @@ int wl_ctx_set_path(wl_ctx *ctx, int path)
 }
 const char *wl_last_kernel(const wl_ctx *ctx) { return ctx ? ctx->last_kernel : "none"; }
 
+int wl_ctx_set_option(wl_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key || !*key || strlen(key) >= (size_t)Opts::kKeyLen) return WL_EINVAL_ARG;
+    Opts &o = ctx->opts;
+    for (int i = 0; i < o.n; ++i)
+        if (strcmp(o.key[i], key) == 0) { o.val[i] = (long long)value; return WL_OK; }
+    if (o.n >= Opts::kMax) return WL_EINVAL_ARG;
+    strcpy(o.key[o.n], key);
+    o.val[o.n] = (long long)value;
+    ++o.n;
+    return WL_OK;
+}
+int wl_ctx_clear_options(wl_ctx *ctx)
+{
+    if (!ctx) return WL_EINVAL_ARG;
+    ctx->opts.n = 0;
+    return WL_OK;
+}
+
 int wl_dwt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
                   const double *qmf, int flen, int L, int fw, void *stream)
 {
@@ -345,7 +370,7 @@ int wl_dwt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, con
     int rc = check_box(ndims, dims, L, b);
     if (rc) return rc;
     if (y == x) return WL_EALIAS;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     return dtype == WL_F32 ? dwt_filter_impl<float>(ctx, st, b, (float *)y, (const float *)x, qmf, flen, L, fw)
                            : dwt_filter_impl<double>(ctx, st, b, (double *)y, (const double *)x, qmf, flen, L, fw);
@@ -364,7 +389,7 @@ static int lifting_common(wl_ctx *ctx, int dtype, void *y, const void *x, int nd
             if (dims[d] != dims[0]) return WL_EINVAL_CUBE;
     int rc = check_box(ndims, dims, L, b);
     if (rc) return rc;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     return dtype == WL_F32
                ? dwt_lifting_impl<float>(ctx, st, b, (float *)y, (const float *)x, nsteps, is_update, ncoef, shift, coefs, norm1, norm2, L, fw)
@@ -411,7 +436,7 @@ int wl_dwtc_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t len, 
     int rc = check_dwtc(len, nsignals, ld, L, b);
     if (rc) return rc;
     if (y == x) return WL_EALIAS;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     return dtype == WL_F32 ? dwt_filter_impl<float>(ctx, st, b, (float *)y, (const float *)x, qmf, flen, L, fw)
                            : dwt_filter_impl<double>(ctx, st, b, (double *)y, (const double *)x, qmf, flen, L, fw);
@@ -427,7 +452,7 @@ int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y, int64_t len, int64_t nsigna
     BoxSpec b;
     int rc = check_dwtc(len, nsignals, ld, L, b);
     if (rc) return rc;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     return dtype == WL_F32
                ? dwt_lifting_impl<float>(ctx, st, b, (float *)y, (const float *)y, nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, L, fw)
@@ -564,7 +589,7 @@ int wl_wpt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n, con
     if (y == x) return WL_EALIAS;
     int64_t last_set = -1;
     if (!isvalidtree(n, tree, ntree, &last_set)) return WL_EINVAL_TREE;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WL_F32) {
         Taps<float> t; make_taps<float>(qmf, flen, t);
@@ -584,7 +609,7 @@ int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
     if (n < 1) return WL_EDIMS;
     int64_t last_set = -1;
     if (!isvalidtree(n, tree, ntree, &last_set)) return WL_EINVAL_TREE;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
+    WL_SCOPE(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WL_F32) {
         LiftScheme<float> sc;

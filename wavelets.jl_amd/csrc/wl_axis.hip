@@ -13,7 +13,6 @@
 // Arithmetic: the closed forms of wl_internal.h, bit-identical to the generic kernels.
 #include "wl_fast.h"
 
-#include <cstdlib>
 
 namespace wl {
 
@@ -465,7 +464,7 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
         *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, n0 * n1, 0, n0 * n1, n2, 1, cu_count);
         // rows + columns of every plane in ONE launch when the planes are big enough for the fused 2-D level kernel
         bool planes = false;
-        if (*err == hipSuccess && std::getenv("WL_NO_PLANES") == nullptr)
+        if (*err == hipSuccess && opt("WL_NO_PLANES", 0) == 0)
             planes = fwd2d_planes<T>(st, taps, T0, y, y1, y2, ll, n0, n1, n2, (int)h2, cu_count, err);
         // rows: axis 2 on n2 matrices of n0 x n1
         if (!planes && *err == hipSuccess) *err = launch_axis<T, FF, 1>(st, taps, T0, n0, n0 * n1, T1, n0, n0 * n1, n0, n1, n2, cu_count);
@@ -500,7 +499,7 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     WL_DISPATCH_FA(F, {
         // columns + rows of every plane in ONE launch when the planes are big enough for the fused 2-D inverse kernel
         bool planes = false;
-        if (std::getenv("WL_NO_PLANES") == nullptr)
+        if (opt("WL_NO_PLANES", 0) == 0)
             planes = inv2d_planes<T>(st, taps, x, x1, x2, llsrc, T1, n0, n1, n2, (int)h2, cu_count, err);
         // columns first (transforms_filter.jl:269-273): merged lines into T0 (dense box); the low-low corner takes its
         // approximation from the deeper reconstruction

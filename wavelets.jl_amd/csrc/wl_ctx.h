@@ -12,7 +12,37 @@ struct wl_ctx {
     int path = 0;                       // 0 auto, 1 generic only
     const char *last_kernel = "none";
     int cu_count = 256;
+    wl::Opts opts;                      // wl_ctx_set_option
 };
+
+// Installed by every ABI entry point for the duration of the call: makes the context's device current (and restores
+// the caller's device on exit, so a call never changes the process's current device) and publishes the context's
+// option table to the launchers.
+struct CallScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    const wl::Opts *prev_opts;
+    explicit CallScope(wl_ctx *ctx) : prev_opts(wl::tl_opts)
+    {
+        wl::tl_opts = &ctx->opts;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != ctx->device) {
+            err = hipSetDevice(ctx->device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~CallScope()
+    {
+        wl::tl_opts = prev_opts;
+        if (switched) (void)hipSetDevice(prev);
+    }
+    CallScope(const CallScope &) = delete;
+    CallScope &operator=(const CallScope &) = delete;
+};
+#define WL_SCOPE(ctx)                                   \
+    CallScope scope__(ctx);                             \
+    if (scope__.err != hipSuccess) return hip_fail((ctx), scope__.err)
 
 inline int hip_fail(wl_ctx *ctx, hipError_t e)
 {

@@ -1,0 +1,118 @@
+// wl_dev.h -- device-side helpers shared by the fast-path translation units (vector loads/stores, LDS-only barriers,
+// DPP lane shifts, compile-time tap blocks).
+#pragma once
+#include "wl_internal.h"
+
+namespace wl {
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int F>
+struct TapsF {
+    T h[F];
+    T g[F];
+};
+template <typename T, int F>
+inline TapsF<T, F> shrink(const Taps<T> &t)
+{
+    TapsF<T, F> r;
+    for (int i = 0; i < F; ++i) { r.h[i] = t.h[i]; r.g[i] = t.g[i]; }
+    return r;
+}
+
+template <typename T, int N>
+struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T>
+struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int N>
+__device__ __forceinline__ void vload(const T *p, T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    V t = *reinterpret_cast<const V *>(p);
+    if constexpr (N == 1) v[0] = t;
+    else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void vstore(T *p, const T (&v)[N])
+{
+    typedef typename VecOf<T, N>::type V;
+    if constexpr (N == 1) *p = v[0];
+    else {
+        V t;
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = v[i];
+        *reinterpret_cast<V *>(p) = t;
+    }
+}
+// 16-byte-granular load/store of N elements (N*sizeof(T) may exceed 16 bytes)
+template <typename T, int N>
+__device__ __forceinline__ void vload16(const T *p, T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    static_assert(N % C == 0, "chunking");
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        T t[C];
+        vload<T, C>(p + c * C, t);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void vstore16(T *p, const T (&v)[N])
+{
+    constexpr int C = 16 / sizeof(T);
+    static_assert(N % C == 0, "chunking");
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        T t[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        vstore<T, C>(p + c * C, t);
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
+// release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); kernels that
+// stream results to HBM between barriers and never read them back do not need that.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and one that also drains this wave's global loads (after staging HBM data into LDS)
+__device__ __forceinline__ void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr __host__ __device__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Whole-wave lane shifts on the VALU (DPP wave_shl:1 / wave_shr:1 -- gfx9-family controls, valid
+// on gfx950): lane i receives the value of lane i+1 (shl) or lane i-1 (shr).  No LDS round trip,
+// unlike __shfl (ds_bpermute).  Lanes shifted in from outside the wave get an unspecified value;
+// callers never store results that depend on them.
+__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_next(float v) { return __int_as_float(dpp_from_next(__float_as_int(v))); }
+__device__ __forceinline__ float from_prev(float v) { return __int_as_float(dpp_from_prev(__float_as_int(v))); }
+__device__ __forceinline__ double from_next(double v)
+{
+    int lo = dpp_from_next(__double2loint(v)), hi = dpp_from_next(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_prev(double v)
+{
+    int lo = dpp_from_prev(__double2loint(v)), hi = dpp_from_prev(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// swap with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float from_partner(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double from_partner(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace wl

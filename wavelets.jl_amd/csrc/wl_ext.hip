@@ -642,7 +642,6 @@ inline int ext_enter(wl_ctx *ctx, int dtype)
 {
     if (!ctx) return WL_EINVAL_ARG;
     if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
-    WL_HIP(ctx, hipSetDevice(ctx->device));
     return WL_OK;
 }
 
@@ -662,6 +661,7 @@ int wl_modwt(wl_ctx *ctx, int dtype, void *out, int64_t ldo, const void *x, int6
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!out || !x || !qmf) return WL_EINVAL_ARG;
     if (flen < 1 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
     if (n < 1 || ldo < n) return WL_EDIMS;
@@ -677,6 +677,7 @@ int wl_imodwt(wl_ctx *ctx, int dtype, void *x, const void *xw, int64_t ldw, int6
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!x || !xw || !qmf) return WL_EINVAL_ARG;
     if (flen < 1 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
     if (n < 1 || ncols < 1 || ldw < n) return WL_EDIMS;
@@ -689,6 +690,7 @@ int wl_threshold(wl_ctx *ctx, int dtype, void *x, int64_t n, int th, double t, i
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!x && n > 0) return WL_EINVAL_ARG;
     if (th < WL_TH_HARD || th > WL_TH_NEG) return WL_EINVAL_ARG;
     if (th <= WL_TH_STEIN && !(t >= 0)) return WL_EINVAL_ARG;           // @assert t >= 0
@@ -707,6 +709,7 @@ int wl_threshold_biggest(wl_ctx *ctx, int dtype, void *x, int64_t n, int64_t m, 
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if ((!x && n > 0) || m < 0) return WL_EINVAL_ARG;
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -717,6 +720,7 @@ int wl_median(wl_ctx *ctx, int dtype, const void *v, int64_t n, double *result, 
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!v || !result) return WL_EINVAL_ARG;
     if (n < 1) return WL_EDIMS;
     hipStream_t st = (hipStream_t)stream;
@@ -731,6 +735,7 @@ int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *str
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!y || !result) return WL_EINVAL_ARG;
     if (n < 1) return WL_EDIMS;
     rc = ensure_aux(ctx);
@@ -756,6 +761,7 @@ int wl_circshift(wl_ctx *ctx, int dtype, void *b, const void *a, int ndims, cons
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!b || !a || !dims || !shift) return WL_EINVAL_ARG;
     if (ndims < 1 || ndims > 3) return WL_EDIMS;
     if (b == a) return WL_EALIAS;
@@ -779,6 +785,7 @@ int wl_arrayadd(wl_ctx *ctx, int dtype, void *y, const void *z, int64_t n, void 
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if ((!y || !z) && n > 0) return WL_EINVAL_ARG;
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -793,6 +800,7 @@ int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *stream)
 {
     int rc = ext_enter(ctx, dtype);
     if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
     if (!y && n > 0) return WL_EINVAL_ARG;
     if (n <= 0) return WL_OK;
     hipStream_t st = (hipStream_t)stream;

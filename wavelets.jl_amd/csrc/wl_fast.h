@@ -42,6 +42,13 @@ template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
+// LDS-exchange streaming kernel (wl_fwd2d.hip): one (nlev = 1) or two (nlev = 2) fused forward 2-D levels, Float32,
+// even F <= 10 (F <= 8 for nlev = 2).  fwd2d_lds_ok = shape eligibility.
+bool fwd2d_lds_ok(int F, int nlev, int64_t ms, int64_t ns);
+hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, bool lvl1, const float *src, int64_t lds,
+                            float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
+                            int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
+
 // Long filters (12, 14, 16, 18, 20, 24 taps): one level of contiguous lines / of the strided axis of a matrix (wl_axis.hip).
 bool long_filter_ok(int F);
 template <typename T>

@@ -27,108 +27,11 @@
 // All of them evaluate the closed forms of wl_internal.h in the reference's summation order
 // with separate multiply/add roundings: results are bit-identical to the generic kernels.
 #include "wl_fast.h"
+#include "wl_dev.h"
 
-#include <cstdlib>
 
 namespace wl {
 
-// ------------------------------------------------------------------------------------------
-template <typename T, int F>
-struct TapsF {
-    T h[F];
-    T g[F];
-};
-template <typename T, int F>
-static TapsF<T, F> shrink(const Taps<T> &t)
-{
-    TapsF<T, F> r;
-    for (int i = 0; i < F; ++i) { r.h[i] = t.h[i]; r.g[i] = t.g[i]; }
-    return r;
-}
-
-template <typename T, int N>
-struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
-template <typename T>
-struct VecOf<T, 1> { typedef T type; };
-
-template <typename T, int N>
-__device__ __forceinline__ void vload(const T *p, T (&v)[N])
-{
-    typedef typename VecOf<T, N>::type V;
-    V t = *reinterpret_cast<const V *>(p);
-    if constexpr (N == 1) v[0] = t;
-    else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = t[i];
-    }
-}
-template <typename T, int N>
-__device__ __forceinline__ void vstore(T *p, const T (&v)[N])
-{
-    typedef typename VecOf<T, N>::type V;
-    if constexpr (N == 1) *p = v[0];
-    else {
-        V t;
-#pragma unroll
-        for (int i = 0; i < N; ++i) t[i] = v[i];
-        *reinterpret_cast<V *>(p) = t;
-    }
-}
-// 16-byte-granular load/store of N elements (N*sizeof(T) may exceed 16 bytes)
-template <typename T, int N>
-__device__ __forceinline__ void vload16(const T *p, T (&v)[N])
-{
-    constexpr int C = 16 / sizeof(T);
-    static_assert(N % C == 0, "chunking");
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        T t[C];
-        vload<T, C>(p + c * C, t);
-#pragma unroll
-        for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
-    }
-}
-template <typename T, int N>
-__device__ __forceinline__ void vstore16(T *p, const T (&v)[N])
-{
-    constexpr int C = 16 / sizeof(T);
-    static_assert(N % C == 0, "chunking");
-#pragma unroll
-    for (int c = 0; c < N / C; ++c) {
-        T t[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
-        vstore<T, C>(p + c * C, t);
-    }
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
-// release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); kernels that
-// stream results to HBM between barriers and never read them back do not need that.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// ... and one that also drains this wave's global loads (after staging HBM data into LDS)
-__device__ __forceinline__ void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-constexpr __host__ __device__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-
-// Whole-wave lane shifts on the VALU (DPP wave_shl:1 / wave_shr:1 -- gfx9-family controls, valid
-// on gfx950): lane i receives the value of lane i+1 (shl) or lane i-1 (shr).  No LDS round trip,
-// unlike __shfl (ds_bpermute).  Lanes shifted in from outside the wave get an unspecified value;
-// callers never store results that depend on them.
-__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ float from_next(float v) { return __int_as_float(dpp_from_next(__float_as_int(v))); }
-__device__ __forceinline__ float from_prev(float v) { return __int_as_float(dpp_from_prev(__float_as_int(v))); }
-__device__ __forceinline__ double from_next(double v)
-{
-    int lo = dpp_from_next(__double2loint(v)), hi = dpp_from_next(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_prev(double v)
-{
-    int lo = dpp_from_prev(__double2loint(v)), hi = dpp_from_prev(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 
 // One level of the QMF pair along the lane axis.  v[] holds this lane's PER consecutive
 // samples of the line; sample offsets outside [0, PER) come from lane + floordiv(off, PER).
@@ -239,17 +142,6 @@ __device__ __forceinline__ void lane_axis_pair2(const typename VecOf<T, 2>::type
         P[q] = s;
         Q[q] = d;
     }
-}
-// swap with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
-__device__ __forceinline__ float from_partner(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
-}
-__device__ __forceinline__ double from_partner(double v)
-{
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
 }
 
 // ==========================================================================================
@@ -1083,13 +975,9 @@ static hipError_t set_max_lds_once(const void *fn, size_t bytes, unsigned char (
     if (e == hipSuccess) { done[dev] = 1; cur[dev] = bytes < 65536 ? 65536 : bytes; }
     return e;
 }
-static int env_int_raw(const char *name, int dflt)
-{
-    const char *s = std::getenv(name);
-    return (s && *s) ? std::atoi(s) : dflt;
-}
-// tuning knobs are read once per call site (getenv walks the whole environment)
-#define env_int(name, dflt) ([]() { static const int v__ = env_int_raw(name, dflt); return v__; }())
+// tuning / test switches: per-context options (wl_ctx_set_option), see wl_internal.h
+#define env_int(name, dflt) ((int)opt(name, dflt))
+#define env_int_raw(name, dflt) ((int)opt(name, dflt))
 
 template <typename T>
 constexpr int tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }     // block elements
@@ -1368,6 +1256,29 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                 int64_t hn2[3] = {n[0] >> NL, n[1], n[2]};
                 cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
                 continue;
+            }
+        }
+        // ---- LDS-exchange streaming kernel: one or two fused 2-D levels (f32, wl_fwd2d.hip) ----
+        if constexpr (sizeof(T) == 4) {
+            if (fastF && two_d && env_int("WL_LDS2D", 1) && n[0] >= env_int("WL_LDS2D_MIN_ROWS", 256) && cur_st.s[0] == 1 &&
+                (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+                int nlev = 0;
+                if ((L - l + 1) >= 2 && env_int("WL_FUSE2", 1) && fwd2d_lds_ok(F, 2, n[0], n[1]) &&
+                    n[0] * n[1] >= (int64_t)env_int_raw("WL_LDS_PAIR_MIN", 1 << 20))
+                    nlev = 2;
+                else if (fwd2d_lds_ok(F, 1, n[0], n[1]))
+                    nlev = 1;
+                if (nlev) {
+                    const bool lastp = (l + nlev - 1 == L);
+                    T *lld = lastp ? y : llbuf;
+                    const int64_t ldd = lastp ? b.full.s[1] : (n[0] >> nlev);
+                    WL_TRY(fwd2d_lds_launch(st, taps, nlev, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, n[0], n[1], cu_count));
+                    if (!dominant) dominant = "k_fwd2d_lds";
+                    lstep = nlev;
+                    int64_t hn2[3] = {n[0] >> nlev, n[1] >> nlev, n[2]};
+                    cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                    continue;
+                }
             }
         }
         // ---- streaming 2-D, two levels fused (f32) ----

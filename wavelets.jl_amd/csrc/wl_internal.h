@@ -14,11 +14,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/wavelets_mi355x.h"
 
 #pragma clang fp contract(off)
 
 namespace wl {
+
+// ---- per-context options (wl_ctx_set_option) ------------------------------------------------
+// Tuning / test switches live on the context, never in the process environment.  Every ABI entry point installs
+// its context's table for the duration of the call (CallScope, wl_ctx.h); kernels' launchers read it with opt().
+// None of them changes a result: they select between kernel families that are bit-identical by construction.
+struct Opts {
+    enum { kMax = 32, kKeyLen = 32 };
+    int n = 0;
+    char key[kMax][kKeyLen];
+    long long val[kMax];
+};
+extern thread_local const Opts *tl_opts;
+inline long long opt(const char *name, long long dflt)
+{
+    const Opts *o = tl_opts;
+    if (o)
+        for (int i = 0; i < o->n; ++i)
+            if (strcmp(o->key[i], name) == 0) return o->val[i];
+    return dflt;
+}
 
 template <typename T>
 struct Taps {

@@ -15,7 +15,6 @@
 //   S = sum over m descending, (o-m) even, of h[m]*s[(o-m)/2];  D = sum over m ascending, (o+m-1) even, of g[m]*d[(o+m-1)/2]
 #include "wl_fast.h"
 
-#include <cstdlib>
 
 namespace wl {
 
@@ -497,11 +496,7 @@ static hipError_t launch_tail_inv(hipStream_t st, const Taps<T> &taps, const T *
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int i_env(const char *name, int dflt)
-{
-    const char *s = std::getenv(name);
-    return (s && *s) ? std::atoi(s) : dflt;
-}
+static inline int i_env(const char *name, int dflt) { return (int)opt(name, dflt); }   // per-context options
 static inline bool i_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int F>

@@ -18,7 +18,6 @@
 // x += c1*a; x += c2*b; ... (lift_perboundary!, :437-451); no FMA contraction.
 #include "wl_fast.h"
 
-#include <cstdlib>
 
 namespace wl {
 
@@ -724,17 +723,13 @@ static hipError_t launch_tail_lift2d(hipStream_t st, const LiftScheme<T> &sc, co
     }
     const int work = n0 * n0;
     int threads = work >= 2048 ? 1024 : (work >= 512 ? 256 : 64);
-    if (const char *e = std::getenv("WL_LIFT_TAIL_THREADS")) { if (*e && std::atoi(e) >= 64) threads = std::atoi(e); }
+    if (opt("WL_LIFT_TAIL_THREADS", 0) >= 64) threads = (int)opt("WL_LIFT_TAIL_THREADS", 0);
     hipLaunchKernelGGL((k_tail_lift2d<T, FW>), dim3(1), dim3(threads), shmem, st, a, sc);
     return hipGetLastError();
 }
 
 // --------------------------------------------------------------------------------------------------
-static int l_env(const char *name, int dflt)
-{
-    const char *s = std::getenv(name);
-    return (s && *s) ? std::atoi(s) : dflt;
-}
+static inline int l_env(const char *name, int dflt) { return (int)opt(name, dflt); }   // per-context options
 
 template <typename T>
 constexpr int lift_tail_cap() { return sizeof(T) == 4 ? 16384 : 8192; }
@@ -1425,8 +1420,8 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;
     while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
-    const char *e = std::getenv("WL_LIFT_TP");
-    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    const int tpo = (int)opt("WL_LIFT_TP", 0);
+    if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     hipLaunchKernelGGL((k_lift2d_inv<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
@@ -1441,8 +1436,8 @@ static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;
     while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
-    const char *e = std::getenv("WL_LIFT_TP");
-    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    const int tpo = (int)opt("WL_LIFT_TP", 0);
+    if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     hipLaunchKernelGGL((k_lift2d_fwd<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
@@ -1456,8 +1451,8 @@ static hipError_t launch_lift_axis_r(hipStream_t st, LiftAxisArgs<T> a, int64_t 
     const int64_t half = a.C >> 1;
     int TP = 64;
     while (TP > 8 && (int64_t)a.nstrips * ((half + TP - 1) / TP) * batch < (int64_t)cu_count * 8) TP >>= 1;
-    const char *e = std::getenv("WL_LIFT_TP");          // test knob: force the chunk length (multiple of 8)
-    if (e && *e && std::atoi(e) >= 8 && (std::atoi(e) % 8) == 0) TP = std::atoi(e);
+    const int tpo = (int)opt("WL_LIFT_TP", 0);          // test knob: force the chunk length (multiple of 8)
+    if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((half + TP - 1) / TP);
     for (int64_t b0 = 0; b0 < batch; b0 += 32768) {

@@ -56,6 +56,41 @@ def _check(rc: int, ctx=None):
 # ---- contexts: one per (device, stream) ------------------------------------------------------
 _CTX = {}
 _FORCE_PATH = 0      # tests flip this to 1 to run the generic kernels only
+_OPTIONS = {}        # wl_ctx_set_option pairs applied to every context (existing and future)
+
+
+def set_option(key: str, value: int):
+    """Set a tuning / test switch (wl_ctx_set_option) on every context of this process.  No option changes a
+    result; the library reads no environment variables."""
+    _OPTIONS[str(key)] = int(value)
+    for h in _CTX.values():
+        _check(_lib.load().wl_ctx_set_option(h, str(key).encode(), int(value)))
+
+
+def clear_options():
+    _OPTIONS.clear()
+    for h in _CTX.values():
+        _check(_lib.load().wl_ctx_clear_options(h))
+
+
+class options:
+    """with W.options(WL_FUSE2_MIN=0): ...   -- options set for the block, previous table restored afterwards."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(_OPTIONS)
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        saved = self.saved
+        clear_options()
+        for k, v in saved.items():
+            set_option(k, v)
+        return False
 
 
 def set_kernel_path(path: int):
@@ -79,6 +114,8 @@ def _context(device: torch.device):
         _check(lib.wl_ctx_create(idx, C.byref(out)))
         h = out
         _check(lib.wl_ctx_set_path(h, _FORCE_PATH))
+        for k, v in _OPTIONS.items():
+            _check(lib.wl_ctx_set_option(h, k.encode(), v))
         _CTX[key] = h
     return h, C.c_void_p(stream)
 

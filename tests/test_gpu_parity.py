@@ -223,6 +223,52 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
                 assert np.array_equal(y, ye), (shape, fname, L, mode, pair, float(np.abs(y - ye).max()))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tail2_kernel(gpu, W, oracle, dtype):
+    """k_tail2_fwd (all remaining levels of a power-of-two block / line <= 16 KiB in one launch, mask wrap): every
+    supported filter length, every depth down to 2 x 2 (lines shorter than the filter wrap several times), square and
+    non-square blocks, 1-D lines, batched lines, forced thread counts -- bit for bit against the oracle and against the
+    general tail kernel."""
+    cap = 4096 if dtype == np.float32 else 2048
+    W.set_option("WL_NO_MULTI2D", 1)          # (64 x 64 blocks would otherwise take one pass of the tile kernel first)
+    for threads in (0, 64, 256):
+        W.set_option("WL_TAIL2_THREADS", threads)
+        for shape in ((64, 64), (32, 32), (64, 32), (16, 64), (8, 8), (4, 4), (2, 2), (128, 16), (2, 64), (64, 2)):
+            if shape[0] * shape[1] > cap:
+                continue
+            x = rng_array(shape, dtype, sum(shape) + threads)
+            Lmax = W.maxtransformlevels(x)
+            for fname in ("db4", "haar", "db2", "db3", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                for L in sorted({1, 2, Lmax - 1, Lmax} - {0}):
+                    if L > Lmax:
+                        continue
+                    y = host(W, W.dwt(dev(W, x), wt, L))
+                    assert W.last_kernel() == "k_tail2_fwd", (shape, L, W.last_kernel())
+                    assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname, L, threads)
+        for n in (2, 4, 8, 64, 512, 2048, 4096):
+            if n > cap:
+                continue
+            x = rng_array((n,), dtype, n + threads)
+            Lmax = W.maxtransformlevels(n)
+            for fname in ("db4", "haar", "db3", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                for L in sorted({1, Lmax // 2, Lmax} - {0}):
+                    y = host(W, W.dwt(dev(W, x), wt, L))
+                    assert W.last_kernel() == "k_tail2_fwd", (n, L, W.last_kernel())
+                    assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, L)), (n, fname, L, threads)
+        xm = rng_array((256, 37), dtype, 5)                      # batched lines: one workgroup per line
+        wt = W.wavelet(W.WT.db4)
+        assert np.array_equal(host(W, W.dwtc(dev(W, xm), wt, 8)), oracle.dwtc_filter(xm, wt.qmf, 8))
+    W.set_option("WL_TAIL2", 0)                                  # the general tail kernel stays reachable and agrees
+    x = rng_array((64, 64), dtype, 1)[:, : (64 if dtype == np.float32 else 32)]
+    x = np.ascontiguousarray(x)
+    wt = W.wavelet(W.WT.db4)
+    y = host(W, W.dwt(dev(W, x), wt, 5))
+    assert W.last_kernel() == "k_tail_fwd"
+    assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 5))
+
+
 def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle):
     """Seeded random sweep over shapes that sit on the eligibility boundaries of the fast kernels
     (strip/tile/chunk multiples, alignment, wrap) -- forward and inverse, against the oracle."""

@@ -49,6 +49,13 @@ hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, b
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
                             int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
 
+// Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
+template <typename T>
+bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev);
+template <typename T>
+hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,
+                        int64_t src_item, int64_t y_item, int nitems, int m0, int m1, int nt, int nlev);
+
 // Long filters (12, 14, 16, 18, 20, 24 taps): one level of contiguous lines / of the strided axis of a matrix (wl_axis.hip).
 bool long_filter_ok(int F);
 template <typename T>

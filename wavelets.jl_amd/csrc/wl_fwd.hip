@@ -1197,8 +1197,8 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         Strides3 box_st = dense_strides(n);
 
         // ---- 2-D multi-level tiles for the cache-resident levels (two levels per launch) ----
-        if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 128) &&
-            n[1] <= env_int("WL_M2D_MAX", 128) && n[0] >= 64 && n[1] >= 64 && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
+        if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 1024) &&
+            n[1] <= env_int("WL_M2D_MAX", 1024) && n[0] >= env_int("WL_M2D_MIN", 64) && n[1] >= env_int("WL_M2D_MIN", 64) && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
             cur_st.s[0] == 1) {
             int NL = (L - l + 1);
             const int nl2max = env_int("WL_M2D_NL", 2);
@@ -1226,11 +1226,16 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
             if (blk <= (two_d ? (int64_t)tail_cap<T>() : line_cap) && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
-                if (two_d)
-                    WL_TRY(launch_tail<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
-                else   // one workgroup per line
-                    WL_TRY(launch_tail<T>(st, taps, cur, 0, y, 0, cur_st.s[1], b.full.s[1], (int)nlines, (int)n[0], 1, 1, L - l + 1));
-                if (!dominant) dominant = "k_tail_fwd";
+                // power-of-two blocks / lines of <= 16 KiB: the latency-optimised tail (wl_tail.hip)
+                const bool t2 = env_int("WL_TAIL2", 1) && tail2_ok<T>(F, two_d ? 2 : 1, n[0], two_d ? n[1] : 1, L - l + 1);
+                if (two_d) {
+                    if (t2) WL_TRY(launch_tail2<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
+                    else WL_TRY(launch_tail<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
+                } else {   // one workgroup per line
+                    if (t2) WL_TRY(launch_tail2<T>(st, taps, cur, 0, y, 0, cur_st.s[1], b.full.s[1], (int)nlines, (int)n[0], 1, 1, L - l + 1));
+                    else WL_TRY(launch_tail<T>(st, taps, cur, 0, y, 0, cur_st.s[1], b.full.s[1], (int)nlines, (int)n[0], 1, 1, L - l + 1));
+                }
+                if (!dominant) dominant = t2 ? "k_tail2_fwd" : "k_tail_fwd";
                 break;
             }
         }
@@ -1264,7 +1269,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                 (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
                 int nlev = 0;
                 if ((L - l + 1) >= 2 && env_int("WL_FUSE2", 1) && fwd2d_lds_ok(F, 2, n[0], n[1]) &&
-                    n[0] * n[1] >= (int64_t)env_int_raw("WL_LDS_PAIR_MIN", 1 << 20))
+                    n[0] * n[1] >= (int64_t)opt("WL_LDS_PAIR_MIN", (long long)1 << 62))
                     nlev = 2;
                 else if (fwd2d_lds_ok(F, 1, n[0], n[1]))
                     nlev = 1;

@@ -1,0 +1,202 @@
+// wl_tail.hip -- the deep end of a forward filter-bank transform: ALL remaining levels of a small power-of-two block
+// (2-D: m0 x m1 <= 4096 elements; 1-D: a line of <= 4096 samples, one workgroup per line for batches) in one launch.
+//
+// At these sizes a level is pure latency: a 64 x 64 block is 16 KiB and the 32 x 32 ... 2 x 2 levels below it hold less
+// data than one wave's registers, yet every level is two dependent passes (reference transforms_filter.jl:161-172:
+// dim 2 then dim 1) with an all-to-all between them.  k_tail_fwd (wl_fwd.hip, any size/filter) spends ~0.7 us per
+// pass on index arithmetic with run-time wrap loops; here the block extents are powers of two, so
+//   * periodic wrap is a bit mask, every LDS address of a window is known before the first read is issued
+//     (2F-2 independent ds_read per output pair, issued back to back);
+//   * the dim-1 pass (contiguous lines) reads its window as F-1 aligned 8-byte pairs;
+//   * F is a compile-time constant, the taps live in SGPRs;
+//   * barriers order LDS traffic only (detail coefficients stream to HBM while the next pass runs).
+// Same closed forms and summation order as everywhere else (wl_internal.h): bit-identical to the generic kernels.
+#include "wl_fast.h"
+#include "wl_dev.h"
+
+namespace wl {
+
+template <typename T, int F>
+struct Tail2Args {
+    const T *src; int64_t s1;       // source block: element (i, j) at src[i + j*s1]
+    T *y; int64_t ldy;              // destination array (same origin as the block)
+    int64_t src_item, y_item;       // per-blockIdx.x offsets (batched lines)
+    int lg0, lg1;                   // block extents 2^lg0 x 2^lg1 (lg1 = 0 with nt = 1: a line)
+    int nt;                         // 1: transform dim 1 only; 2: both dims
+    int nlev;
+    TapsF<T, F> tp;
+};
+
+// (s, d) of pair k from the 2F-2 window values xv[e] = x[(2k - (F-2) + e) mod n]
+template <typename T, int F>
+__device__ __forceinline__ void window_sd(const T (&xv)[2 * F - 2 > 0 ? 2 * F - 2 : 2], const TapsF<T, F> &tp, T &s, T &d)
+{
+    s = tp.h[0] * xv[F - 2];
+#pragma unroll
+    for (int m = 1; m < F; ++m) s = s + tp.h[m] * xv[F - 2 + m];
+    d = tp.g[F - 1] * xv[0];
+#pragma unroll
+    for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * xv[F - 1 - m];
+}
+
+template <typename T, int F>
+__global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
+{
+    typedef typename VecOf<T, 2>::type T2;
+    constexpr int NW = (F == 2) ? 2 : 2 * F - 2;          // window length (F = 2: the pair itself)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const bool multi = nthr > 64;
+    const int m0 = 1 << a.lg0, m1 = 1 << a.lg1;
+    const int ld = (m1 > 1) ? (m0 + 2) : m0;              // even: the 8-byte window reads stay aligned
+    T *A = reinterpret_cast<T *>(smem_raw);
+    T *B = A + (size_t)ld * m1 + 8;
+    const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
+    T *y = a.y + (int64_t)blockIdx.x * a.y_item;
+
+    // ---- stage the block (16-byte loads when the layout allows, all of a thread's loads in flight together) ----
+    {
+        constexpr int VW = 16 / sizeof(T);
+        const int total = m0 * m1;
+        const bool vec_ok = (m0 % VW) == 0 && (a.s1 % VW) == 0 && (a.src_item % VW) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
+        if (vec_ok) {
+            const int totalv = total / VW, lgv = a.lg0 - (VW == 4 ? 2 : 1);
+            for (int idx = tid; idx < totalv; idx += 4 * nthr) {
+                T v[4][VW];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int id = idx + r * nthr;
+                    if (id < totalv) vload<T, VW>(src + (id & ((1 << lgv) - 1)) * VW + (int64_t)(id >> lgv) * a.s1, v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int id = idx + r * nthr;
+                    if (id < totalv) {
+                        T *dst = A + (id & ((1 << lgv) - 1)) * VW + (id >> lgv) * ld;      // ld even: 8-byte aligned at least
+#pragma unroll
+                        for (int e = 0; e < VW; e += 2) *reinterpret_cast<T2 *>(dst + e) = T2{v[r][e], v[r][e + 1]};
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += nthr) A[(idx & (m0 - 1)) + (idx >> a.lg0) * ld] = src[(idx & (m0 - 1)) + (int64_t)(idx >> a.lg0) * a.s1];
+        }
+    }
+    if (multi) lds_barrier_vm(); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    for (int lev = 0; lev < a.nlev; ++lev) {
+        const bool last = (lev == a.nlev - 1);
+        const int lgn0 = a.lg0 - lev, n0 = 1 << lgn0, h0 = n0 >> 1;
+        if (a.nt == 2) {
+            const int lgn1 = a.lg1 - lev, n1 = 1 << lgn1, h1 = n1 >> 1;
+            // ---- dim-2 pass: A (n0 x n1) -> B, [s ; d] along j; lanes along i ----
+            for (int idx = tid; idx < (h1 << lgn0); idx += nthr) {
+                const int i = idx & (n0 - 1), k = idx >> lgn0;
+                const T *p = A + i;
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW; ++e) xv[e] = p[((2 * k - (F - 2) + e) & (n1 - 1)) * ld];
+                T s, d;
+                window_sd<T, F>(xv, a.tp, s, d);
+                B[i + k * ld] = s;
+                B[i + (h1 + k) * ld] = d;
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- dim-1 pass: B -> details to y, approximation to A (h0 x h1) or y; lanes along k ----
+            for (int idx = tid; idx < (n1 << (lgn0 - 1)); idx += nthr) {
+                const int k = idx & (h0 - 1), j = idx >> (lgn0 - 1);
+                const T *p = B + j * ld;
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW / 2; ++e) {
+                    const T2 v = *reinterpret_cast<const T2 *>(p + ((2 * k - (F - 2) + 2 * e) & (n0 - 1)));
+                    xv[2 * e] = v.x; xv[2 * e + 1] = v.y;
+                }
+                T s, d;
+                window_sd<T, F>(xv, a.tp, s, d);
+                T *yc = y + (int64_t)j * a.ldy;
+                yc[h0 + k] = d;
+                if (j < h1 && !last) A[k + j * ld] = s;
+                else yc[k] = s;
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            for (int k = tid; k < h0; k += nthr) {
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW / 2; ++e) {
+                    const T2 v = *reinterpret_cast<const T2 *>(A + ((2 * k - (F - 2) + 2 * e) & (n0 - 1)));
+                    xv[2 * e] = v.x; xv[2 * e + 1] = v.y;
+                }
+                T s, d;
+                window_sd<T, F>(xv, a.tp, s, d);
+                y[h0 + k] = d;
+                if (last) y[k] = s;
+                else B[k] = s;
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            T *t = A; A = B; B = t;
+        }
+    }
+}
+
+template <typename T>
+bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev)
+{
+    if (F < 2 || F > 10 || (F & 1)) return false;
+    auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
+    if (!pow2(m0) || (nt == 2 && !pow2(m1))) return false;
+    if (nt == 1 && m1 != 1) return false;
+    const int64_t cap = 16384 / (int64_t)sizeof(T);                  // 4096 f32 / 2048 f64 elements
+    if (m0 * m1 > cap) return false;
+    // every level needs both extents >= 2
+    int lg0 = 0, lg1 = 0;
+    while (((int64_t)1 << lg0) < m0) ++lg0;
+    while (((int64_t)1 << lg1) < m1) ++lg1;
+    if (nlev < 1 || nlev > lg0 || (nt == 2 && nlev > lg1)) return false;
+    return true;
+}
+
+template <typename T, int F>
+static hipError_t launch_tail2_f(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,
+                                 int64_t src_item, int64_t y_item, int nitems, int m0, int m1, int nt, int nlev)
+{
+    Tail2Args<T, F> a;
+    a.src = src; a.s1 = s1; a.y = y; a.ldy = ldy; a.src_item = src_item; a.y_item = y_item; a.nt = nt; a.nlev = nlev;
+    a.lg0 = 0; a.lg1 = 0;
+    while ((1 << a.lg0) < m0) ++a.lg0;
+    while ((1 << a.lg1) < m1) ++a.lg1;
+    a.tp = shrink<T, F>(taps);
+    const int ld = (m1 > 1) ? (m0 + 2) : m0;
+    const size_t shmem = (2 * ((size_t)ld * m1 + 8)) * sizeof(T);
+    const int pairs = m0 * m1 / 2;                                   // output pairs of the first pass
+    int threads = pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64));
+    const int to = (int)opt("WL_TAIL2_THREADS", 0);
+    if (to >= 64 && to <= 512 && (to % 64) == 0) threads = to;
+    hipLaunchKernelGGL((k_tail2_fwd<T, F>), dim3((unsigned)nitems), dim3(threads), shmem, st, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,
+                        int64_t src_item, int64_t y_item, int nitems, int m0, int m1, int nt, int nlev)
+{
+    switch (taps.F) {
+    case 2: return launch_tail2_f<T, 2>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 4: return launch_tail2_f<T, 4>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 6: return launch_tail2_f<T, 6>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 8: return launch_tail2_f<T, 8>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 10: return launch_tail2_f<T, 10>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template bool tail2_ok<float>(int, int, int64_t, int64_t, int);
+template bool tail2_ok<double>(int, int, int64_t, int64_t, int);
+template hipError_t launch_tail2<float>(hipStream_t, const Taps<float> &, const float *, int64_t, float *, int64_t, int64_t, int64_t, int, int, int,
+                                        int, int);
+template hipError_t launch_tail2<double>(hipStream_t, const Taps<double> &, const double *, int64_t, double *, int64_t, int64_t, int64_t, int, int,
+                                         int, int, int);
+
+}  // namespace wl

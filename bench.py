@@ -5,10 +5,13 @@ A "step" is one full forward transform (the non-allocating dwt!(y, x, wt, L) ent
 synthetic array already resident in HBM:
     default workload  C3 = 2-D dwt, WT.db4 filter bank, 8192 x 8192 Float32, L = 13 (API default)
                       (BASELINE.json configs[2], the configuration the metric is quoted on)
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank transforms
-its own independent 8192 x 8192 array (a batch of N images sharded one per GPU: weak scaling, no
-data-path collective; the filter taps are broadcast from rank 0 over RCCL/xGMI before the timed
-region, as north_star prescribes).  value = whole-job Msamples/s = N * samples / max-over-ranks time.
+With --gpus N > 1 the script runs one rank per GPU over RCCL: under torch.distributed.run (the driver's form) it
+reads RANK / LOCAL_RANK / WORLD_SIZE; started plainly (`python bench.py --gpus N`) it re-launches ITSELF through
+torch.distributed.run with N ranks.  Every rank transforms its own independent 8192 x 8192 array (a batch of N images
+sharded one per GPU: weak scaling, no data-path collective; the filter taps are broadcast from rank 0 over
+RCCL/xGMI before the timed region, as north_star prescribes).  value = whole-job Msamples/s = N * samples /
+max-over-ranks time.  Beside it, `c5_batched` reports BASELINE.json configs[4]: the 65536-signal x 2^16 batch sharded
+65536/N columns per rank (sharding.shard_range), aggregate Msamples/s and GB/s, checksum all-reduced.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (the level-1 launch of k_fwd2d_stream, which moves 8 B/sample):
@@ -45,7 +48,28 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--path", type=int, default=0, help="0 fast kernels, 1 generic kernels only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs")
+    ap.add_argument("--no-c5", action="store_true", help="skip the sharded C5 batch object")
+    ap.add_argument("--c5-signals", type=int, default=65536, help="total signals of the sharded C5 batch (BASELINE: 65536)")
+    ap.add_argument("--stub-backend", default=None, help=argparse.SUPPRESS)   # tests only: 'gloo' = CPU ranks, stub transform
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def respawn_command(args, argv):
+    """`python bench.py --gpus N` started without a launcher: the torch.distributed.run command line that runs the same
+    script with N ranks on this node (None when no re-launch is needed)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
 
 
 def make_workload(W, name, device, seed):
@@ -71,13 +95,49 @@ def make_workload(W, name, device, seed):
     raise ValueError(name)
 
 
+def stub_main(args, rank, world):
+    """Launcher / reduction plumbing on CPU ranks (tests/test_bench_launch.py): gloo backend, the transform replaced by a
+    copy.  Never a measurement: the line says so."""
+    import torch.distributed as dist
+    from wavelets_jl_amd import sharding
+    dist.init_process_group(backend=args.stub_backend)
+    cpu = torch.device("cpu")
+    x = torch.full((64, 64), float(rank + 1))
+    y = torch.empty_like(x)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y.copy_(x)
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dist, cpu)
+    lo, hi = sharding.shard_range(args.c5_signals, rank, dist.get_world_size())
+    cols = sharding.sum_over_ranks(float(hi - lo), dist, cpu)
+    checksum = sharding.sum_over_ranks(float(y.sum()), dist, cpu)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (launcher test, no transform ran)", "stub": True, "value": 0.0, "unit": "Msamples/s",
+                          "n_gpus": dist.get_world_size(), "gpus_requested": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(1, args.steps) * 1e3, "backend": args.stub_backend,
+                          "c5_signals_covered": cols, "checksum_all_ranks": checksum}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    cmd = respawn_command(args, sys.argv[1:])
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.stub_backend:
+        return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} HIP devices are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -155,12 +215,21 @@ def main():
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtag, "data": "synthetic (standard normal, seed 42 + 1000*rank), resident in HBM",
         "config": {"workload": label, "L": int(L), "arrays": world, "parallelism": f"{world} independent arrays, one per GPU",
-                   "kernel": kernel, "kernel_path": "generic" if args.path else "fast"},
+                   "kernel": kernel, "kernel_path": "generic" if args.path else "fast", "gpus_requested": args.gpus,
+                   "world_size": (dist.get_world_size() if dist is not None else 1),
+                   "backend": (dist.get_backend() + " (RCCL)" if dist is not None else "single process"),
+                   "untimed_precondition_steps": precondition},
         "achieved_hbm_GBps_algorithmic": round(gbps, 1), "precondition_steps": precondition,
         "checksum_all_ranks": checksum,
         "device_ms_per_step": round(dev_ms_per_step, 5),
     }
 
+    if args.workload == "c3" and not args.no_c5:
+        # every rank takes part (barriers / reductions inside); the object is kept by rank 0
+        del y
+        c5 = c5_batched_leg(W, sharding, dist, device, rank, world, args)
+        if rank == 0:
+            out["c5_batched"] = c5
     if rank == 0 and world == 1 and not batched:
         out["pipelined"] = pipelined_leg(W, x, wt, L, args)
     if rank == 0:
@@ -184,6 +253,48 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def c5_batched_leg(W, sharding, dist, device, rank, world, args):
+    """BASELINE.json configs[4]: batched column-wise dwt, WT.db4, `--c5-signals` (65536) signals x 2^16 Float32, L = 16,
+    the batch sharded by columns over the ranks (rank r owns sharding.shard_range(signals, r, world): 65536/N columns, no
+    signal data crosses GPUs); rank 0's filter taps reach the others by one RCCL broadcast.  Strong scaling of a fixed
+    batch: value = signals * 2^16 / max-over-ranks time.  Protocol as the headline: barrier + synchronize, warm-up,
+    K timed steps, synchronize, MAX over ranks; checksum SUM-reduced over RCCL."""
+    n = 1 << 16
+    lo, hi = sharding.shard_range(args.c5_signals, rank, world)
+    ncol = hi - lo
+    wt = sharding.broadcast_wavelet(W.wavelet(W.WT.db4), dist, device)
+    g = torch.Generator(device=device).manual_seed(4242 + 1000 * rank)
+    x = torch.randn(ncol, n, generator=g, dtype=torch.float32, device=device).t()      # Julia layout: n x ncol, column = signal
+    y = W.similar(x)
+    fn = lambda: W.dwtc_(y, x, wt, 16)
+    steps, warm = 5, 2
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    dt = sharding.max_over_ranks(dt, dist, device) / steps
+    checksum = sharding.sum_over_ranks(float(y.sum(dtype=torch.float64).item()), dist, device)
+    kernel = W.last_kernel()
+    total = args.c5_signals * n
+    del x, y
+    W.destroy_contexts()                     # (the batch's workspace)
+    torch.cuda.empty_cache()
+    return {"workload": f"batched column-wise dwt db4, {args.c5_signals} signals x 2^16 f32, L=16, sharded over {world} GPU(s)",
+            "signals_total": args.c5_signals, "signals_per_rank": ncol, "scaling": "strong", "steps": steps, "warmup": warm,
+            "ms_per_step": round(dt * 1e3, 4), "Msamples_per_s": round(total / dt / 1e6, 1),
+            "aggregate_algorithmic_GBps": round(8.0 * total / dt / 1e9, 1), "checksum_all_ranks": checksum, "kernel": kernel,
+            "collectives": "1 broadcast of the taps (256 B), 1 MAX + 1 SUM all-reduce of 8 B; no signal data crosses GPUs"}
 
 
 def pipelined_leg(W, x, wt, L, args, nstreams=4):
@@ -282,22 +393,56 @@ def _time_launches(fn, reps):
     return sum(durs) / len(durs), durs[len(durs) // 2], durs[0]
 
 
+def _time_back_to_back(fn, reps):
+    """Average duration of one launch inside a train of `reps` identical launches (one event pair around the train: no host
+    gaps between the launches, which is how the kernel runs inside a transform)."""
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _rocprof_summary(kname_substr):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this same
+    command (profiles/r02_c3_kernel_stats.csv), so that the line can be checked against profiles/ without a GPU."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r02_c3_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    best = None
+    for r in csv.DictReader(open(path)):
+        if kname_substr in r.get("Name", ""):
+            if best is None or float(r["AverageNs"]) > float(best["AverageNs"]):
+                best = r
+    if best is None:
+        return None
+    return {"file": "profiles/r02_c3_kernel_stats.csv", "kernel": best["Name"], "calls": int(best["Calls"]),
+            "avg_launch_ms": round(float(best["AverageNs"]) * 1e-6, 5)}
+
+
 def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
     """Dominant kernel = the launch that consumes the full-size input.  Its algorithmic bytes are
     2*N*sizeof(T): it reads every input sample once and writes N coefficients (8 B/sample
-    f32) -- that holds for the single-level kernels and for k_fwd2d_stream2, which finishes TWO levels
+    f32) -- that holds for the single-level kernels and for the fused-pair kernels, which finish TWO levels
     in the same pass (3/4 N level-1 details + 1/4 N level-2 coefficients).  A call with L = 1 (L = 2
-    for the fused pair kernel) is exactly one launch of that kernel, so HIP events around such calls
-    on the launch stream give its average duration; rocprofv3 --stats reports the same instance
-    (the first-level launch has its own template instantiation)."""
-    Ldom = 2 if main_kernel == "k_fwd2d_stream2" else 1
+    for a fused pair) is exactly one launch of that kernel (its first-level template instance, which
+    rocprofv3 --stats reports under its own name).  `frac` uses HIP events on the launch stream around a train of
+    such launches (live, this run); `rocprof` repeats the computation from the committed rocprofv3 summary."""
+    Ldom = 2 if main_kernel in ("k_fwd2d_stream2", "k_fwd2d_lds2") else 1
     y1 = W.similar(x)
     fn1 = (lambda: W.dwtc_(y1, x, wt, Ldom)) if batched else (lambda: W.dwt_oop_(y1, x, wt, Ldom))
-    reps = max(20, args.steps)
+    reps = max(20, min(args.steps, 200))
+    train_ms = _time_back_to_back(fn1, reps)
     avg_ms, med_ms, min_ms = _time_launches(fn1, reps)
     kname = W.last_kernel()
     alg_bytes = 2 * x.numel() * esize
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (train_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     note = "traffic: no PMC summary committed yet"
@@ -312,16 +457,17 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
     out = {"bound": "hbm", "kernel": f"{kname} (first launch: level{'s 1-2' if Ldom == 2 else ' 1'})",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
-           "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
+           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(train_ms, 5),
+           "timing": f"HIP events around a train of {reps} launches on the launch stream",
+           "isolated_launch_ms": {"avg": round(avg_ms, 5), "median": round(med_ms, 5), "min": round(min_ms, 5),
+                                  "note": "one event pair per launch: includes the idle-stream launch latency"},
            "launches_timed": reps, "traffic_note": note,
            "frac_of_measured_copy_6290GBps": round(achieved / 6290.0, 4)}
-    if Ldom == 2:
-        # for reference: the single-level kernel (L = 1 call) on the same array
-        a1, m1, _ = _time_launches((lambda: W.dwt_oop_(y1, x, wt, 1)), reps)
-        out["single_level_kernel"] = {"kernel": W.last_kernel() + " (level 1 only)", "avg_launch_ms": round(a1, 5),
-                                      "achieved": round(alg_bytes / (a1 * 1e-3) / 1e9, 1),
-                                      "frac": round(alg_bytes / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    rp = _rocprof_summary(kname)
+    if rp is not None:
+        rp["achieved"] = round(alg_bytes / (rp["avg_launch_ms"] * 1e-3) / 1e9, 1)
+        rp["frac"] = round(rp["achieved"] / HBM_PEAK_GBPS, 4)
+        out["rocprof"] = rp
     return out
 
 
@@ -341,12 +487,17 @@ def cpu_baseline_leg(W, workload, wt, L):
         dt = time.perf_counter() - t0
         sample = f"one full 2-D db4 dwt of the {n}x{n} f32 array, L={L}, 1 thread (the reference has no threading)"
         ns = xs.size
-        # secondary number: the same algorithm with its per-level line loops on every host core (OpenMP)
+        # anchor against the one number the reference publishes for this path (README.md:249-250: 1-D db2 dwt of 2^20
+        # Float64, 20 levels, 24.8 ms per call on unstated hardware): the same call through the oracle on this host
+        x1 = rng.random(1 << 20)
+        db2 = W.wavelet(W.WT.db2)
+        oracle.dwt_filter(x1, db2.qmf, 20)
         t1 = time.perf_counter()
-        oracle.dwt2d_filter_mt(xs, wt.qmf, L)
-        dt_mt = time.perf_counter() - t1
-        extra = {"all_cores": {"value": round(ns / dt_mt / 1e6, 2), "unit": "Msamples/s", "cores": oracle.max_threads(),
-                               "kind": "port", "sample": "same array, line loops parallelised with OpenMP", "seconds": round(dt_mt, 2)}}
+        for _ in range(5):
+            oracle.dwt_filter(x1, db2.qmf, 20)
+        c1_ms = (time.perf_counter() - t1) / 5 * 1e3
+        extra = {"c1_anchor": {"workload": "1-D dwt db2 filter 2^20 f64, L=20, 1 thread", "oracle_ms_per_call": round(c1_ms, 2),
+                               "reference_readme_ms_per_call": 24.8, "reference_hardware": "unstated (README.md:249-250)"}}
     else:
         # parity-test configs: repeat full-size (c5: a 1/64 sub-batch) transforms for about 10 s
         if workload == "c1":

@@ -92,14 +92,14 @@ def dwt_filter(x: np.ndarray, qmf, L=None, fw=True) -> np.ndarray:
     return np.ascontiguousarray(yf)
 
 
-def dwt2d_filter_mt(x: np.ndarray, qmf, L=None) -> np.ndarray:
-    """forward 2-D filter dwt, the per-level line loops on all OpenMP threads (same results as dwt_filter)"""
+def dwt2d_filter_mt(x: np.ndarray, qmf, L=None, fw=True) -> np.ndarray:
+    """2-D filter dwt / idwt, the per-level line loops on all OpenMP threads (bit-identical to dwt_filter)"""
     xf = _col(x)
     yf = np.empty_like(xf, order="F")
     q = np.ascontiguousarray(qmf, dtype=np.float64)
     L = maxtransformlevels(x) if L is None else L
     rc = lib().wlo_dwt2d_filter_mt(_dt(xf), _p(yf), _p(xf), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]),
-                                   q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L))
+                                   q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), 1 if fw else 0)
     if rc:
         raise OracleError(rc)
     return np.ascontiguousarray(yf)
@@ -309,7 +309,9 @@ def noisest(x: np.ndarray, transform, L=1) -> float:
     y[detailrange(y, L)] is LINEAR indexing with size(y, 1): for matrices it takes the lower half of the first column."""
     y = x if transform is None else transform(x, L)
     n1 = y.shape[0]
-    lo, hi = n1 >> L, n1 >> (L - 1)                      # 0-based [lo, hi)
+    # detailrange(n, L) = round(Int, n/2^L + 1) : round(Int, n/2^(L-1)), ties to even (non_dyadic.jl:7); Python's round()
+    # is the same banker's rounding.  0-based half-open: [lo, hi)
+    lo, hi = int(round(n1 / 2 ** L + 1)) - 1, int(round(n1 / 2 ** (L - 1)))
     dr = np.asfortranarray(y).reshape(-1, order="F")[lo:hi].copy()
     return mad(dr) / 0.6745
 

@@ -212,13 +212,13 @@ WLO_API int wlo_dwt_filter(int dtype, void *y, const void *x, int ndims, const i
     return WLO_EINVAL_DTYPE;
 }
 
-/* 2-D forward filter dwt with the line loops on OpenMP threads (cpu_baseline "all cores") */
+/* 2-D filter dwt / idwt with the line loops on OpenMP threads (bit-identical to the 1-thread loop) */
 WLO_API int wlo_dwt2d_filter_mt(int dtype, void *y, const void *x, int64_t m, int64_t n,
-                                const double *qmf, int flen, int L)
+                                const double *qmf, int flen, int L, int fw)
 {
     if (flen < 2 || flen > WLO_MAXF) return WLO_EINVAL_FILTER;
-    if (dtype == 0) return f_dwt2d_fw_mt_f32((float *)y, (const float *)x, (long)m, (long)n, qmf, flen, L);
-    if (dtype == 1) return f_dwt2d_fw_mt_f64((double *)y, (const double *)x, (long)m, (long)n, qmf, flen, L);
+    if (dtype == 0) return f_dwt2d_fw_mt_f32((float *)y, (const float *)x, (long)m, (long)n, qmf, flen, L, fw);
+    if (dtype == 1) return f_dwt2d_fw_mt_f64((double *)y, (const double *)x, (long)m, (long)n, qmf, flen, L, fw);
     return WLO_EINVAL_DTYPE;
 }
 WLO_API int wlo_max_threads(void)

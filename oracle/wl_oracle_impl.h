@@ -268,22 +268,24 @@ static int FN(f_dwt2d)(T *y, const T *x, long m, long n, const double *qmf, int 
     return 0;
 }
 
-/* Same 2-D forward algorithm as f_dwt2d, with the two per-level line loops
+/* Same 2-D algorithm as f_dwt2d (forward and inverse), with the two per-level line loops
  * (dwt_transform_strided! over rows, dwt_transform_cols! over columns) spread
  * over OpenMP threads, each with its own scratch (si, tmpvec).  The reference
- * itself is single-threaded; this variant exists only to report "the
- * reference's algorithm on all host cores" next to the 1-thread baseline.
- * Results are identical to f_dwt2d (lines are independent).                 */
-static int FN(f_dwt2d_fw_mt)(T *y, const T *x, long m, long n, const double *qmf, int flen, int L)
+ * itself is single-threaded; this variant exists so that the GPU tests can check the
+ * 8192 x 8192 configuration element by element in seconds.  Results are identical to
+ * f_dwt2d (lines are independent; tests/test_oracle_properties.py compares the bits). */
+static int FN(f_dwt2d_fw_mt)(T *y, const T *x, long m, long n, const double *qmf, int flen, int L, int fw)
 {
     if (L < 0) return WLO_EINVAL_L;
     if (!wlo_sufficientpoweroftwo(m, L) || !wlo_sufficientpoweroftwo(n, L)) return WLO_EINVAL_SIZE;
     if (y == x) return WLO_EALIAS;
     if (L == 0) { memcpy(y, x, (size_t)(m * n) * sizeof(T)); return 0; }
     T scf[WLO_MAXF], dcf[WLO_MAXF];
-    FN(makereverseqmfpair)(qmf, flen, 1, scf, dcf);
+    FN(makereverseqmfpair)(qmf, flen, fw, scf, dcf);
     long tl = (n << 1) > m ? (n << 1) : m;
-    long nsub = n, msub = m;
+    long nsub, msub;
+    if (fw) { nsub = n; msub = m; }
+    else { nsub = n / (1L << (L - 1)); msub = m / (1L << (L - 1)); memcpy(y, x, (size_t)(m * n) * sizeof(T)); }
     const T *inputArray = x;
     for (int it = 0; it < L; ++it) {
         const T *in = inputArray;
@@ -291,23 +293,38 @@ static int FN(f_dwt2d_fw_mt)(T *y, const T *x, long m, long n, const double *qmf
         {
             T si[WLO_MAXF];
             T *tmpbuffer = (T *)malloc((size_t)tl * sizeof(T));
+            if (fw) {
 #pragma omp for schedule(static)
-            for (long i = 1; i <= msub; ++i) {
-                FN(stridedcopy_in)(tmpbuffer, in, i, m, nsub);
-                FN(f_dwt1level)(tmpbuffer + nsub, tmpbuffer, nsub, flen, 1, dcf, scf, si);
-                FN(stridedcopy_out)(y, i, m, tmpbuffer + nsub, nsub);
-            }
+                for (long i = 1; i <= msub; ++i) {          /* rows (transforms_filter.jl:161-168) */
+                    FN(stridedcopy_in)(tmpbuffer, in, i, m, nsub);
+                    FN(f_dwt1level)(tmpbuffer + nsub, tmpbuffer, nsub, flen, fw, dcf, scf, si);
+                    FN(stridedcopy_out)(y, i, m, tmpbuffer + nsub, nsub);
+                }
 #pragma omp for schedule(static)
-            for (long i = 1; i <= nsub; ++i) {
-                long xi = 1 + (i - 1) * m;
-                memcpy(tmpbuffer, &A1(y, xi), (size_t)msub * sizeof(T));
-                FN(f_dwt1level)(&A1(y, xi), tmpbuffer, msub, flen, 1, dcf, scf, si);
+                for (long i = 1; i <= nsub; ++i) {          /* columns (:169-172) */
+                    long xi = 1 + (i - 1) * m;
+                    memcpy(tmpbuffer, &A1(y, xi), (size_t)msub * sizeof(T));
+                    FN(f_dwt1level)(&A1(y, xi), tmpbuffer, msub, flen, fw, dcf, scf, si);
+                }
+            } else {
+#pragma omp for schedule(static)
+                for (long i = 1; i <= nsub; ++i) {          /* columns first (:174-178) */
+                    long xi = 1 + (i - 1) * m;
+                    memcpy(tmpbuffer, &A1(in, xi), (size_t)msub * sizeof(T));
+                    FN(f_dwt1level)(&A1(y, xi), tmpbuffer, msub, flen, fw, dcf, scf, si);
+                }
+#pragma omp for schedule(static)
+                for (long i = 1; i <= msub; ++i) {          /* then rows (:179-183) */
+                    FN(stridedcopy_in)(tmpbuffer, y, i, m, nsub);
+                    FN(f_dwt1level)(tmpbuffer + nsub, tmpbuffer, nsub, flen, fw, dcf, scf, si);
+                    FN(stridedcopy_out)(y, i, m, tmpbuffer + nsub, nsub);
+                }
             }
             free(tmpbuffer);
         }
         inputArray = y;
-        msub >>= 1;
-        nsub >>= 1;
+        msub = fw ? msub >> 1 : msub << 1;
+        nsub = fw ? nsub >> 1 : nsub << 1;
     }
     return 0;
 }

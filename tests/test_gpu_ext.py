@@ -73,7 +73,7 @@ def test_threshold_bitexact(gpu, W, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_median_mad_bitexact(gpu, W, oracle, dtype):
-    for n in (1, 2, 3, 10, 11, 1000, 4097, (1 << 20) + 3, 1 << 21):
+    for n in (1, 2, 3, 10, 11, 1000, 4095, 4096, 4097, 8191, 8192, 8193, (1 << 20) + 3, 1 << 21):
         v = rng_array((n,), dtype, n)
         assert W.median(W.to_device(v)) == oracle.median(v), n
         vd = W.to_device(v)
@@ -121,6 +121,13 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
     vs = W.VisuShrink(n)
     wt = W.DEFAULT_WAVELET
     assert W.noisest(xd) == oracle.noisest(x, lambda a, l: oracle.dwt_filter(a, wt.qmf, l))
+    # wt = nothing on lengths without a 2^L factor: the detail range follows the reference's round(Int, .) (ties to even):
+    # n = 5, L = 1 -> Julia 4:5 (3.5 rounds to 4), n = 7 -> 4:7 (4.5 rounds to 4), n = 9, L = 2 -> 3:4
+    for n5, L5, lohi in ((5, 1, (3, 5)), (7, 1, (3, 7)), (9, 2, (2, 4)), (11, 1, (5, 11)), (6, 2, (1, 3))):
+        v = rng_array((n5,), dtype, n5)
+        expect = oracle.mad(v[lohi[0]:lohi[1]].copy()) / 0.6745
+        assert oracle.noisest(v, None, L5) == expect, (n5, L5)
+        assert W.noisest(W.to_device(v), None, L5) == expect, (n5, L5)
     cases = [dict(TI=True), dict(TI=True, nspin=8), dict(TI=False), dict(wt=None), dict(TI=True, nspin=3),
              dict(wt=W.wavelet(W.WT.cdf97, W.WT.Lifting)), dict(wt=W.wavelet(W.WT.cdf97, W.WT.Lifting), TI=True, nspin=4),
              dict(dnt=W.VisuShrink(W.SoftTH(), 2.5), L=3), dict(wt=W.wavelet(W.WT.db4), dnt=W.VisuShrink(W.SteinTH(), 3.0))]

@@ -169,3 +169,17 @@ def test_closed_form_lift_bitexact(oracle, W, dtype):
                     oracle.lift(w_o, half, is_upd, st.param.shift, c)
                     w_c = cf.lift_step(w.copy(), half, is_upd, st.param.shift, c)
                     assert np.array_equal(w_o, w_c), (sname, half, st, np.abs(w_o - w_c).max())
+
+
+def test_threaded_2d_oracle_is_bit_identical(oracle, W):
+    """oracle.dwt2d_filter_mt (line loops on OpenMP threads, used by the full-size GPU parity test) gives the very bits
+    of the reference-order single-thread loop, forward and inverse, f32 and f64, square and non-square, several depths."""
+    for dtype in (np.float32, np.float64):
+        for shape, Ls in (((256, 256), (1, 3, 8)), ((512, 128), (2, 7)), ((64, 192), (1, 6))):
+            x = rng_array(shape, dtype, sum(shape))
+            for fname in ("db4", "haar", "sym5", "batt2"):
+                q = W.wavelet(getattr(W.WT, fname)).qmf
+                for L in Ls:
+                    y = oracle.dwt_filter(x, q, L)
+                    assert np.array_equal(oracle.dwt2d_filter_mt(x, q, L), y)
+                    assert np.array_equal(oracle.dwt2d_filter_mt(y, q, L, fw=False), oracle.dwt_filter(y, q, L, fw=False))

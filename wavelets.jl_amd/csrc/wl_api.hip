@@ -518,6 +518,9 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     Work<T> w = carve<T>(ctx->ws, n);
     uint8_t *dtree = (uint8_t *)ctx->ws + ws_elems(n) * sizeof(T);
     WL_HIP(ctx, hipMemcpyAsync(dtree, tree, (size_t)ncopy, hipMemcpyHostToDevice, st));
+    // `tree` is the caller's pageable buffer and may be freed as soon as this call returns: the copy must have read it by
+    // then (trees are tiny next to the transform, and wpt is not a throughput path)
+    WL_HIP(ctx, hipStreamSynchronize(st));
 
     const int Lmax = wl_maxtransformlevels(n);
     // depths in processing order, skipping depths where no node is set (pure copy-through)

@@ -521,7 +521,10 @@ __global__ void __launch_bounds__(1024) k_mad_lds(T *v, int n, int do_mad, SelSt
     }
     if (tid == 0) s->result = (double)m;
 }
-constexpr int64_t kMadLdsMax = 8192;
+// keys of n elements in dynamic LDS next to ~1 KiB of static LDS: stay under the 64 KiB a kernel gets without
+// hipFuncSetAttribute (Float64 keys are 8 bytes)
+template <typename T>
+constexpr int64_t mad_lds_max() { return sizeof(T) == 4 ? 8192 : 4096; }
 
 template <typename T>
 int mad_small(wl_ctx *ctx, hipStream_t st, T *v, int64_t n, int do_mad, double *result_host)
@@ -724,7 +727,7 @@ int wl_median(wl_ctx *ctx, int dtype, const void *v, int64_t n, double *result, 
     if (!v || !result) return WL_EINVAL_ARG;
     if (n < 1) return WL_EDIMS;
     hipStream_t st = (hipStream_t)stream;
-    if (n <= kMadLdsMax)        // (the kernel does not write v when do_mad == 0)
+    if (n <= (dtype == WL_F32 ? mad_lds_max<float>() : mad_lds_max<double>()))        // (the kernel does not write v when do_mad == 0)
         return dtype == WL_F32 ? mad_small<float>(ctx, st, (float *)const_cast<void *>(v), n, 0, result)
                                : mad_small<double>(ctx, st, (double *)const_cast<void *>(v), n, 0, result);
     return dtype == WL_F32 ? median_impl<float>(ctx, st, (const float *)v, n, result, (float *)nullptr)
@@ -741,7 +744,7 @@ int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *str
     rc = ensure_aux(ctx);
     if (rc != WL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (n <= kMadLdsMax)
+    if (n <= (dtype == WL_F32 ? mad_lds_max<float>() : mad_lds_max<double>()))
         return dtype == WL_F32 ? mad_small<float>(ctx, st, (float *)y, n, 1, result) : mad_small<double>(ctx, st, (double *)y, n, 1, result);
     void *mdev = (char *)ctx->aux + 4096;          // the first median, in the element type
     const unsigned nb = ext_blocks(n, 4, ctx->cu_count);

@@ -1278,7 +1278,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                     T *lld = lastp ? y : llbuf;
                     const int64_t ldd = lastp ? b.full.s[1] : (n[0] >> nlev);
                     WL_TRY(fwd2d_lds_launch(st, taps, nlev, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, n[0], n[1], cu_count));
-                    if (!dominant) dominant = "k_fwd2d_lds";
+                    if (!dominant) dominant = (nlev == 2) ? "k_fwd2d_lds2" : "k_fwd2d_lds";
                     lstep = nlev;
                     int64_t hn2[3] = {n[0] >> nlev, n[1] >> nlev, n[2]};
                     cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;

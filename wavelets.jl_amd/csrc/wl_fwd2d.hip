@@ -52,7 +52,9 @@ __device__ __forceinline__ void wg_lds_sync(bool multi)
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <int F, int NLEV>
+// LVL1 only gives the launch that consumes the full-size input its own symbol (rocprofv3 --stats then reports the dominant
+// kernel separately from the same code running on the smaller levels).
+template <int F, int NLEV, int LVL1>
 __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
 {
     typedef float T;
@@ -358,15 +360,20 @@ static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, int nlev
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     const int nthreads = 64 * sh.nw;
     const size_t shmem = (size_t)2 * (4 * nthreads + 16) * 8 + (nlev == 2 ? (size_t)2 * (2 * nthreads + 16) * 8 + (size_t)8 * nthreads * 8 : 0);
-    if (nlev == 2) {
-        hipError_t e = set_lds_attr(reinterpret_cast<const void *>(&k_fwd2d_lds<F, 2>), 65536);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_fwd2d_lds<F, 2>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
-    } else {
-        hipError_t e = set_lds_attr(reinterpret_cast<const void *>(&k_fwd2d_lds<F, 1>), 65536);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_fwd2d_lds<F, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
+#define WL_LDS_LAUNCH(NL_, L1_)                                                                                        \
+    do {                                                                                                               \
+        hipError_t e = set_lds_attr(reinterpret_cast<const void *>(&k_fwd2d_lds<F, NL_, L1_>), 65536);                 \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL((k_fwd2d_lds<F, NL_, L1_>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);     \
+    } while (0)
+    if constexpr (F <= 8) {
+        if (nlev == 2) {
+            if (lvl1) WL_LDS_LAUNCH(2, 1); else WL_LDS_LAUNCH(2, 0);
+            return hipGetLastError();
+        }
     }
+    if (lvl1) WL_LDS_LAUNCH(1, 1); else WL_LDS_LAUNCH(1, 0);
+#undef WL_LDS_LAUNCH
     return hipGetLastError();
 }
 

@@ -163,9 +163,9 @@ def noisest(x, wt=_DEFAULT, L: int = 1) -> float:
     x = _prep_in(x)
     y = x if wt is None else dwt(x, wt, L)
     n1 = int(y.shape[0])
-    lo, hi = n1 >> L, n1 >> (L - 1)
+    r = Util.detailrange(n1, L)            # round(Int, n/2^L + 1) : round(Int, n/2^(L-1)), ties to even (non_dyadic.jl:7)
     flat = y.t().reshape(-1) if y.dim() == 2 else (y.permute(2, 1, 0).reshape(-1) if y.dim() == 3 else y)
-    dr = flat[lo:hi].clone()
+    dr = flat[r.start - 1:r.stop - 1].clone()
     return mad_(dr) / 0.6745
 
 

@@ -228,15 +228,35 @@ def _default_L(x, L):
 
 
 # ---- core calls ----------------------------------------------------------------------------------
-def _filter_call(y: torch.Tensor, x: torch.Tensor, filt: OrthoFilter, L: int, fw: bool):
+def _check_one(y: torch.Tensor, vector_only: bool = False):
+    """What every caller-supplied array must satisfy before its data_ptr() reaches the C ABI."""
+    if not isinstance(y, torch.Tensor):
+        raise TypeError("expected a torch tensor resident on the GPU")
+    if y.device.type != "cuda":
+        raise HIPError("wavelets_jl_amd runs on MI355X (gfx950) HIP devices only; there is no CPU path")
+    if y.dtype not in (torch.float32, torch.float64):
+        raise TypeError("element type must be Float32 or Float64")
+    if vector_only and y.dim() != 1:
+        raise TypeError("wpt is defined for vectors only (WPTArray = AbstractVector)")
+    if not is_julia_layout(y):
+        raise ArgumentError("arrays must be dense column-major (Julia layout); see to_device/similar")
+
+
+def _check_pair(y: torch.Tensor, x: torch.Tensor, vector_only: bool = False):
+    """(y, x) handed to an out-of-place entry point: same shape (DimensionMismatch, transforms_filter.jl:25-26), same
+    element type, same device, both dense column-major -- the library trusts the extents it is given."""
+    _check_one(y, vector_only)
+    _check_one(x, vector_only)
     if tuple(x.shape) != tuple(y.shape):
         raise DimensionMismatch("in and out array size must match")
     if x.dtype != y.dtype:
         raise TypeError("x and y must have the same element type")
-    if not (is_julia_layout(y) and is_julia_layout(x)):
-        raise ArgumentError("arrays must be dense column-major (Julia layout); see to_device/similar")
     if x.device != y.device:
         raise HIPError("x and y are on different devices")
+
+
+def _filter_call(y: torch.Tensor, x: torch.Tensor, filt: OrthoFilter, L: int, fw: bool):
+    _check_pair(y, x)
     lib = _lib.load()
     h, st = _context(x.device)
     q = np.ascontiguousarray(filt.qmf, dtype=np.float64)
@@ -247,8 +267,10 @@ def _filter_call(y: torch.Tensor, x: torch.Tensor, filt: OrthoFilter, L: int, fw
 
 
 def _lifting_call(y: torch.Tensor, x: Optional[torch.Tensor], sch: GLS, L: int, fw: bool):
-    if not is_julia_layout(y):
-        raise ArgumentError("array must be dense column-major (Julia layout); see to_device/similar")
+    if x is None:
+        _check_one(y)
+    else:
+        _check_pair(y, x)
     lib = _lib.load()
     h, st = _context(y.device)
     iu, nc, sh, cf = sch.flatten()
@@ -407,8 +429,7 @@ def _tree_arg(n, tree_or_L):
 
 
 def _wpt_filter_call(y, x, filt, tree, fw):
-    if tuple(x.shape) != tuple(y.shape):
-        raise DimensionMismatch("in and out array size must match")
+    _check_pair(y, x, vector_only=True)
     lib = _lib.load()
     h, st = _context(x.device)
     q = np.ascontiguousarray(filt.qmf, dtype=np.float64)
@@ -420,6 +441,7 @@ def _wpt_filter_call(y, x, filt, tree, fw):
 
 
 def _wpt_lifting_call(y, sch, tree, fw):
+    _check_one(y, vector_only=True)
     lib = _lib.load()
     h, st = _context(y.device)
     iu, nc, sh, cf = sch.flatten()

@@ -185,6 +185,7 @@ def test_fused_level_pair_kernel(gpu, W, oracle):
     kernels (odd/even L, non-square blocks, partial strips and chunks, every supported filter length)."""
     W.set_option("WL_FUSE2_MIN", 0)
     W.set_option("WL_LDS2D", 0)          # (the LDS-exchange kernel, tested below, takes these shapes by default)
+    W.set_option("WL_M2D_MAX", 128)      # (... and the tile kernel everything up to 1024 x 1024)
     for shape, Ls in (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (4, 9)), ((528, 96), (2, 4)),
                       ((4096, 64), (2,))):
         x = rng_array(shape, np.float32, sum(shape))
@@ -210,6 +211,7 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
     W.set_option("WL_LDS_MODE", mode)
     W.set_option("WL_FUSE2", pair)
     W.set_option("WL_LDS_PAIR_MIN", 0)
+    W.set_option("WL_M2D_MAX", 128)      # (the tile kernel would otherwise take everything up to 1024 x 1024)
     shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4, 9)), ((528, 96), (1, 2, 4)), ((4096, 64), (1, 2)),
               ((256, 256), (1, 2)), ((1000, 64), (1, 2, 3)), ((272, 64), (1,)), ((768, 1024), (2, 3)), ((1280, 128), (1, 2)))
     for shape, Ls in shapes:

@@ -1198,7 +1198,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
 
         // ---- 2-D multi-level tiles for the cache-resident levels (two levels per launch) ----
         if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 1024) &&
-            n[1] <= env_int("WL_M2D_MAX", 1024) && n[0] >= env_int("WL_M2D_MIN", 64) && n[1] >= env_int("WL_M2D_MIN", 64) && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
+            n[1] <= env_int("WL_M2D_MAX", 1024) && n[0] >= env_int("WL_M2D_MIN", 128) && n[1] >= env_int("WL_M2D_MIN", 128) && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&
             cur_st.s[0] == 1) {
             int NL = (L - l + 1);
             const int nl2max = env_int("WL_M2D_NL", 2);

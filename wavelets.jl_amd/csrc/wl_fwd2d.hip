@@ -54,6 +54,24 @@ __device__ __forceinline__ void wg_lds_sync(bool multi)
 
 // LVL1 only gives the launch that consumes the full-size input its own symbol (rocprofv3 --stats then reports the dominant
 // kernel separately from the same code running on the smaller levels).
+// Column loads and their waits are written by hand.  hipcc's own wait-count insertion, given the rotating 16-slot ring, puts
+// vmcnt(1) / vmcnt(0) in front of two of every eight steps (checked in the ISA: tools/probes/waitcnt_probe.hip has the small
+// reproduction): the wave then waits for the loads it issued a few instructions earlier AND for all of its stores, twice per
+// iteration -- the four-step prefetch distance never exists.  Here the load is opaque to the compiler and the wait names the
+// two ring slots it guards, so every consumer depends on the wait through its data.
+typedef float F4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(F4 &dst, const float *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// "at most N vector-memory operations outstanding": loads and stores retire in issue order on gfx9-family counters, so this
+// covers every load that has at least N younger operations behind it.
+template <int N>
+__device__ __forceinline__ void wait_vm(F4 &a, F4 &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 template <int F, int NLEV, int LVL1>
 __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
 {
@@ -113,9 +131,17 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         for (int c = 0; c < R - 2; ++c) {
             int64_t jc = j0 + c;
             if (jc >= ns) jc -= ns;
-            ring[c] = *reinterpret_cast<const T4 *>(base + jc * a.lds);
+            gload16(ring[c], base + jc * a.lds);
         }
     }
+    // the first steps find all 14 prologue columns complete (one full wait per wave, once)
+#pragma unroll
+    for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
+    // The newest two columns of step t's window (2t+F-2, 2t+F-1) were requested PFD steps earlier.  Younger operations behind
+    // them when step t needs them: 2*PFD loads (two per step, this step's included) plus the stores of the PFD steps in
+    // between -- 4 per step for a wave that owns rows (NLEV = 1), at least 3 per step while level-1 details are being written
+    // (NLEV = 2); none for helper / out-of-range waves.
+    const bool wave_stores = __builtin_amdgcn_ballot_w64(own) != 0;
     T *const yb = a.y + (int64_t)blockIdx.y * a.bs_y;
     const bool to_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
     T *const llb = to_ll ? (a.ll + (int64_t)blockIdx.y * a.bs_ll) : yb;
@@ -130,8 +156,16 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
-                ring[(2 * u + R - 2 + e) % R] = *reinterpret_cast<const T4 *>(base + jc * a.lds);
+                gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
             }
+        }
+        if (prefetch) {
+            constexpr int NL = 2 * PFD, NS = NL + PFD * (NLEV == 1 ? 4 : 3);
+            static_assert(NS < 64, "vmcnt is a 6-bit counter");
+            if (wave_stores && (NLEV == 1 || t <= S_own)) wait_vm<NS>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);
+            else wait_vm<NL>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);
+        } else {
+            wait_vm<0>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);      // (last steps of the chunk: nothing left to overlap)
         }
         // ---- level l, dim-2 pass on row pairs: {A, B}[r] = scaling / detail (column k / kd) of row r ----
         T2 sa01 = a.tp.h[0] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
@@ -149,12 +183,13 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         T2 *const w1 = x1 + (t & 1) * rows1;
         *reinterpret_cast<T4 *>(w1 + 4 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
         *reinterpret_cast<T4 *>(w1 + 4 * lp + 2) = T4{sa23.x, da23.x, sa23.y, da23.y};
-        // ---- level l+1, dim-2 pass: every second step, on the approximation ring.  This step's approximation column
-        //      (k) only exists after the exchange below, so the window is columns k-8 .. k-1 = slots u .. u+7 (slot u is
-        //      overwritten with column k further down) ----
-        const bool lvl2 = (NLEV == 2) && !(u & 1) && (t >= U);
+        // level l+1 runs behind the exchange, spread over two steps: at even steps (lvl2a) its dim-2 pass on the
+        // approximation ring -- this step's column (k) is not there yet, so the window is columns k-8 .. k-1 = slots
+        // u .. u+7 -- publishes {A2, B2} for the next barrier; at odd steps (lvl2b) the dim-1 pass consumes them
+        const bool lvl2a = (NLEV == 2) && !(u & 1) && (t >= U);
+        const bool lvl2b = (NLEV == 2) && (u & 1) && (t >= U + 1);
         T2 *const w2 = x2 + ((t >> 1) & 1) * rows2;
-        if (lvl2) {
+        auto level2_dim2 = [&]() __attribute__((always_inline)) {
             T2 r2[F];
 #pragma unroll
             for (int m = 0; m < F; ++m) r2[m] = x3[((u + m) % U) * nthreads];
@@ -165,13 +200,15 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
                 sa = sa + a.tp.h[m] * r2[m];
                 da = da + a.tp.g[F - 1 - m] * r2[m];
             }
-            *reinterpret_cast<T4 *>(w2 + 2 * lp) = T4{sa.x, da.x, sa.y, da.y};
-        }
+            return T4{sa.x, da.x, sa.y, da.y};
+        };
         wg_lds_sync(multi);
         __builtin_amdgcn_sched_barrier(0);
         if (helper) {
             // the helper wave owns no output; for level 2 its first lanes keep the approximation rows above the strip alive
             if (NLEV == 2) {
+                T4 ab2 = T4{0.f, 0.f, 0.f, 0.f};
+                if (lvl2a) ab2 = level2_dim2();            // (reads slot u before it is overwritten below)
                 T2 Eh[10];
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
@@ -183,6 +220,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
 #pragma unroll
                 for (int m = 1; m < F; ++m) { s0 = s0 + a.tp.h[m] * Eh[m]; s1 = s1 + a.tp.h[m] * Eh[2 + m]; }
                 x3[u * nthreads] = T2{s0.x, s1.x};
+                if (lvl2a) *reinterpret_cast<T4 *>(w2 + 2 * lp) = ab2;
             }
             return;
         }
@@ -210,6 +248,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         int64_t kd = k + SH;
         if (kd >= nxj) kd -= nxj;
         if (NLEV == 2) {
+            if (lvl2a) *reinterpret_cast<T4 *>(w2 + 2 * lp) = level2_dim2();   // (reads slot u before it is overwritten)
             x3[u * nthreads] = T2{P[0].x, P[1].x};     // approximation column kbase + t
             if (t < S_own) {
                 // even lane: ds rows kod..kod+3 of column k;  odd lane: sd rows ko-2..ko+1 and dd rows kod-2..kod+1 of column kd
@@ -249,7 +288,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
             }
         }
         // ---- level l+1, dim-1 pass: window = approximation rows 2L' .. 2L'+9 ----
-        if (lvl2) {
+        if (lvl2b) {
             __builtin_amdgcn_sched_barrier(0);         // (keeps the level-2 window out of the level-1 live range: register pressure)
             T2 E2[10];
 #pragma unroll
@@ -265,7 +304,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
 #pragma unroll
             for (int m = F - 2; m >= 0; --m) Q2 = Q2 + a.tp.g[m] * E2[9 - m];
             {
-                const int64_t k2 = kbase2 + ((t - U) >> 1);
+                const int64_t k2 = kbase2 + ((t - U - 1) >> 1);
                 int64_t kd2 = k2 + SH;
                 if (kd2 >= nxj2) kd2 -= nxj2;
                 const T rP = from_partner(odd ? P2.x : P2.y);

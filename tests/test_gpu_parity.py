@@ -446,6 +446,44 @@ def test_lifting_lines_fast_paths(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.idwtc(dev(W, ye), sch, L)), oracle.dwtc_lifting(ye, sch, L, fw=False))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_register_tail(gpu, W, oracle, dtype):
+    """k_tail_lift_reg (every remaining forward lifting level of a power-of-two line in one wave's registers, rotating
+    DPP neighbours, ds_bpermute below 64 pairs): every line length from 2 up to the hand-over size, every depth class,
+    the three known scheme shapes, in place, batched, as the end of a long transform -- bit for bit against the oracle and
+    against the LDS tail it replaces."""
+    nmax = 4096 if dtype == np.float32 else 2048
+    n = 2
+    while n <= nmax:
+        x = rng_array((n,), dtype, n)
+        Lmax = W.maxtransformlevels(n)
+        for sname in ("cdf97", "db2", "haar"):
+            sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+            for L in sorted({1, 2, Lmax // 2, Lmax - 1, Lmax} - {0}):
+                if L > Lmax:
+                    continue
+                ye = oracle.dwt_lifting(x, sch, L)
+                y = host(W, W.dwt(dev(W, x), sch, L))
+                assert W.last_kernel() == "k_tail_lift_reg", (n, sname, L, W.last_kernel())
+                assert np.array_equal(y, ye), (n, sname, L)
+                t = dev(W, x)
+                W.dwt_(t, sch, L)
+                assert np.array_equal(host(W, t), ye), (n, sname, L, "in place")
+        n *= 2
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    for shape, L in (((1024, 40), 10), ((4096 if dtype == np.float32 else 2048, 5), 7), ((64, 33), 6), ((1 << 15, 24), 15)):
+        xb = rng_array(shape, dtype, shape[1])
+        assert np.array_equal(host(W, W.dwtc(dev(W, xb), sch, L)), oracle.dwtc_lifting(xb, sch, L)), shape
+    x = rng_array((1 << 20,), dtype, 3)
+    ye = oracle.dwt_lifting(x, sch, 20)
+    assert np.array_equal(host(W, W.dwt(dev(W, x), sch, 20)), ye)
+    W.set_option("WL_LIFT_REGTAIL", 0)
+    assert np.array_equal(host(W, W.dwt(dev(W, x), sch, 20)), ye)
+    xs = rng_array((2048,), dtype, 9)
+    y0 = host(W, W.dwt(dev(W, xs), sch, 11))
+    assert W.last_kernel() == "k_tail_lift" and np.array_equal(y0, oracle.dwt_lifting(xs, sch, 11))
+
+
 def test_lifting_equals_filter_on_gpu(gpu, W):
     """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
     for nd in (1, 2, 3):

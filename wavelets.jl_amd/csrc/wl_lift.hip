@@ -530,6 +530,193 @@ __global__ void __launch_bounds__(1024) k_tail_lift(LiftTailArgs<T> a, LiftSchem
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// Register-resident forward tail: ALL remaining levels of a power-of-two line of <= 4096 (Float32) / 2048 (Float64)
+// samples in ONE WAVE, known scheme shapes.  The LDS tail below pays a barrier per pass -- split, every lifting step,
+// normalize: six per cdf9/7 level, 66 for the last eleven levels of a long line, ~0.5 us each.  Here the wave holds the whole
+// line: lane L owns pairs PPL*L .. PPL*L + PPL-1, the steps run in registers exactly as in the streaming kernels, the
+// out-of-lane operands come from the neighbouring lane by a ROTATING DPP shift (lane 63's neighbour is lane 0: the periodic
+// boundary of the reference, transforms_lifting.jl:437-451), and the next level's pairs (s[2i], s[2i+1]) are already in the
+// same lane.  Once a lane is down to one pair (64 pairs left) the line is finished with one sample per lane and
+// ds_bpermute gathers (six levels, 32 .. 1 pairs).  No LDS storage, no barrier.
+__device__ __forceinline__ int l_dpp_rol(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }   // lane i <- lane i+1 (mod 64)
+__device__ __forceinline__ int l_dpp_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false); }   // lane i <- lane i-1 (mod 64)
+__device__ __forceinline__ float l_rol(float v) { return __int_as_float(l_dpp_rol(__float_as_int(v))); }
+__device__ __forceinline__ float l_ror(float v) { return __int_as_float(l_dpp_ror(__float_as_int(v))); }
+__device__ __forceinline__ double l_rol(double v) { return __hiloint2double(l_dpp_rol(__double2hiint(v)), l_dpp_rol(__double2loint(v))); }
+__device__ __forceinline__ double l_ror(double v) { return __hiloint2double(l_dpp_ror(__double2hiint(v)), l_dpp_ror(__double2loint(v))); }
+__device__ __forceinline__ float l_gather(float v, int srclane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(srclane << 2, __float_as_int(v))); }
+__device__ __forceinline__ double l_gather(double v, int srclane)
+{
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(srclane << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(srclane << 2, __double2loint(v)));
+}
+
+template <typename T, int PPL>
+__device__ __forceinline__ T lane_operand_rot(const T (&op)[PPL], int off)
+{
+    const int delta = l_floordiv(off, PPL);
+    const int e = off - delta * PPL;
+    T v = op[e];
+    if (delta == 1) v = l_rol(v);
+    else if (delta == 2) v = l_rol(l_rol(v));
+    else if (delta == -1) v = l_ror(v);
+    else if (delta == -2) v = l_ror(l_ror(v));
+    return v;
+}
+
+// all steps of one level on the whole line held by the wave (pairs PPL*lane + jj); same arithmetic as lift_steps_lane
+template <typename T, int ID, int PPL>
+__device__ __forceinline__ void lift_steps_wave(T (&s)[PPL], T (&d)[PPL], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF], int lane)
+{
+    typedef Shape<ID> SH;
+    const int kfirst = PPL * lane, half = 64 * PPL;
+#pragma unroll
+    for (int st = 0; st < SH::NS; ++st) {
+        const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+        T res[PPL];
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) {
+            T o[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                o[kk] = (T)0;
+                if (kk < nc) o[kk] = upd ? lane_operand_rot<T, PPL>(s, jj + kk - sh) : lane_operand_rot<T, PPL>(d, jj + kk - sh);
+            }
+            const int jg = kfirst + jj - sh;
+            const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+            const T x = upd ? d[jj] : s[jj];
+            T acc = c[st][0] * o[0];
+            if (nc > 1) acc = acc + c[st][1] * o[1];
+            if (nc > 2) acc = acc + c[st][2] * o[2];
+            const T xin = x + acc;
+            T xb = x + c[st][0] * o[0];
+            if (nc > 1) xb = xb + c[st][1] * o[1];
+            if (nc > 2) xb = xb + c[st][2] * o[2];
+            res[jj] = inb ? xin : xb;
+        }
+#pragma unroll
+        for (int jj = 0; jj < PPL; ++jj) { if (upd) d[jj] = res[jj]; else s[jj] = res[jj]; }
+    }
+}
+
+template <typename T>
+struct LiftRegArgs {
+    const T *src; int64_t src_item;
+    T *y; int64_t y_item;
+    int n0, nlev;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+// one sample per lane: levels of <= 32 pairs
+template <typename T, int ID>
+__device__ __forceinline__ void lift_reg_small(T v, int m, int nlev, const LiftRegArgs<T> &a, T *y, int lane)
+{
+    typedef Shape<ID> SH;
+    for (int lev = 0; lev < nlev; ++lev) {
+        const int half = m >> 1;
+        T s = l_gather(v, (2 * lane) & 63), d = l_gather(v, (2 * lane + 1) & 63);       // Util.split!
+#pragma unroll
+        for (int st = 0; st < SH::NS; ++st) {
+            const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+            const T opv = upd ? s : d;
+            T o[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                o[kk] = (T)0;
+                if (kk < nc) o[kk] = l_gather(opv, (lane + kk - sh) & (half - 1));
+            }
+            const int jg = lane - sh;
+            const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+            const T x = upd ? d : s;
+            T acc = a.c[st][0] * o[0];
+            if (nc > 1) acc = acc + a.c[st][1] * o[1];
+            if (nc > 2) acc = acc + a.c[st][2] * o[2];
+            const T xin = x + acc;
+            T xb = x + a.c[st][0] * o[0];
+            if (nc > 1) xb = xb + a.c[st][1] * o[1];
+            if (nc > 2) xb = xb + a.c[st][2] * o[2];
+            const T r = inb ? xin : xb;
+            if (upd) d = r; else s = r;
+        }
+        if (lane < half) y[half + lane] = d * a.norm2;
+        v = s * a.norm1;
+        if (lev == nlev - 1) { if (lane < half) y[lane] = v; }
+        m = half;
+    }
+}
+
+template <typename T, int ID, int PPL>
+__device__ __forceinline__ void lift_reg_levels(T (&s)[PPL], T (&d)[PPL], int nlev, const LiftRegArgs<T> &a, T *y, int lane)
+{
+    lift_steps_wave<T, ID, PPL>(s, d, a.c, lane);
+    constexpr int half = 64 * PPL;
+    T dO[PPL], sO[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { dO[j] = d[j] * a.norm2; sO[j] = s[j] * a.norm1; }
+    stv_l<T, PPL>(y + half + PPL * lane, dO);
+    if (nlev == 1) { stv_l<T, PPL>(y + PPL * lane, sO); return; }
+    if constexpr (PPL > 1) {
+        T s2[PPL / 2], d2[PPL / 2];
+#pragma unroll
+        for (int j = 0; j < PPL / 2; ++j) { s2[j] = sO[2 * j]; d2[j] = sO[2 * j + 1]; }
+        lift_reg_levels<T, ID, PPL / 2>(s2, d2, nlev - 1, a, y, lane);
+    } else {
+        lift_reg_small<T, ID>(sO[0], 64, nlev - 1, a, y, lane);
+    }
+}
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(64) k_tail_lift_reg(LiftRegArgs<T> a)
+{
+    const int lane = threadIdx.x;
+    const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
+    T *y = a.y + (int64_t)blockIdx.x * a.y_item;
+    const int n = a.n0;
+    if (n <= 64) {
+        const T v = (lane < n) ? src[lane] : (T)0;
+        lift_reg_small<T, ID>(v, n, a.nlev, a, y, lane);
+        return;
+    }
+#define WL_REG_CASE(PPL_)                                                              \
+    case PPL_: {                                                                       \
+        T v[2 * PPL_], s[PPL_], d[PPL_];                                               \
+        ldv_l<T, 2 * PPL_>(src + 2 * PPL_ * lane, v);                                  \
+        _Pragma("unroll") for (int j = 0; j < PPL_; ++j) { s[j] = v[2 * j]; d[j] = v[2 * j + 1]; } \
+        lift_reg_levels<T, ID, PPL_>(s, d, a.nlev, a, y, lane);                        \
+    } break
+    switch (n >> 7) {
+        WL_REG_CASE(1);
+        WL_REG_CASE(2);
+        WL_REG_CASE(4);
+        WL_REG_CASE(8);
+        WL_REG_CASE(16);
+    default:
+        if constexpr (sizeof(T) == 4) {
+            T v[64], s[32], d[32];
+            ldv_l<T, 64>(src + 64 * lane, v);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { s[j] = v[2 * j]; d[j] = v[2 * j + 1]; }
+            lift_reg_levels<T, ID, 32>(s, d, a.nlev, a, y, lane);
+        }
+        break;
+    }
+#undef WL_REG_CASE
+}
+
+template <typename T>
+static bool lift_reg_ok(int id, int64_t n, int nlev, const T *src, int64_t src_item, const T *y, int64_t y_item)
+{
+    if (id != 0 && id != 2 && id != 4) return false;                       // forward shapes
+    if (n < 2 || (n & (n - 1)) != 0 || n > (sizeof(T) == 4 ? 4096 : 2048)) return false;
+    if (nlev < 1 || ((int64_t)1 << nlev) > n) return false;
+    constexpr int VEC = 16 / sizeof(T);
+    // the wide loads / stores of the first level want 16-byte aligned lines (lines of < 2*VEC... samples use scalar accesses)
+    if (n > 64 && ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (src_item % VEC) || (y_item % VEC))) return false;
+    return true;
+}
+
 // --------------------------------------------------------------------------------------------------
 // LDS tail for SQUARE 2-D blocks (n0 <= 64): every remaining level of the 2-D lifting transform inside one workgroup
 // (any scheme).  Forward: per level rows (dim 2) then columns (dim 1), each as split -> steps -> normalize on all
@@ -828,7 +1015,10 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     if (nlines > 1 && (ld % VEC) != 0) return WL_OK;
     // the LDS tail can hold up to lift_tail_cap samples; a single line (or a few) hands over later, at 2048
     // samples, because one workgroup is slow on a long line while the streaming kernels use the whole chip
-    const int cap = (nlines >= 32) ? lift_tail_cap<T>() : 2048;
+    int cap = (nlines >= 32) ? lift_tail_cap<T>() : 2048;
+    // known forward shapes on power-of-two lines: the single-wave register tail takes over at 4096 / 2048 samples
+    const bool reg_tail = fw && l_env("WL_LIFT_REGTAIL", 1) && (id == 0 || id == 2 || id == 4) && (n & (n - 1)) == 0;
+    if (reg_tail) cap = (sizeof(T) == 4) ? 4096 : 2048;
     // every level must be either stream-able (known shape, n_l >= 512, n_l % 8 == 0) or inside the tail
     int l_tail = L + 1;                       // first level (1-based) handled by the tail (fw) ...
     for (int l = 1; l <= L; ++l) {
@@ -906,7 +1096,19 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             if (!dom) dom = "k_lift1d_stream";
             cur = llbuf; cur_ls = hl; pp ^= 1;
         }
-        if (l_tail <= L) {
+        if (l_tail <= L && reg_tail &&
+            lift_reg_ok<T>(id, n >> (l_tail - 1), L - l_tail + 1, cur, cur_ls, y, ld)) {
+            LiftRegArgs<T> r;
+            r.src = cur; r.src_item = cur_ls; r.y = y; r.y_item = ld; r.n0 = (int)(n >> (l_tail - 1)); r.nlev = L - l_tail + 1;
+            for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                for (int k = 0; k < WL_MAX_NCOEF; ++k) r.c[i][k] = a.c[i][k];
+            r.norm1 = a.norm1; r.norm2 = a.norm2;
+            if (id == 0) hipLaunchKernelGGL((k_tail_lift_reg<T, 0>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            else if (id == 2) hipLaunchKernelGGL((k_tail_lift_reg<T, 2>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            else hipLaunchKernelGGL((k_tail_lift_reg<T, 4>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            WL_CHECK_LAUNCH();
+            if (!dom) dom = "k_tail_lift_reg";
+        } else if (l_tail <= L) {
             LiftTailArgs<T> t;
             const int64_t nl = n >> (l_tail - 1);
             t.src = cur; t.src_item = cur_ls; t.y = y; t.y_item = ld; t.ll = nullptr; t.ll_item = 0;

@@ -89,10 +89,16 @@ typedef struct wl_ctx wl_ctx;
  * vectors per call, transforms_filter.jl:16-23,117-119)                                */
 WL_API int wl_ctx_create(int device, wl_ctx **out);
 WL_API int wl_ctx_destroy(wl_ctx *ctx);
-/* Upper bound of the device workspace a transform of this shape needs; wl_ctx_reserve
- * grows the context's workspace once so that later calls never allocate.              */
+/* Device workspace of the fast filter-bank paths for dwt / idwt of this shape: the
+ * approximation ping-pong, 2 * (N / 2^ndims) elements (N = number of samples; for dwtc pass
+ * ndims = 1 and dims[0] = len * nsignals).  wl_ctx_reserve grows the context's workspace
+ * once so that later calls of that kind never allocate.  Lifting transforms, long (> 10 taps
+ * in 2-D) / odd-length filters, 3-D boxes and the generic kernel family use up to 4 N more
+ * elements: the context grows to that on their first call (grow-only; a call that grows the
+ * workspace synchronises the device).  wl_ctx_workspace_held reports the current size.    */
 WL_API size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L);
 WL_API int wl_ctx_reserve(wl_ctx *ctx, size_t bytes);
+WL_API size_t wl_ctx_workspace_held(const wl_ctx *ctx);
 /* hipStreamSynchronize for hosts without their own HIP binding.                        */
 WL_API int wl_stream_sync(wl_ctx *ctx, void *stream);
 WL_API const char *wl_strerror(int status);

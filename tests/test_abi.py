@@ -34,7 +34,9 @@ def test_hostonly_entry_points(W):
     for n, e in ((1, 0), (2, 1), (40, 3), (1 << 24, 24), (8192, 13), (7, 0)):
         assert lib.wl_maxtransformlevels(n) == e
     dims = (C.c_int64 * 3)(8192, 8192, 1)
-    assert lib.wl_workspace_bytes(0, 2, dims, 13) >= 4 * 8192 * 8192 * 4
+    # the fast filter-bank path of C3 holds two approximation buffers of N/4 elements: 128 MiB (+ padding), not 4 N
+    wsb = lib.wl_workspace_bytes(0, 2, dims, 13)
+    assert 2 * (8192 * 8192 // 4) * 4 <= wsb <= 129 * 2 ** 20
 
 
 def test_header_compiles_as_c():

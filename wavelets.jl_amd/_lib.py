@@ -42,6 +42,7 @@ SIGNATURES = {
     "wl_ctx_destroy": (C.c_int, [_vp]),
     "wl_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, _i64p, C.c_int]),
     "wl_ctx_reserve": (C.c_int, [_vp, C.c_size_t]),
+    "wl_ctx_workspace_held": (C.c_size_t, [_vp]),
     "wl_stream_sync": (C.c_int, [_vp, _vp]),
     "wl_last_hip_error": (C.c_int, [_vp]),
     "wl_ctx_set_path": (C.c_int, [_vp, C.c_int]),

@@ -186,15 +186,25 @@ int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T
         ctx->last_kernel = "copy";
         return WL_OK;
     }
-    int rc = ensure_ws(ctx, ws_elems(N) * sizeof(T));
+    // The fast paths need the approximation ping-pong only (2 * (N >> nt) elements); the generic / long-filter / 3-D families
+    // also want three N-element buffers.  Start with whichever the context already holds (at least the ping-pong); a level
+    // that finds the big buffers missing reports WL_RETRY_GEN, the workspace grows once, and the call is repeated -- x is
+    // never modified by a filter transform, so repeating is harmless.
+    const size_t ab_bytes = ws_ab_elems(N, b.nt) * sizeof(T), full_bytes = ws_elems(N, b.nt) * sizeof(T);
+    const bool want_gen = (ctx->path != 0) || (b.nd == 3) || (flen % 2 != 0) || (flen > 10 && b.nt > 1);
+    int rc = ensure_ws(ctx, want_gen ? full_bytes : ab_bytes);
     if (rc) return rc;
     Taps<T> taps;
     make_taps<T>(qmf, flen, taps);
-    if (fw)
-        return filter_fwd_levels<T>(ctx->ws, ctx->cu_count, ctx->path, st, b, y, x, taps, L,
-                                    &ctx->last_kernel, &ctx->last_hip);
-    return filter_inv_levels<T>(ctx->ws, ctx->cu_count, ctx->path, st, b, y, x, taps, L,
-                                &ctx->last_kernel, &ctx->last_hip);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool have_gen = ctx->ws_bytes >= full_bytes;
+        rc = fw ? filter_fwd_levels<T>(ctx->ws, have_gen, ctx->cu_count, ctx->path, st, b, y, x, taps, L, &ctx->last_kernel, &ctx->last_hip)
+                : filter_inv_levels<T>(ctx->ws, have_gen, ctx->cu_count, ctx->path, st, b, y, x, taps, L, &ctx->last_kernel, &ctx->last_hip);
+        if (rc != WL_RETRY_GEN) return rc;
+        rc = ensure_ws(ctx, full_bytes);
+        if (rc) return rc;
+    }
+    return WL_EINVAL_ARG;
 }
 
 template <typename T>
@@ -314,8 +324,12 @@ size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L)
     if (!dims || ndims < 1 || ndims > 3) return 0;
     int64_t N = 1;
     for (int d = 0; d < ndims; ++d) N *= dims[d];
-    return ws_elems(N) * (dtype == WL_F64 ? 8 : 4);
+    // what the fast filter-bank paths of dwt / idwt on this box use: the approximation ping-pong, 2 * (N / 2^ndims) elements.
+    // (dwtc: pass ndims = 1 with dims[0] = len * nsignals.)  Lifting, long / odd filters, 3-D boxes and the generic
+    // family use up to 4 N elements more; the context grows to that on their first call.
+    return ws_ab_elems(N, ndims) * (dtype == WL_F64 ? 8 : 4);
 }
+size_t wl_ctx_workspace_held(const wl_ctx *ctx) { return ctx ? ctx->ws_bytes : 0; }
 
 int wl_ctx_reserve(wl_ctx *ctx, size_t bytes)
 {

@@ -10,13 +10,13 @@ namespace wl {
 // per level (streaming kernels for large levels, one LDS-resident kernel for the tail,
 // generic otherwise), 1 = generic kernels only.  *kernel_name = dominant kernel used.
 template <typename T>
-int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
                       T *y, const T *x, const Taps<T> &taps, int L,
                       const char **kernel_name, int *hip_err);
 
 // Inverse filter-bank transform: all L levels (streaming kernels for large levels, generic otherwise).
 template <typename T>
-int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
                       T *y, const T *x, const Taps<T> &taps, int L,
                       const char **kernel_name, int *hip_err);
 

@@ -1162,7 +1162,7 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
-int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
                       T *y, const T *x, const Taps<T> &taps, int L, const char **kernel_name, int *hip_err)
 {
 #define WL_TRY(expr)                                                  \
@@ -1171,7 +1171,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } \
     } while (0)
     const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
-    Work<T> w = carve<T>(ws, N);
+    Work<T> w = carve<T>(ws, N, b.nt, ws_gen);
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     const bool fastF = (path == 0) && (F % 2 == 0) && (F <= 10);
@@ -1340,6 +1340,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             } else if (two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 32) == 0 && (ldy % VEC) == 0 &&
                        (cur_st.s[1] % VEC) == 0 && aligned16(cur) && aligned16(y) && aligned16(llbuf)) {
                 // rows (dim 2) into T0 = [s-columns | d-columns], then the columns of T0 as lines with the LL quadrant routed on
+                if (!w.T0) return WL_RETRY_GEN;
                 done = long_axis_level<T>(st, taps, 1, cur, cur_st.s[1], w.T0, n[0], n[0], n[1], cu_count, &e);
                 WL_TRY(e);
                 if (done) {
@@ -1358,6 +1359,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
         if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {
             hipError_t e3 = hipSuccess;
+            if (!w.T0) return WL_RETRY_GEN;
             done = fast3d_fwd_level<T>(st, taps, cur, cur_st.s[1], cur_st.s[2], y, b.full.s[1], b.full.s[2],
                                        last ? (T *)nullptr : llbuf, n, w.T0, w.T1, cu_count, &e3);
             WL_TRY(e3);
@@ -1365,6 +1367,7 @@ int filter_fwd_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         }
         // ---- generic level (any rank / size / filter) ----
         if (!done) {
+            if (b.nt > 1 && !w.T0) return WL_RETRY_GEN;
             const T *in = cur;
             Strides3 in_st = cur_st;
             int tog = 0;
@@ -1432,9 +1435,9 @@ template bool fwd2d_planes<float>(hipStream_t, const Taps<float> &, const float 
 template bool fwd2d_planes<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, double *, int64_t,
                                    int64_t, int64_t, int, int, hipError_t *);
 
-template int filter_fwd_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
+template int filter_fwd_levels<float>(void *, bool, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);
-template int filter_fwd_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,
+template int filter_fwd_levels<double>(void *, bool, int, int, hipStream_t, const BoxSpec &, double *, const double *,
                                        const Taps<double> &, int, const char **, int *);
 
 }  // namespace wl

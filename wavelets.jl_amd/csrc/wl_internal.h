@@ -100,23 +100,29 @@ hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, 
 template <typename T>
 hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, Strides3 dst_st, Extent3 n);
 
-// ---- workspace carve-up shared by the level loops (elements of T; N = box elements) ----
-//   T0, T1 : N each   inter-pass buffers (T1 only for 3-D)
-//   W      : N        lifting work buffer
-//   A, B   : N/2 each approximation ping-pong (level l writes the one level l+1 reads)
-inline size_t ws_elems(int64_t N) { return (size_t)(4 * N + 64); }
+// ---- workspace carve-up shared by the level loops (elements of T; N = box elements, nt = transformed axes) ----
+//   A, B   : (N >> nt) + 64 each   approximation ping-pong (level l writes the one level l+1 reads; the largest tenant is
+//                                  the level-1 approximation, or the level-2 reconstruction of an inverse)
+//   T0, T1 : N each                inter-pass buffers of the generic / long-filter / 3-D families (T1 only for 3-D)
+//   W      : N                     lifting work buffer
+// The fast filter-bank paths only ever touch A and B: their calls reserve ws_ab_elems(); a level that needs T0 / T1 / W
+// without having them returns WL_RETRY_GEN (internal) and the ABI layer repeats the call with the full workspace
+// (out-of-place filter transforms only, so repeating is harmless).
+constexpr int WL_RETRY_GEN = -1000;
+inline size_t ws_ab_each(int64_t N, int nt) { return (size_t)((N >> nt) + 64); }
+inline size_t ws_ab_elems(int64_t N, int nt) { return 2 * ws_ab_each(N, nt); }
+inline size_t ws_elems(int64_t N, int nt = 1) { return ws_ab_elems(N, nt) + (size_t)(3 * N + 64); }
 template <typename T>
 struct Work { T *T0, *T1, *W, *A, *B; };
 template <typename T>
-inline Work<T> carve(void *ws, int64_t N)
+inline Work<T> carve(void *ws, int64_t N, int nt = 1, bool with_gen = true)
 {
     Work<T> w;
     T *p = (T *)ws;
-    w.T0 = p; p += N;
-    w.T1 = p; p += N;
-    w.W = p; p += N;
-    w.A = p; p += N / 2 + 8;
-    w.B = p;
+    w.A = p; p += ws_ab_each(N, nt);
+    w.B = p; p += ws_ab_each(N, nt);
+    if (with_gen) { w.T0 = p; p += N; w.T1 = p; p += N; w.W = p; }
+    else { w.T0 = nullptr; w.T1 = nullptr; w.W = nullptr; }
     return w;
 }
 inline Strides3 dense_strides(const int64_t n[3])

@@ -779,7 +779,7 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
     }
 
 template <typename T>
-int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const BoxSpec &b,
+int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
                       T *y, const T *x, const Taps<T> &taps, int L, const char **kernel_name, int *hip_err)
 {
 #define WL_TRYI(expr)                                                  \
@@ -788,7 +788,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } \
     } while (0)
     const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
-    Work<T> w = carve<T>(ws, N);
+    Work<T> w = carve<T>(ws, N, b.nt, ws_gen);
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     const bool fastF = (path == 0) && (F % 2 == 0) && (F <= 10) && i_env("WL_NO_INVFAST", 0) == 0;
@@ -896,6 +896,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
             b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) && i_al16(y)) {
             // dim-1 pass: every column is a line of length n0: s = rows [0,h0), d = rows [h0,n0)
             const int64_t h0 = n[0] >> 1, h1 = n[1] >> 1;
+            if (!w.T0) return WL_RETRY_GEN;
             T *tmp = w.T0;                         // n0 x n1 dense
             bool ok = true;
             if (llsrc) {
@@ -928,6 +929,7 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
                 // columns (dim 1) into T0, the approximation quadrant from the deeper reconstruction; then rows (dim 2)
                 const T *ss = llsrc ? llsrc : x;
                 const int64_t sls = llsrc ? llsrc_st.s[1] : ldx;
+                if (!w.T0) return WL_RETRY_GEN;
                 done = long_lines_inv_level<T>(st, taps, ss, sls, x + h0, ldx, w.T0, n[0], n[0], h1, cu_count, &e);
                 WL_TRYI(e);
                 if (done) {
@@ -943,12 +945,14 @@ int filter_inv_levels(void *ws, int cu_count, int path, hipStream_t st, const Bo
         }
         if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
             hipError_t e3 = hipSuccess;
+            if (!w.T0) return WL_RETRY_GEN;
             done = fast3d_inv_level<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, res_st.s[1], res_st.s[2], n,
                                        w.T0, w.T1, cu_count, &e3);
             WL_TRYI(e3);
             if (done) dominant = "k_inv_axis_stream";
         }
         if (!done) {
+            if (b.nt > 1 && !w.T0) return WL_RETRY_GEN;
             const T *in = x;
             Strides3 in_st = b.full;
             int tog = 0;
@@ -1014,9 +1018,9 @@ template bool inv2d_planes<float>(hipStream_t, const Taps<float> &, const float 
 template bool inv2d_planes<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *, int64_t,
                                    int64_t, int64_t, int, int, hipError_t *);
 
-template int filter_inv_levels<float>(void *, int, int, hipStream_t, const BoxSpec &, float *, const float *,
+template int filter_inv_levels<float>(void *, bool, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);
-template int filter_inv_levels<double>(void *, int, int, hipStream_t, const BoxSpec &, double *, const double *,
+template int filter_inv_levels<double>(void *, bool, int, int, hipStream_t, const BoxSpec &, double *, const double *,
                                        const Taps<double> &, int, const char **, int *);
 
 }  // namespace wl

@@ -136,6 +136,13 @@ def last_kernel(device=None) -> str:
     return _lib.load().wl_last_kernel(h).decode()
 
 
+def workspace_held(device=None) -> int:
+    """bytes of device workspace currently held by the context of the current stream (grow-only)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    h, _ = _context(dev)
+    return int(_lib.load().wl_ctx_workspace_held(h))
+
+
 def reserve_workspace(x: torch.Tensor, L: int = 0):
     """Pre-grow the context's device workspace for transforms of x's shape (so that timed
     regions never allocate)."""

@@ -359,6 +359,11 @@ def secondary_leg(W, device):
     extra.append(("3-D dwt db4 filter 512^3 f32", 9, x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4))
     xm = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
     extra.append(("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, xm, lambda: W.modwt(xm, db4, 8), (1 + 9) * xm.numel() * 4))
+    # translation-invariant denoise (denoising.jl:36-67), default wavelet sym5, 8 x 8 spins as one device-resident batch:
+    # 64 forward + 64 inverse transforms of the image per call; algorithmic bytes = (read + write) per spin and direction
+    xd = torch.randn(2048, 2048, generator=g, dtype=torch.float32).to(device).t()
+    extra.append(("2-D denoise TI 8x8 spins sym5 2048x2048 f32 (64 dwt + 64 idwt, fused batch)", 6, xd,
+                  lambda: W.denoise(xd, TI=True), 64 * 2 * 2 * xd.numel() * 4))
     for label, L, x, fn, alg in extra:
         for _ in range(3):
             fn()
@@ -374,7 +379,8 @@ def secondary_leg(W, device):
         res.append({"workload": label, "L": int(L), "dtype": "f32", "ms_per_step": round(ms, 5),
                     "Msamples_per_s": round(x.numel() / ms / 1e3, 1), "algorithmic_GBps": round(alg / ms / 1e6, 1),
                     "kernel": W.last_kernel()})
-    del extra, x2, y2, x3, y3, xm
+    del extra, x2, y2, x3, y3, xm, xd
+    W.destroy_contexts()
     torch.cuda.empty_cache()
     return res
 

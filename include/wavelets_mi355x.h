@@ -216,6 +216,17 @@ WL_API int wl_arrayadd(wl_ctx *ctx, int dtype, void *y, const void *z, int64_t n
 /* y[i] = T(y[i] * s) with s::Float64 -- rmul!(y, 1/pns), denoising.jl:66.                  */
 WL_API int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *stream);
 
+/* denoise(x, wt::OrthoFilter; L, dnt, TI = true, nspin) fused on the device (denoising.jl:21-67), 1-D vectors and square
+ * matrices: all prod(nspin) circularly shifted copies are transformed, thresholded and transformed back as ONE batch
+ * (in groups when the buffers would exceed the context's cap), then un-shifted and summed in spin order -- the summation
+ * order of the reference, so the result carries the same roundings -- and scaled by 1/prod(nspin).  The noise estimate
+ * sigma = noisest(x, wt) = mad!(level-1 detail range) / 0.6745 is computed on the device and consumed there (no host
+ * round trip) unless sigma_host >= 0 supplies it (a custom estnoise).  th: wl_thtype, t_unit: dnt.t (threshold =
+ * sigma * t_unit in Float64).  y must not alias x.  Nothing is allocated per spin; the call only enqueues.            */
+WL_API int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                         const double *qmf, int flen, int L, int th, double t_unit, const int64_t *nspin,
+                         double sigma_host, void *stream);
+
 /* ---- introspection (tests / bench) ---------------------------------------------------- */
 /* Select the kernel family: 0 = auto (fast paths where they apply), 1 = generic kernels
  * only.  Both produce bit-identical results; the switch exists so tests can prove it.   */

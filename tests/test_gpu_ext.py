@@ -149,3 +149,20 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
     assert np.array_equal(y, _oracle_denoise(oracle, W, a, wt, 5, W.VisuShrink(32), True, (2, 3)))
     with pytest.raises(W.ArgumentError, match="square/cube"):
         W.denoise(W.to_device(rng_array((32, 16), dtype, 1)))
+    # the fused device-resident batch (wl_denoise_ti_filter): sizes that reach the plane-batched fast kernels, spins
+    # processed in several groups (small buffer cap), a custom noise estimate handed over as a host scalar
+    b = (doppler(512)[:, None] * doppler(512)[None, :] + 0.05 * np.random.default_rng(3).standard_normal((512, 512))).astype(dtype)
+    bd = W.to_device(b)
+    e = _oracle_denoise(oracle, W, b, wt, 6, W.VisuShrink(512), True, (4, 3))
+    y = host(W, W.denoise(bd, TI=True, nspin=(4, 3)))
+    assert W.last_kernel() == "denoise_ti_batch" and np.array_equal(y, e)
+    W.set_option("WL_TI_WS_CAP_MB", 8)                           # 12 spins of 1 MiB: groups of a few spins
+    assert np.array_equal(host(W, W.denoise(bd, TI=True, nspin=(4, 3))), e)
+    W.clear_options()
+    v = (doppler(4096) + 0.05 * np.random.default_rng(4).standard_normal(4096)).astype(dtype)
+    e1 = _oracle_denoise(oracle, W, v, W.wavelet(W.WT.db4), 6, W.VisuShrink(W.SoftTH(), 2.0), True, (16,))
+    y1 = host(W, W.denoise(W.to_device(v), W.wavelet(W.WT.db4), dnt=W.VisuShrink(W.SoftTH(), 2.0), TI=True, nspin=16))
+    assert np.array_equal(y1, e1)
+    # custom estnoise: the same estimate computed by the caller must give the same bits
+    y2 = host(W, W.denoise(bd, TI=True, nspin=(4, 3), estnoise=lambda a, w: W.noisest(a, w)))
+    assert np.array_equal(y2, e)

@@ -37,17 +37,6 @@ inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int
 
 inline int ensure_ws(wl_ctx *ctx, size_t bytes) { return wl_ensure_ws(ctx, bytes); }
 
-template <typename T>
-void make_taps(const double *qmf, int flen, Taps<T> &t)
-{
-    t.F = flen;
-    for (int i = 0; i < WL_MAX_FLEN; ++i) { t.h[i] = (T)0; t.g[i] = (T)0; }
-    for (int i = 0; i < flen; ++i) {
-        t.h[i] = (T)qmf[i];                                   // copyto!(Vector{T}, qmf)
-        t.g[i] = (i % 2 == 0) ? t.h[i] : (T)(t.h[i] * (T)-1); // mirror(h), util_main.jl:30
-    }
-}
-
 // makescheme (transforms_lifting.jl:13-25)
 template <typename T>
 int make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift,

@@ -7,9 +7,12 @@
 // literally (Float32 data with Float64 taps / threshold: compute in Float64, round on every store) so the
 // results are bit-identical to the reference loops.
 #include "wl_ctx.h"
+#include "wl_fast.h"
 
 #include <cmath>
 #include <cstring>
+
+using namespace wl;
 
 namespace {
 
@@ -535,8 +538,10 @@ int mad_small(wl_ctx *ctx, hipStream_t st, T *v, int64_t n, int do_mad, double *
     const int threads = n >= 2048 ? 1024 : (n >= 256 ? 256 : 64);
     hipLaunchKernelGGL((k_mad_lds<T>), dim3(1), dim3(threads), (size_t)n * sizeof(typename KeyOf<T>::U), st, v, (int)n, do_mad, s);
     WL_HIP(ctx, hipGetLastError());
-    WL_HIP(ctx, hipMemcpyAsync(result_host, &s->result, sizeof(double), hipMemcpyDeviceToHost, st));
-    WL_HIP(ctx, hipStreamSynchronize(st));
+    if (result_host) {              // (nullptr: the result stays in the selection state on the device, nobody waits)
+        WL_HIP(ctx, hipMemcpyAsync(result_host, &s->result, sizeof(double), hipMemcpyDeviceToHost, st));
+        WL_HIP(ctx, hipStreamSynchronize(st));
+    }
     return WL_OK;
 }
 
@@ -639,6 +644,144 @@ template <typename T>
 __global__ void __launch_bounds__(EXT_THREADS) k_rmul(T *__restrict__ y, int64_t n, double s, int vec_ok)
 {
     ew_inplace<T>(y, n, vec_ok, [=](T v, int64_t) { return (T)((double)v * s); });
+}
+
+
+// ---- translation-invariant denoising as ONE batch (denoising.jl:36-67) ---------------------------------------------------
+// spin i (1-based) shifts dimension d by nspin2circ(nspin, i)[d] (denoising.jl:112-121: first dimension fastest)
+struct TiGeom { int64_t n0, n1, N; int64_t nsp0, nsp1; int64_t b0; };
+__device__ __forceinline__ void ti_shift_of(const TiGeom &g, int64_t spin0, int64_t &s0, int64_t &s1)
+{
+    s0 = (spin0 % g.nsp0) % g.n0;
+    s1 = ((spin0 / g.nsp0) % g.nsp1) % g.n1;
+}
+// Z[b] = circshift(x, +shift(b0 + b)): z[i] = x[i - shift] (Util.circshift!, util_main.jl:105-130)
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_ti_shift(T *__restrict__ Z, const T *__restrict__ x, TiGeom g, int64_t total)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthr) {
+        const int64_t b = e / g.N, r = e - b * g.N, i1 = r / g.n0, i0 = r - i1 * g.n0;
+        int64_t s0, s1;
+        ti_shift_of(g, g.b0 + b, s0, s1);
+        int64_t j0 = i0 - s0, j1 = i1 - s1;
+        if (j0 < 0) j0 += g.n0;
+        if (j1 < 0) j1 += g.n1;
+        Z[e] = x[j0 + g.n0 * j1];
+    }
+}
+// y += circshift(Z[b], -shift(b0 + b)) for b = 0 .. nb-1 IN THAT ORDER (arrayadd! once per spin: the summation order
+// of the reference, so the sums carry the same roundings)
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_ti_accumulate(T *__restrict__ y, const T *__restrict__ Z, TiGeom g, int64_t nb, int first)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < g.N; r += nthr) {
+        const int64_t i1 = r / g.n0, i0 = r - i1 * g.n0;
+        T acc = first ? (T)0 : y[r];
+        for (int64_t b = 0; b < nb; ++b) {
+            int64_t s0, s1;
+            ti_shift_of(g, g.b0 + b, s0, s1);
+            int64_t j0 = i0 + s0, j1 = i1 + s1;
+            if (j0 >= g.n0) j0 -= g.n0;
+            if (j1 >= g.n1) j1 -= g.n1;
+            acc = acc + Z[b * g.N + j0 + g.n0 * j1];
+        }
+        y[r] = acc;
+    }
+}
+// threshold!(x, TH, sigma * t_unit) with sigma = mad / 0.6745 read from the device (noisest, denoising.jl:92-101): the
+// product is formed in Float64 exactly as Julia does for a Float64 dnt.t, whatever the element type
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_threshold_dev(T *__restrict__ x, int64_t n, int th, const double *__restrict__ mad_dev,
+                                                               double t_unit, double sigma_host, int vec_ok)
+{
+    const double sigma = (sigma_host >= 0) ? sigma_host : (*mad_dev / 0.6745);
+    const double t = sigma * t_unit;
+    ew_inplace<T>(x, n, vec_ok, [=](T v, int64_t) { return threshold_one<T, double>(v, th, t); });
+}
+template <typename T>
+__global__ void __launch_bounds__(EXT_THREADS) k_copy_range(T *__restrict__ dst, const T *__restrict__ src, int64_t n)
+{
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += nthr) dst[e] = src[e];
+}
+
+template <typename T>
+int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, const int64_t *dims, const double *qmf, int flen, int L,
+                    int th, double t_unit, const int64_t *nspin, double sigma_host)
+{
+    const int64_t n0 = dims[0], n1 = (ndims == 2) ? dims[1] : 1, N = n0 * n1;
+    const int64_t nsp0 = nspin[0], nsp1 = (ndims == 2) ? nspin[1] : 1, pns = nsp0 * nsp1;
+    Taps<T> taps;
+    make_taps<T>(qmf, flen, taps);
+    int rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    SelState *sel = (SelState *)ctx->aux;
+    // spins per batch: the whole set unless the buffers (2 N B for the shifted copies and their coefficients, plus the
+    // transform workspace of the batch box) would pass the cap
+    const size_t cap = (size_t)opt("WL_TI_WS_CAP_MB", 16384) << 20;
+    auto need = [&](int64_t B) { return (ws_elems(N * B, ndims) + (size_t)2 * N * B + (size_t)n0 + 64) * sizeof(T); };
+    int64_t B = pns;
+    while (B > 1 && need(B) > cap) B = (B + 1) / 2;
+    if (B > 65535) B = 65535;
+    rc = wl_ensure_ws(ctx, need(B));
+    if (rc != WL_OK) return rc;
+    T *tw = (T *)ctx->ws;                                   // transform workspace of the batch box (with the generic buffers)
+    T *Z = tw + ws_elems(N * B, ndims);
+    T *XT = Z + N * B;
+    T *dr = XT + N * B;                                     // detail range of the noise estimate (n0/2 samples)
+    const unsigned nbk = ext_blocks(N * B, 4, ctx->cu_count);
+
+    // ---- sigma = noisest(x, wt): level-1 transform, MAD of y1[detailrange(y1, 1)] (linear indexing: first column) ----
+    if (!(sigma_host >= 0)) {
+        BoxSpec b1;
+        b1.nd = ndims; b1.nt = ndims;
+        b1.dims[0] = n0; b1.dims[1] = n1; b1.dims[2] = 1;
+        b1.full = dense_strides(b1.dims);
+        if (n0 < 2 || (n0 % 2) != 0 || (ndims == 2 && (n1 % 2) != 0)) return WL_EINVAL_SIZE;
+        rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, b1, XT, x, taps, 1, &ctx->last_kernel, &ctx->last_hip);
+        if (rc != WL_OK) return rc;
+        const int64_t lo = (int64_t)llround((double)n0 / 2 + 1) - 1, hi = n0;        // detailrange(n0, 1), 0-based half open
+        const int64_t nd = hi - lo;
+        hipLaunchKernelGGL((k_copy_range<T>), dim3(ext_blocks(nd, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, dr, XT + lo, nd);
+        if (nd <= mad_lds_max<T>()) {
+            rc = mad_small<T>(ctx, st, dr, nd, 1, nullptr);
+            if (rc != WL_OK) return rc;
+        } else {
+            void *mdev = (char *)ctx->aux + 4096;
+            rc = median_impl<T>(ctx, st, dr, nd, nullptr, (T *)mdev);
+            if (rc != WL_OK) return rc;
+            hipLaunchKernelGGL((k_absdev<T>), dim3(ext_blocks(nd, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, dr, nd, (const T *)mdev, vec_ok16(dr));
+            rc = median_impl<T>(ctx, st, dr, nd, nullptr, (T *)nullptr);
+            if (rc != WL_OK) return rc;
+        }
+    }
+    // ---- the spins, B at a time ----
+    BoxSpec bb;
+    bb.nd = ndims + 1; bb.nt = ndims;
+    bb.dims[0] = n0; bb.dims[1] = (ndims == 2) ? n1 : 0; bb.dims[2] = 1;
+    TiGeom g;
+    g.n0 = n0; g.n1 = n1; g.N = N; g.nsp0 = nsp0; g.nsp1 = nsp1;
+    for (int64_t b0 = 0; b0 < pns; b0 += B) {
+        const int64_t nb = (pns - b0 < B) ? (pns - b0) : B;
+        g.b0 = b0;
+        if (ndims == 2) { bb.dims[2] = nb; }
+        else { bb.dims[1] = nb; bb.dims[2] = 1; }
+        bb.full = dense_strides(bb.dims);
+        hipLaunchKernelGGL((k_ti_shift<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, Z, x, g, N * nb);
+        rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
+        if (rc != WL_OK) return rc;
+        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, XT, N * nb, th, &sel->result, t_unit, sigma_host,
+                           vec_ok16(XT));
+        const char *kn = nullptr;
+        rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, Z, XT, taps, L, &kn, &ctx->last_hip);
+        if (rc != WL_OK) return rc;
+        hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL((k_rmul<T>), dim3(ext_blocks(N, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, N, 1.0 / (double)pns, vec_ok16(y));
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
 }
 
 inline int ext_enter(wl_ctx *ctx, int dtype)
@@ -758,6 +901,31 @@ int wl_mad(wl_ctx *ctx, int dtype, void *y, int64_t n, double *result, void *str
     if (rc != WL_OK) return rc;
     hipLaunchKernelGGL((k_absdev<double>), dim3(nb), dim3(EXT_THREADS), 0, st, (double *)y, n, (const double *)mdev, vec_ok16(y));
     return median_impl<double>(ctx, st, (const double *)y, n, result, (double *)nullptr);
+}
+
+int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims, const double *qmf, int flen,
+                         int L, int th, double t_unit, const int64_t *nspin, double sigma_host, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
+    if (!y || !x || !dims || !qmf || !nspin) return WL_EINVAL_ARG;
+    if (ndims < 1 || ndims > 2) return WL_EDIMS;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (th < WL_TH_HARD || th > WL_TH_NEG) return WL_EINVAL_ARG;
+    for (int d = 0; d < ndims; ++d)
+        if (dims[d] < 1 || nspin[d] < 1) return WL_EDIMS;
+    if (ndims == 2 && dims[0] != dims[1]) return WL_EINVAL_CUBE;            // iscube(x) (denoising.jl:29)
+    if (L < 0) return WL_EINVAL_L;
+    for (int d = 0; d < ndims; ++d)
+        if (L >= 62 || (dims[d] % ((int64_t)1 << L)) != 0) return WL_EINVAL_SIZE;
+    if (y == x) return WL_EALIAS;
+    if (th <= WL_TH_STEIN && !(t_unit >= 0)) return WL_EINVAL_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    rc = dtype == WL_F32 ? denoise_ti_impl<float>(ctx, st, (float *)y, (const float *)x, ndims, dims, qmf, flen, L, th, t_unit, nspin, sigma_host)
+                         : denoise_ti_impl<double>(ctx, st, (double *)y, (const double *)x, ndims, dims, qmf, flen, L, th, t_unit, nspin, sigma_host);
+    if (rc == WL_OK) ctx->last_kernel = "denoise_ti_batch";
+    return rc;
 }
 
 int wl_circshift(wl_ctx *ctx, int dtype, void *b, const void *a, int ndims, const int64_t *dims, const int64_t *shift, void *stream)

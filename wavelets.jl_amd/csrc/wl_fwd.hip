@@ -1196,6 +1196,19 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         Strides3 ll_st = dense_strides(hn);
         Strides3 box_st = dense_strides(n);
 
+        // ---- batch of independent 2-D blocks (box n0 x n1 x B, first two axes transformed: the shifted copies of a
+        //      translation-invariant denoise): one launch of the LDS-exchange kernel per level, planes over blockIdx.y ----
+        if constexpr (sizeof(T) == 4) {
+            if (fastF && b.nd == 3 && b.nt == 2 && fwd2d_lds_ok(F, 1, n[0], n[1]) && n[2] <= 65535 && cur_st.s[0] == 1 &&
+                (cur_st.s[1] % VEC) == 0 && (cur_st.s[2] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&
+                (b.full.s[2] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+                WL_TRY(fwd2d_lds_launch(st, taps, 1, l == 1, cur, cur_st.s[1], y, b.full.s[1], last ? (T *)nullptr : llbuf, hn[0],
+                                        n[0], n[1], cu_count, n[2], cur_st.s[2], b.full.s[2], ll_st.s[2], (int)n[2]));
+                if (!dominant) dominant = "k_fwd2d_lds";
+                cur = llbuf; cur_st = ll_st; pp ^= 1;
+                continue;
+            }
+        }
         // ---- 2-D multi-level tiles for the cache-resident levels (two levels per launch) ----
         if (fastF && F <= 8 && two_d && env_int("WL_NO_MULTI2D", 0) == 0 && n[0] <= env_int("WL_M2D_MAX", 1024) &&
             n[1] <= env_int("WL_M2D_MAX", 1024) && n[0] >= env_int("WL_M2D_MIN", 128) && n[1] >= env_int("WL_M2D_MIN", 128) && (n[0] % 64) == 0 && (n[1] % 64) == 0 &&

@@ -48,6 +48,18 @@ struct Taps {
     T g[WL_MAX_FLEN];   // mirror(h)
 };
 
+// makereverseqmfpair (wt_main.jl:172-183): taps converted to T first, mirror sign applied in T
+template <typename T>
+inline void make_taps(const double *qmf, int flen, Taps<T> &t)
+{
+    t.F = flen;
+    for (int i = 0; i < WL_MAX_FLEN; ++i) { t.h[i] = (T)0; t.g[i] = (T)0; }
+    for (int i = 0; i < flen; ++i) {
+        t.h[i] = (T)qmf[i];                                   // copyto!(Vector{T}, qmf)
+        t.g[i] = (i % 2 == 0) ? t.h[i] : (T)(t.h[i] * (T)-1); // mirror(h), util_main.jl:30
+    }
+}
+
 template <typename T>
 struct LiftStep {
     int is_update;      // 0: Predict (writes the s half), 1: Update (writes the d half)

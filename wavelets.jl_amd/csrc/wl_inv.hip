@@ -915,6 +915,14 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             done = true;
             dominant = "k_inv_dim2_stream";
         }
+        // ---- batch of independent 2-D blocks (box n0 x n1 x B, first two axes transformed): the fused inverse level
+        //      kernel with the planes over blockIdx.y ----
+        if (!done && fastF && b.nd == 3 && b.nt == 2 && b.full.s[0] == 1 && (l == 1 || res_st.s[1] == n[0])) {
+            hipError_t e = hipSuccess;
+            done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e);
+            WL_TRYI(e);
+            if (done) dominant = "k_inv2d_stream";
+        }
         // ---- long filters (12..24 taps) ----
         if (!done && path == 0 && long_filter_ok(F) && i_env("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1) {
             hipError_t e = hipSuccess;

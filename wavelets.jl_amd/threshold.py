@@ -20,7 +20,7 @@ from . import util as Util
 from . import wt as WT
 from .transforms import (ArgumentError, DimensionMismatch, HIPError, _check, _context, _dims, _dtype_code, _prep_in,
                          dwt, dwt_oop_, idwt, idwt_, idwt_oop_, is_julia_layout, julia_layout, similar)
-from .wt import GLS, wavelet
+from .wt import GLS, OrthoFilter, wavelet
 
 
 # ---- threshold types (threshold_main.jl:8-17) --------------------------------------------------
@@ -218,12 +218,28 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
     nspin = tuple(8 for _ in range(x.dim())) if nspin is None else nspin
     if not Util.iscube(x):
         raise ArgumentError("array must be square/cube")
+    nsp = (int(nspin),) if not hasattr(nspin, "__len__") else tuple(int(s) for s in nspin)
+    if (TI and isinstance(wt, OrthoFilter) and x.dim() <= 2 and len(nsp) >= x.dim() and isinstance(dnt.th, THType)
+            and dnt.th.code is not None and dnt.th.code >= 0):
+        # the translation-invariant branch for orthogonal filters, vectors and square matrices: one device-resident batch
+        # (wl_denoise_ti_filter) -- all spins transformed / thresholded / inverted together, the noise estimate consumed on
+        # the device, nothing allocated per spin, no host synchronisation.  Same arithmetic in the same order as the loop below.
+        sig = -1.0 if estnoise is noisest else float(estnoise(x, wt))
+        if sig < 0 and estnoise is not noisest:
+            raise AssertionError("t >= 0")
+        y = similar(x)
+        h, st = _context(x.device)
+        q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
+        nsv = (C.c_int64 * 3)(*(list(nsp[:x.dim()]) + [1] * (3 - x.dim())))
+        _check(_lib.load().wl_denoise_ti_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
+                                                q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), dnt.th.code, float(dnt.t), nsv,
+                                                sig, st), h)
+        return y
     sigma = estnoise(x, wt)
     t = sigma * dnt.t
     if TI:
         if wt is None:
             raise RuntimeError("TI not supported with wt=nothing")
-        nsp = (int(nspin),) if not hasattr(nspin, "__len__") else tuple(int(s) for s in nspin)
         pns = int(np.prod(nsp))
         y = similar(x)
         y.zero_()

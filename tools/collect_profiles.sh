@@ -1,27 +1,31 @@
 #!/bin/bash
 # Collect the round's measurement evidence on the GPU box (run through gpurun from the repo root):
-#   bench lines for every BASELINE config, rocprofv3 kernel stats, and the PMC traffic passes of the headline
-#   kernel (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only).  rocprofv3 does not exit on
-#   its own on this image once the child has finished, hence the hard timeouts; the CSVs are complete by then.
-R=${1:-r01}
-O=$PWD/gpurun_out/prof_$R
+#   bench lines for every BASELINE config, rocprofv3 kernel stats of the same commands, the PMC traffic passes of the
+#   headline kernel (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only) and the perf matrix.
+#   tools/rp.sh returns as soon as rocprofv3's CSVs are on disk (rocprofv3 does not exit on its own on this image).
+R=${1:-r02}
+REPO=$PWD
+O=$REPO/gpurun_out/prof_$R
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-REPO=$OLDPWD
+export LD_LIBRARY_PATH=$REPO/wavelets.jl_amd:$LD_LIBRARY_PATH
+B=$REPO/tools/wlbench.bin
 for c in c3 c1 c2 c4 c5; do
-  extra="--no-secondary"; [ $c = c3 ] && extra=""
-  timeout 280 python $REPO/bench.py --workload $c $extra > $O/bench_$c.json 2> $O/bench_$c.err
+  extra="--no-secondary --no-c5"; [ $c = c3 ] && extra=""
+  timeout 400 python $REPO/bench.py --workload $c $extra > $O/bench_$c.json 2> $O/bench_$c.err
 done
+# rocprofv3 --kernel-trace --stats of the bench command itself (short: the statistics need a few hundred launches, not more)
 for c in c3 c2 c4 c5; do
-  timeout -s KILL 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -o $R -- \
-    python $REPO/bench.py --workload $c --no-cpu --no-secondary --steps 50 --warmup 3 > $O/stats_$c.log 2>&1
+  $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --steps 50 --warmup 3
 done
-for k in idwt2d lift2d dwt3d modwt; do
-  timeout -s KILL 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$k -o $R -- \
-    python $REPO/tools/run_case.py $k 20 > $O/stats_$k.log 2>&1
+for k in idwt2d lift2d dwt3d modwt denoise; do
+  $REPO/tools/rp.sh $O/stats_$k $R "--kernel-trace --stats" python $REPO/tools/run_case.py $k 20
 done
+# PMC: the first launch of the headline transform (L = 1 call = exactly that kernel), torch-free harness
 for pmc in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 100 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_$pmc -o $R -- \
-    python $REPO/bench.py --workload c3 --no-cpu --no-secondary --steps 30 --warmup 0 --levels 2 > $O/pmc_$pmc.log 2>&1
+  $REPO/tools/rp.sh $O/pmc_$pmc $R "--kernel-trace --pmc $pmc" $B L=1 reps=30 warm=5 check=0
 done
-find $O -name "*.csv" | head -50
+$REPO/tools/rp.sh $O/pmc_sq $R "--kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $B L=1 reps=30 warm=5 check=0
+$REPO/tools/rp.sh $O/pmc_tcc $R "--kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $B L=1 reps=30 warm=5 check=0
+timeout 600 python $REPO/tools/perf_matrix.py > $O/perf_matrix.md 2> $O/perf_matrix.err
+find $O -name "*.csv" -size +4M -delete
+find $O -name "*.csv" | head -60

@@ -66,7 +66,28 @@ for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
     rows.append(("denoise 1-D 2^22 / 2-D 2048^2 (sym5, VisuShrink, L=6)", tag, 6, t1, t2, float("nan"), float("nan"), "noisest + dwt + threshold! + idwt"))
     del v, w, a, out
     torch.cuda.empty_cache()
+# ---- every orthogonal filter of the reference's FILTERS table (wt_main.jl:372-436) on the headline shape ----
+frows = []
+names = ["haar"] + [f"db{i}" for i in range(2, 11)] + ["coif2", "coif4", "coif6", "coif8"] + [f"sym{i}" for i in range(4, 11)] + \
+        ["batt2", "batt4", "batt6", "beyl", "vaid"]
+x = jl((8192, 8192), torch.float32); y = W.similar(x)
+for nm in names:
+    wt = W.wavelet(getattr(W.WT, nm))
+    tf = timeit(lambda: W.dwt_oop_(y, x, wt, 13), reps=8); kf = W.last_kernel()
+    ti = timeit(lambda: W.idwt_oop_(x, y, wt, 13), reps=8); ki = W.last_kernel()
+    frows.append((nm, len(wt.qmf), tf, ti, kf, ki))
+del x, y
+torch.cuda.empty_cache()
+
 print("| entry point | T | L | forward µs | inverse µs | fwd GB/s (algorithmic) | inv GB/s | dominant kernels |")
 print("|---|---|---|---|---|---|---|---|")
 for r in rows:
     print(f"| {r[0]} | {r[1]} | {r[2]} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.0f} | {r[6]:.0f} | {r[7]} |")
+
+print()
+print("Filter table (wt_main.jl:372-436), 2-D dwt / idwt 8192 x 8192 Float32, L = 13:")
+print()
+print("| filter | taps | forward µs | inverse µs | forward kernel | inverse kernel |")
+print("|---|---|---|---|---|---|")
+for r in frows:
+    print(f"| {r[0]} | {r[1]} | {r[2]:.1f} | {r[3]:.1f} | {r[4]} | {r[5]} |")

@@ -24,6 +24,9 @@ elif case == "dwt3d":
 elif case == "modwt":
     x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
     fn = lambda: W.modwt(x, db4, 8)
+elif case == "denoise":
+    x = torch.randn(2048, 2048, generator=g, dtype=torch.float32).cuda().t()
+    fn = lambda: W.denoise(x, TI=True)
 else:
     raise SystemExit("unknown case")
 for _ in range(reps):

@@ -1,12 +1,13 @@
 """Turn gpurun_out/prof_<round>/ (written by tools/collect_profiles.sh on the GPU box) into the committed summaries
-under profiles/: per-config bench lines, rocprofv3 kernel-stats CSVs, the PMC counter CSVs of the headline kernel and
-profiles/pmc_latest.json (bytes per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 note)."""
+under profiles/: per-config bench lines, rocprofv3 kernel-stats CSVs, the PMC counter CSVs of the headline kernel,
+profiles/pmc_latest.json (bytes per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 note) and the perf matrix."""
 import csv, glob, json, os, shutil, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
+HEAD = "k_fwd2d_lds<8, 1, 1>"          # first launch of the 8192 x 8192 f32 db4 transform (its own template instance)
 
 
 def find(sub, pat):
@@ -20,38 +21,62 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
-for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "dwt3d", "modwt"):
+for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "dwt3d", "modwt", "denoise"):
     p = find(f"stats_{k}", "*kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(DST, f"{R}_{k}_kernel_stats.csv"))
+p = os.path.join(SRC, "perf_matrix.md")
+if os.path.exists(p) and os.path.getsize(p) > 100:
+    shutil.copy(p, os.path.join(DST, f"{R}_perf_matrix.md"))
+
+
+def counters(sub):
+    """{counter: (average per launch of the headline kernel, launches)} from one PMC pass"""
+    p = find(sub, "*counter_collection.csv")
+    out = {}
+    if not p:
+        return out, None
+    acc = {}
+    for r in csv.DictReader(open(p)):
+        if HEAD in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        out[k] = (sum(v) / len(v), len(v))
+    return out, p
+
+
 pm = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
-    p = find(f"pmc_{name}", "*counter_collection.csv")
-    if not p:
-        continue
-    rows = [r for r in csv.DictReader(open(p)) if "k_fwd2d_stream2" in r["Kernel_Name"] and r["Counter_Name"] == name]
-    keep = os.path.join(DST, f"{R}_c3_first_launch_pmc_{name.lower()}.csv")
-    with open(p) as f, open(keep, "w") as g:           # keep only the headline kernel's rows (small file)
-        for i, line in enumerate(f):
-            if i == 0 or "k_fwd2d_stream2" in line:
-                g.write(line)
-    vals = [float(r["Counter_Value"]) for r in rows]
-    pm[name] = (sum(vals) / len(vals), len(vals))
+    c, p = counters(f"pmc_{name}")
+    if name in c:
+        pm[name] = c[name]
+        keep = os.path.join(DST, f"{R}_c3_first_launch_pmc_{name.lower()}.csv")
+        with open(p) as f, open(keep, "w") as g:           # keep only the headline kernel's rows (small file)
+            for i, line in enumerate(f):
+                if i == 0 or HEAD in line:
+                    g.write(line)
+extra = {}
+for sub in ("pmc_sq", "pmc_tcc"):
+    c, _ = counters(sub)
+    for k, v in c.items():
+        extra[k] = round(v[0], 1)
 if len(pm) == 2:
     fetch = pm["FETCH_SIZE"][0] * 1024 * 2          # KB -> bytes, x2 (gfx950: FETCH_SIZE counts half of the 16-B/lane reads)
     write = pm["WRITE_SIZE"][0] * 1024
     alg = 2 * 8192 * 8192 * 4
     out = {
-        "kernel": "wl::k_fwd2d_stream2<float, 8, 1> (first launch of the 8192x8192 f32 db4 dwt: levels 1-2)",
-        "kernel_short": "k_fwd2d_stream2",
+        "kernel": f"wl::{HEAD} (first launch of the 8192x8192 f32 db4 dwt: level 1)",
+        "kernel_short": "k_fwd2d_lds",
         "FETCH_SIZE_KB_raw": round(pm["FETCH_SIZE"][0], 1), "WRITE_SIZE_KB_raw": round(pm["WRITE_SIZE"][0], 1),
         "launches": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]],
         "fetch_bytes_corrected": int(fetch), "write_bytes": int(write), "hbm_bytes_per_launch": int(fetch + write),
         "algorithmic_bytes_per_launch": alg,
+        "other_counters_avg_per_launch": extra,
         "note": ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only "
                  f"(profiles/{R}_c3_first_launch_pmc_*.csv); per-launch averages in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-                 "(gfx950 reports 1/2 of 16-B/lane coalesced reads). traffic/algorithmic = %.3f (read side: strip overlap 48/256 rows "
-                 "mostly absorbed by L2, chunk halo 18/128 columns)" % ((fetch + write) / alg)),
+                 "(gfx950 reports 1/2 of 16-B/lane coalesced reads). traffic/algorithmic = %.3f (exact row tiling: the only "
+                 "redundant reads are the 6 halo columns per 128-column chunk and the helper waves' 8 halo rows per 1024)"
+                 % ((fetch + write) / alg)),
     }
     json.dump(out, open(os.path.join(DST, "pmc_latest.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))

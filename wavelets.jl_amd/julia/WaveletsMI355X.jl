@@ -21,6 +21,32 @@ const DT = Dict(Float32 => Cint(0), Float64 => Cint(1))
 # overlap on the GPU (the small levels of one hide behind the first kernel of the next).
 const CTX = Dict{Tuple{Int,UInt},Ptr{Cvoid}}()
 const CTX_LOCK = ReentrantLock()
+const OPTIONS = Dict{String,Int64}()                     # wl_ctx_set_option pairs applied to every context
+
+"""Destroy every context (and its device workspace) created so far; new ones are created on demand.  Registered with
+`atexit`, and useful after a burst of work on short-lived tasks: a context is keyed by (device, stream) and would
+otherwise live as long as the process."""
+function destroy_contexts!()
+    lock(CTX_LOCK) do
+        for h in values(CTX)
+            ccall((:wl_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+        end
+        empty!(CTX)
+    end
+    return nothing
+end
+__init__() = atexit(destroy_contexts!)
+
+"""`set_option!("WL_TJ", 128)`: tuning / test switch on every context (DESIGN.md section 5 lists them; none changes a result)."""
+function set_option!(key::AbstractString, value::Integer)
+    lock(CTX_LOCK) do
+        OPTIONS[String(key)] = Int64(value)
+        for h in values(CTX)
+            check(ccall((:wl_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), h, key, value))
+        end
+    end
+    return nothing
+end
 
 stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))     # hipStream_t of the current task
 function ctx()
@@ -30,6 +56,9 @@ function ctx()
         get!(CTX, key) do
             r = Ref{Ptr{Cvoid}}(C_NULL)
             check(ccall((:wl_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), dev, r))
+            for (k, v) in OPTIONS
+                check(ccall((:wl_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), r[], k, v))
+            end
             r[]
         end
     end
@@ -75,6 +104,21 @@ function Transforms._dwt!(y::ROCArray{T,N}, scheme::GLS, L::Integer, fw::Bool) w
     return y
 end
 
+# dwt(x, scheme::GLS, L) / idwt(x, scheme, L) of the reference are `y = similar(x); copyto!(y, x); _dwt!(y, scheme, L, fw)`
+# (transforms_main.jl:119-124).  The library's out-of-place entry fuses the copy away (same bits, one pass less).
+for (f, fw) in ((:dwt, true), (:idwt, false))
+    @eval function Transforms.$f(x::ROCArray{T,N}, scheme::GLS, L::Integer=Util.maxtransformlevels(x)) where {T<:Union{Float32,Float64},N}
+        y = similar(x)
+        isup, nc, sh, cf = flatten(scheme)
+        check(ccall((:wl_dwt_lifting_oop, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                     Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), length(isup), isup, nc, sh, cf,
+                    scheme.norm1, scheme.norm2, L, $fw, stream()))
+        return y
+    end
+end
+
 # ---- wavelet packets: replaces _wpt!, transforms_filter.jl:301, transforms_lifting.jl:283
 function Transforms._wpt!(y::ROCVector{T}, x::ROCVector{T}, filter::OrthoFilter, tree::BitVector,
                           fw::Bool) where {T<:Union{Float32,Float64}}
@@ -104,6 +148,19 @@ for (f, fw) in ((:dwtc, true), (:idwtc, false))
                     (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
                     ctx(), DT[T], pointer(y), pointer(x), size(x, 1), size(x, 2), size(x, 1),
                     filter.qmf, length(filter.qmf), L, $fw, stream()))
+        return y
+    end
+end
+
+for (f, fw) in ((:dwtc, true), (:idwtc, false))
+    @eval function $f(x::ROCMatrix{T}, scheme::GLS, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T<:Union{Float32,Float64}}
+        y = copy(x)                                 # lifting is in place (transforms_lifting.jl:30)
+        isup, nc, sh, cf = flatten(scheme)
+        check(ccall((:wl_dwtc_lifting, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                     Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), size(y, 1), size(y, 2), size(y, 1), length(isup), isup, nc, sh, cf,
+                    scheme.norm1, scheme.norm2, L, $fw, stream()))
         return y
     end
 end
@@ -167,6 +224,32 @@ function Threshold.arrayadd!(y::ROCArray{T}, z::ROCArray{T}) where {T<:Union{Flo
     length(y) == length(z) || throw(DimensionMismatch("lengths must be equal"))
     check(ccall((:wl_arrayadd, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(z), length(y), stream()))
+    return y
+end
+
+
+# ---- denoise, translation-invariant branch (denoising.jl:36-67) as one device-resident batch ----------------------
+# The generic method of the reference already works on ROCArrays through the methods above (one spin at a time, a host
+# round trip for sigma).  For orthogonal filters on vectors and square matrices this method runs all prod(nspin) spins
+# as one batch and keeps sigma on the device; other argument combinations fall through to the generic method.
+using Wavelets.Threshold: DNFT, VisuShrink, noisest
+function Threshold.denoise(x::ROCArray{T,N}, wt::OrthoFilter=Threshold.DEFAULT_WAVELET;
+                           L::Int=min(Util.maxtransformlevels(x), 6), dnt::S=VisuShrink(size(x, 1)),
+                           estnoise::Function=noisest, TI::Bool=false,
+                           nspin::Union{Int,Tuple}=tuple([8 for i = 1:ndims(x)]...)) where {T<:Union{Float32,Float64},N,S<:DNFT}
+    if !(TI && N <= 2 && haskey(THCODE, typeof(dnt.th)))
+        return invoke(Threshold.denoise, Tuple{AbstractArray,Union{Wavelets.WT.DiscreteWavelet,Nothing}}, x, wt;
+                      L=L, dnt=dnt, estnoise=estnoise, TI=TI, nspin=nspin)
+    end
+    Util.iscube(x) || throw(ArgumentError("array must be square/cube"))
+    sigma = estnoise === noisest ? -1.0 : Float64(estnoise(x, wt))
+    y = similar(x)
+    nsp = Int64[(nspin isa Int ? (nspin,) : nspin)..., 1, 1, 1][1:3]
+    check(ccall((:wl_denoise_ti_filter, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Cdouble, Ptr{Int64},
+                 Cdouble, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), wt.qmf, length(wt.qmf), L, THCODE[typeof(dnt.th)],
+                Float64(dnt.t), nsp, sigma, stream()))
     return y
 end
 

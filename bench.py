@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="0 fast kernels, 1 generic kernels only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs")
     ap.add_argument("--no-c5", action="store_true", help="skip the sharded C5 batch object")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the 4-stream leg (profiling runs: overlapping launches skew per-kernel statistics)")
     ap.add_argument("--c5-signals", type=int, default=65536, help="total signals of the sharded C5 batch (BASELINE: 65536)")
     ap.add_argument("--stub-backend", default=None, help=argparse.SUPPRESS)   # tests only: 'gloo' = CPU ranks, stub transform
     return ap.parse_args()
@@ -230,7 +231,7 @@ def main():
         c5 = c5_batched_leg(W, sharding, dist, device, rank, world, args)
         if rank == 0:
             out["c5_batched"] = c5
-    if rank == 0 and world == 1 and not batched:
+    if rank == 0 and world == 1 and not batched and not args.no_pipelined:
         out["pipelined"] = pipelined_leg(W, x, wt, L, args)
     if rank == 0:
         out["roofline"] = roofline_leg(W, x, wt, batched, esize, args, kernel)

@@ -15,7 +15,7 @@ for c in c3 c1 c2 c4 c5; do
 done
 # rocprofv3 --kernel-trace --stats of the bench command itself (short: the statistics need a few hundred launches, not more)
 for c in c3 c2 c4 c5; do
-  $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --steps 50 --warmup 3
+  $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --no-pipelined --steps 50 --warmup 3
 done
 for k in idwt2d lift2d dwt3d modwt denoise; do
   $REPO/tools/rp.sh $O/stats_$k $R "--kernel-trace --stats" python $REPO/tools/run_case.py $k 20

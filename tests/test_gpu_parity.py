@@ -185,7 +185,8 @@ def test_fused_level_pair_kernel(gpu, W, oracle):
     kernels (odd/even L, non-square blocks, partial strips and chunks, every supported filter length)."""
     W.set_option("WL_FUSE2_MIN", 0)
     W.set_option("WL_LDS2D", 0)          # (the LDS-exchange kernel, tested below, takes these shapes by default)
-    W.set_option("WL_M2D_MAX", 128)      # (... and the tile kernel everything up to 1024 x 1024)
+    W.set_option("WL_M2D_MAX", 128)      # (... and the tile kernels everything up to 2048 x 2048)
+    W.set_option("WL_TILE", 0)
     for shape, Ls in (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (4, 9)), ((528, 96), (2, 4)),
                       ((4096, 64), (2,))):
         x = rng_array(shape, np.float32, sum(shape))
@@ -211,7 +212,8 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
     W.set_option("WL_LDS_MODE", mode)
     W.set_option("WL_FUSE2", pair)
     W.set_option("WL_LDS_PAIR_MIN", 0)
-    W.set_option("WL_M2D_MAX", 128)      # (the tile kernel would otherwise take everything up to 1024 x 1024)
+    W.set_option("WL_M2D_MAX", 128)      # (the tile kernels would otherwise take everything up to 2048 x 2048)
+    W.set_option("WL_TILE", 0)
     shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4, 9)), ((528, 96), (1, 2, 4)), ((4096, 64), (1, 2)),
               ((256, 256), (1, 2)), ((1000, 64), (1, 2, 3)), ((272, 64), (1,)), ((768, 1024), (2, 3)), ((1280, 128), (1, 2)))
     for shape, Ls in shapes:
@@ -223,6 +225,29 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
                 assert W.last_kernel() in ("k_fwd2d_lds", "k_fwd2d_lds2"), (shape, L, W.last_kernel())
                 ye = oracle.dwt_filter(x, wt.qmf, L)
                 assert np.array_equal(y, ye), (shape, fname, L, mode, pair, float(np.abs(y - ye).max()))
+
+
+@pytest.mark.parametrize("nl3max", [0, 4096])
+def test_tile_kernel(gpu, W, oracle, nl3max):
+    """k_fwd2d_tile (1..3 fused levels of a cache-resident block per launch, one-sided halos, 64 x 64 tiles): every supported
+    filter length, one / two / three levels per launch (WL_TILE_NL3_MAX), depths that end inside / after the tiled levels,
+    non-square blocks, periodic wrap of the last tiles -- bit for bit against the oracle."""
+    W.set_option("WL_TILE_NL3_MAX", nl3max)
+    W.set_option("WL_TILE_MAX", 2048)
+    W.set_option("WL_LDS2D_MIN_ROWS", 1 << 20)      # keep the streaming kernel out: every level >= 128 goes to the tile kernel
+    shapes = (((128, 128), (1, 2, 3, 7)), ((256, 256), (1, 2, 3, 4, 8)), ((512, 512), (2, 3, 5, 9)), ((1024, 1024), (3, 6)),
+              ((256, 128), (1, 2, 3, 7)), ((128, 512), (2, 3)), ((2048, 2048), (2, 3)), ((192, 320), (1, 2, 3)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape) + nl3max)
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            if shape[0] >= 1024 and fname in ("db2", "db3"):
+                continue
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_tile", (shape, L, W.last_kernel())
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                assert np.array_equal(y, ye), (shape, fname, L, nl3max, int((y != ye).sum()))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -49,6 +49,11 @@ hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, b
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
                             int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
 
+// Tile kernel for the cache-resident 2-D levels (wl_tile.hip): NL = 1..3 fused forward levels per launch, Float32, even F <= 10.
+bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N);
+hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, const float *src, int64_t lds, float *y, int64_t ldy,
+                             float *ll, int64_t ldll, int M, int N);
+
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
 template <typename T>
 bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev);

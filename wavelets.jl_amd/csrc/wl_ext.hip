@@ -655,39 +655,61 @@ __device__ __forceinline__ void ti_shift_of(const TiGeom &g, int64_t spin0, int6
     s0 = (spin0 % g.nsp0) % g.n0;
     s1 = ((spin0 / g.nsp0) % g.nsp1) % g.n1;
 }
-// Z[b] = circshift(x, +shift(b0 + b)): z[i] = x[i - shift] (Util.circshift!, util_main.jl:105-130)
+// Z[b] = circshift(x, +shift(b0 + b)): z[i] = x[i - shift] (Util.circshift!, util_main.jl:105-130).
+// grid: x = groups of 4 rows, y = column, z = spin (no integer division per element; 16-byte stores, the shifted reads are
+// four scalar loads from a contiguous run)
 template <typename T>
-__global__ void __launch_bounds__(EXT_THREADS) k_ti_shift(T *__restrict__ Z, const T *__restrict__ x, TiGeom g, int64_t total)
+__global__ void __launch_bounds__(256) k_ti_shift(T *__restrict__ Z, const T *__restrict__ x, TiGeom g)
 {
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += nthr) {
-        const int64_t b = e / g.N, r = e - b * g.N, i1 = r / g.n0, i0 = r - i1 * g.n0;
-        int64_t s0, s1;
-        ti_shift_of(g, g.b0 + b, s0, s1);
-        int64_t j0 = i0 - s0, j1 = i1 - s1;
-        if (j0 < 0) j0 += g.n0;
-        if (j1 < 0) j1 += g.n1;
-        Z[e] = x[j0 + g.n0 * j1];
+    const int64_t b = blockIdx.z, i1 = blockIdx.y;
+    int64_t s0, s1;
+    ti_shift_of(g, g.b0 + b, s0, s1);
+    int64_t j1 = i1 - s1;
+    if (j1 < 0) j1 += g.n1;
+    const T *src = x + g.n0 * j1;
+    T *dst = Z + b * g.N + g.n0 * i1;
+    for (int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i0 < g.n0; i0 += 4 * (int64_t)gridDim.x * blockDim.x) {
+        T v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int64_t j0 = i0 + e - s0;
+            if (j0 < 0) j0 += g.n0;
+            v[e] = (i0 + e < g.n0) ? src[j0] : (T)0;
+        }
+        if (i0 + 3 < g.n0 && (g.n0 & 3) == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[i0 + e] = v[e];
+        } else {
+            for (int e = 0; e < 4 && i0 + e < g.n0; ++e) dst[i0 + e] = v[e];
+        }
     }
 }
 // y += circshift(Z[b], -shift(b0 + b)) for b = 0 .. nb-1 IN THAT ORDER (arrayadd! once per spin: the summation order
-// of the reference, so the sums carry the same roundings)
+// of the reference, so the sums carry the same roundings).  grid: x = groups of 4 rows, y = column.
 template <typename T>
-__global__ void __launch_bounds__(EXT_THREADS) k_ti_accumulate(T *__restrict__ y, const T *__restrict__ Z, TiGeom g, int64_t nb, int first)
+__global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const T *__restrict__ Z, TiGeom g, int64_t nb, int first)
 {
-    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < g.N; r += nthr) {
-        const int64_t i1 = r / g.n0, i0 = r - i1 * g.n0;
-        T acc = first ? (T)0 : y[r];
+    const int64_t i1 = blockIdx.y;
+    for (int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i0 < g.n0; i0 += 4 * (int64_t)gridDim.x * blockDim.x) {
+        T acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (first || i0 + e >= g.n0) ? (T)0 : y[i0 + e + g.n0 * i1];
         for (int64_t b = 0; b < nb; ++b) {
             int64_t s0, s1;
             ti_shift_of(g, g.b0 + b, s0, s1);
-            int64_t j0 = i0 + s0, j1 = i1 + s1;
-            if (j0 >= g.n0) j0 -= g.n0;
+            int64_t j1 = i1 + s1;
             if (j1 >= g.n1) j1 -= g.n1;
-            acc = acc + Z[b * g.N + j0 + g.n0 * j1];
+            const T *zp = Z + b * g.N + g.n0 * j1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int64_t j0 = i0 + e + s0;
+                if (j0 >= g.n0) j0 -= g.n0;
+                if (i0 + e < g.n0) acc[e] = acc[e] + zp[j0];
+            }
         }
-        y[r] = acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i0 + e < g.n0) y[i0 + e + g.n0 * i1] = acc[e];
     }
 }
 // threshold!(x, TH, sigma * t_unit) with sigma = mad / 0.6745 read from the device (noisest, denoising.jl:92-101): the
@@ -769,7 +791,10 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
         if (ndims == 2) { bb.dims[2] = nb; }
         else { bb.dims[1] = nb; bb.dims[2] = 1; }
         bb.full = dense_strides(bb.dims);
-        hipLaunchKernelGGL((k_ti_shift<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, Z, x, g, N * nb);
+        {
+            const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
+            hipLaunchKernelGGL((k_ti_shift<T>), dim3(gx, (unsigned)n1, (unsigned)nb), dim3(256), 0, st, Z, x, g);
+        }
         rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
         if (rc != WL_OK) return rc;
         hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, XT, N * nb, th, &sel->result, t_unit, sigma_host,
@@ -777,7 +802,10 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
         const char *kn = nullptr;
         rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, Z, XT, taps, L, &kn, &ctx->last_hip);
         if (rc != WL_OK) return rc;
-        hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
+        {
+            const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
+            hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(gx, (unsigned)n1), dim3(256), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
+        }
     }
     hipLaunchKernelGGL((k_rmul<T>), dim3(ext_blocks(N, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, N, 1.0 / (double)pns, vec_ok16(y));
     WL_HIP(ctx, hipGetLastError());
@@ -916,6 +944,7 @@ int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndi
     for (int d = 0; d < ndims; ++d)
         if (dims[d] < 1 || nspin[d] < 1) return WL_EDIMS;
     if (ndims == 2 && dims[0] != dims[1]) return WL_EINVAL_CUBE;            // iscube(x) (denoising.jl:29)
+    if (ndims == 2 && dims[1] > 65535) return WL_EINVAL_SIZE;               // (one grid row per column in the shift kernels)
     if (L < 0) return WL_EINVAL_L;
     for (int d = 0; d < ndims; ++d)
         if (L >= 62 || (dims[d] % ((int64_t)1 << L)) != 0) return WL_EINVAL_SIZE;

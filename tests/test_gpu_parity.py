@@ -152,6 +152,37 @@ def test_fused_inverse_2d_kernel(gpu, W, oracle, dtype, ppl):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_battle_filter_kernels(gpu, W, oracle, dtype):
+    """Odd-length, 23..59-tap Battle-Lemarie filters (wt_main.jl:372-436): k_vl_lines_* (LDS-staged lines) and k_vl_axis_*
+    (register window marching along the strided axis), 1-D / batched columns / 2-D incl. non-square blocks and axis lengths
+    shorter than the filter, forward and inverse, bit for bit against the oracle; smaller levels fall to the generic kernels."""
+    for fname, flen in (("batt2", 23), ("batt4", 41), ("batt6", 59)):
+        wt = W.wavelet(getattr(W.WT, fname))
+        assert len(wt.qmf) == flen
+        for shape, Ls in (((4096,), (1, 3, 12)), ((1 << 16,), (16,)), ((1000 * 8,), (2,)), ((512, 512), (1, 2)), ((1024, 2048), (3,)),
+                          ((2048, 64), (1,)), ((520, 96), (1,)), ((512, 32), (1,)), ((4096, 4096), (1,))):
+            if dtype == np.float64 and shape in ((1024, 2048), (4096, 4096)):
+                continue
+            if shape == (4096, 4096) and flen != 59:
+                continue
+            x = rng_array(shape, dtype, flen + sum(shape))
+            for L in Ls:
+                ye = oracle.dwt2d_filter_mt(x, wt.qmf, L) if shape == (4096, 4096) else oracle.dwt_filter(x, wt.qmf, L)
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                big = L == 1 and int(np.prod(shape)) > 16384      # smaller blocks are finished by the LDS tail kernels alone
+                assert W.last_kernel() == "k_vl_lines" or not big, (fname, shape, L, W.last_kernel())
+                assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                assert W.last_kernel() == "k_vl_lines" or not big, (fname, shape, L, W.last_kernel())
+                xe = oracle.dwt2d_filter_mt(ye, wt.qmf, L, fw=False) if shape == (4096, 4096) else oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+                assert np.array_equal(xr, xe), (fname, shape, L, "inv")
+        xm = rng_array((4096, 5), dtype, flen)
+        assert np.array_equal(host(W, W.dwtc(dev(W, xm), wt, 4)), oracle.dwtc_filter(xm, wt.qmf, 4))
+        ym = oracle.dwtc_filter(xm, wt.qmf, 4)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ym), wt, 4)), oracle.dwtc_filter(ym, wt.qmf, 4, fw=False))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_long_filter_kernels(gpu, W, oracle, dtype):
     """12..24-tap filters (db6..db10, sym6..sym10, coif4..coif8): k_long_lines (multi-lane halo) and the 32-slot
     ring of the axis kernels, 1-D / batched columns / 2-D, forward and inverse, bit for bit against the oracle."""

@@ -530,7 +530,14 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     default: break;                                          \
     }
 
-bool long_filter_ok(int F) { return F == 12 || F == 14 || F == 16 || F == 18 || F == 20 || F == 24; }
+static bool ring_filter_ok(int F) { return F == 12 || F == 14 || F == 16 || F == 18 || F == 20 || F == 24; }
+bool long_filter_ok(int F) { return ring_filter_ok(F) || vlong_filter_ok(F); }
+// smallest 2-D level the two-pass long-filter path takes (rows n0 contiguous, n1 columns)
+bool long_shape2d_ok(int F, int64_t n0, int64_t n1)
+{
+    if (vlong_filter_ok(F)) return n0 >= 16 && (n0 % 8) == 0 && n1 >= 16 && (n1 % 8) == 0;
+    return n0 >= 512 && (n0 % 8) == 0 && n1 >= 32 && (n1 % 32) == 0;
+}
 
 // One forward level of `nlines` lines with a long filter: s -> sdst, d -> ddst (line strides in elements).
 template <typename T>
@@ -539,9 +546,13 @@ bool long_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int
 {
     constexpr int VEC = 16 / sizeof(T);
     *err = hipSuccess;
-    if (!long_filter_ok(taps.F) || n < 512 || (n % 8) != 0 || !a_al16(src) || !a_al16(sdst) || !a_al16(ddst) ||
+    if (!long_filter_ok(taps.F) || n < (vlong_filter_ok(taps.F) ? 16 : 512) || (n % 8) != 0 || !a_al16(src) || !a_al16(sdst) || !a_al16(ddst) ||
         (nlines > 1 && ((src_ls % VEC) != 0 || (s_ls % VEC) != 0 || (d_ls % VEC) != 0)))
         return false;
+    if (vlong_filter_ok(taps.F)) {
+        *err = vl_lines_fwd<T>(st, taps, src, src_ls, sdst, s_ls, ddst, d_ls, n, nlines);
+        return true;
+    }
     bool ok = false;
     WL_DISPATCH_FL(taps.F, {
         LongArgs<T, FF> a;
@@ -557,9 +568,13 @@ bool long_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, in
 {
     constexpr int VEC = 16 / sizeof(T);
     *err = hipSuccess;
-    if (!long_filter_ok(taps.F) || n < 512 || (n % 8) != 0 || !a_al16(ssrc) || !a_al16(dsrc) || !a_al16(dst) ||
+    if (!long_filter_ok(taps.F) || n < (vlong_filter_ok(taps.F) ? 16 : 512) || (n % 8) != 0 || !a_al16(ssrc) || !a_al16(dsrc) || !a_al16(dst) ||
         (nlines > 1 && ((s_ls % VEC) != 0 || (d_ls % VEC) != 0 || (o_ls % VEC) != 0)))
         return false;
+    if (vlong_filter_ok(taps.F)) {
+        *err = vl_lines_inv<T>(st, taps, ssrc, s_ls, dsrc, d_ls, dst, o_ls, n, nlines);
+        return true;
+    }
     bool ok = false;
     WL_DISPATCH_FL(taps.F, {
         LongArgs<T, FF> a;
@@ -576,9 +591,13 @@ bool long_axis_level(hipStream_t st, const Taps<T> &taps, int fw, const T *src, 
 {
     constexpr int VEC = 16 / sizeof(T);
     *err = hipSuccess;
-    if (!long_filter_ok(taps.F) || (C % 32) != 0 || C < 32 || (R % VEC) != 0 || (lds % VEC) != 0 || (ldd % VEC) != 0 ||
+    if (!long_filter_ok(taps.F) || (C % (vlong_filter_ok(taps.F) ? 8 : 32)) != 0 || C < (vlong_filter_ok(taps.F) ? 16 : 32) || (R % VEC) != 0 || (lds % VEC) != 0 || (ldd % VEC) != 0 ||
         !a_al16(src) || !a_al16(dst))
         return false;
+    if (vlong_filter_ok(taps.F)) {
+        *err = vl_axis<T>(st, taps, fw, src, lds, dst, ldd, R, C, cu_count);
+        return true;
+    }
     bool ok = false;
     WL_DISPATCH_FL(taps.F, {
         if (fw) *err = launch_axis<T, FF, 1>(st, taps, src, lds, 0, dst, ldd, 0, R, C, 1, cu_count);

@@ -63,6 +63,18 @@ hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64
 
 // Long filters (12, 14, 16, 18, 20, 24 taps): one level of contiguous lines / of the strided axis of a matrix (wl_axis.hip).
 bool long_filter_ok(int F);
+bool long_shape2d_ok(int F, int64_t n0, int64_t n1);
+// ---- odd-length / up to 64-tap filters (Battle 23, 41, 59): wl_vlong.hip ----
+bool vlong_filter_ok(int F);
+template <typename T>
+hipError_t vl_lines_fwd(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls, T *ddst,
+                        int64_t d_ls, int64_t n, int64_t nlines);
+template <typename T>
+hipError_t vl_lines_inv(hipStream_t st, const Taps<T> &taps, const T *ssrc, int64_t s_ls, const T *dsrc, int64_t d_ls, T *dst,
+                        int64_t o_ls, int64_t n, int64_t nlines);
+template <typename T>
+hipError_t vl_axis(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t lds, T *dst, int64_t ldd, int64_t R, int64_t C,
+                   int cu_count);
 template <typename T>
 bool long_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls,
                           T *ddst, int64_t d_ls, int64_t n, int64_t nlines, int cu_count, hipError_t *err);

@@ -814,18 +814,36 @@ __device__ __forceinline__ void tail_pair(const T *p, int stride, int k, int n, 
 #pragma unroll
         for (int m = FC - 2; m >= 0; --m) d = d + tp.g[m] * xv[FC - 1 - m];
     } else {
+        // run-time length: taps in blocks of 8 with the block's LDS reads issued before its arithmetic (one dependent
+        // read per tap made a 59-tap line cost ~100 cycles per tap)
         const int F = tp.F;
         int i = wrap_idx(2 * k, n);
         s = tp.h[0] * p[i * stride];
-        for (int m = 1; m < F; ++m) {
-            if (++i >= n) i -= n;
-            s = s + tp.h[m] * p[i * stride];
+        for (int m0 = 1; m0 < F; m0 += 8) {
+            T xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 + e < F) {
+                    if (++i >= n) i -= n;
+                    xv[e] = p[i * stride];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 + e < F) s = s + tp.h[m0 + e] * xv[e];
         }
         i = wrap_idx(2 * k + 1 - (F - 1), n);
         d = tp.g[F - 1] * p[i * stride];
-        for (int m = F - 2; m >= 0; --m) {
-            if (++i >= n) i -= n;
-            d = d + tp.g[m] * p[i * stride];
+        for (int m0 = F - 2; m0 >= 0; m0 -= 8) {
+            T xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 - e >= 0) {
+                    if (++i >= n) i -= n;
+                    xv[e] = p[i * stride];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 - e >= 0) d = d + tp.g[m0 - e] * xv[e];
         }
     }
 }
@@ -1261,7 +1279,10 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         const int64_t line_cap = (lines && nlines >= 32 && fastF) ? env_int("WL_TAIL_LINES_CAP", 512) : tail_cap<T>();
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
-            if (blk <= (two_d ? (int64_t)tail_cap<T>() : line_cap) && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
+            // filters beyond 24 taps: one workgroup is slow at 2 F multiply-adds per sample -- the chip-wide line / axis
+            // kernels of wl_vlong.hip take every level down to 16 samples per dimension first
+            const int64_t vl_cap = (vlong_filter_ok(F) && env_int("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40);
+            if (blk <= (two_d ? (int64_t)tail_cap<T>() : line_cap) && blk <= vl_cap && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
                 // power-of-two blocks / lines of <= 16 KiB: the latency-optimised tail (wl_tail.hip)
                 const bool t2 = env_int("WL_TAIL2", 1) && tail2_ok<T>(F, two_d ? 2 : 1, n[0], two_d ? n[1] : 1, L - l + 1);
                 if (two_d) {
@@ -1373,7 +1394,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 const int64_t sls = last ? ldy : ll_st.s[1];
                 done = long_lines_fwd_level<T>(st, taps, cur, cur_st.s[1], sd, sls, y + h0, ldy, n[0], nlines, cu_count, &e);
                 WL_TRY(e);
-            } else if (two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 32) == 0 && (ldy % VEC) == 0 &&
+            } else if (two_d && long_shape2d_ok(F, n[0], n[1]) && (ldy % VEC) == 0 &&
                        (cur_st.s[1] % VEC) == 0 && aligned16(cur) && aligned16(y) && aligned16(llbuf)) {
                 // rows (dim 2) into T0 = [s-columns | d-columns], then the columns of T0 as lines with the LL quadrant routed on
                 if (!w.T0) return WL_RETRY_GEN;
@@ -1390,7 +1411,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     if (!ok) return WL_EINVAL_ARG;      // (eligibility is identical for the three launches)
                 }
             }
-            if (done && !dominant) dominant = "k_long_lines";
+            if (done && !dominant) dominant = vlong_filter_ok(F) ? "k_vl_lines" : "k_long_lines";
         }
         // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
         if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {

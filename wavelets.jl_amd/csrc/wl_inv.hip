@@ -289,19 +289,47 @@ __device__ __forceinline__ T tail_inv_one(const T *sp, int ss, const T *dp, int 
                 first = false;
             }
     } else {
-        for (int m = F - 1; m >= 0; --m)
-            if (((o - m) & 1) == 0) {
-                T term = tp.h[m] * sp[iw((o - m) / 2, nx) * ss];
-                S = first ? term : (S + term);
-                first = false;
+        // run-time length: every second tap, the coefficient index going up by one per term (one periodic reduction for the
+        // start, a conditional wrap afterwards), blocks of 8 terms with their LDS reads issued before the arithmetic
+        {
+            const int mt = (((F - 1 - o) & 1) == 0) ? F - 1 : F - 2;       // largest tap with (o - m) even
+            if (mt >= 0) {
+                int k = iw((o - mt) / 2, nx);
+                S = tp.h[mt] * sp[k * ss];
+                for (int m0 = mt - 2; m0 >= 0; m0 -= 16) {
+                    T xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 - 2 * e >= 0) {
+                            if (++k >= nx) k = 0;
+                            xv[e] = sp[k * ss];
+                        }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 - 2 * e >= 0) S = S + tp.h[m0 - 2 * e] * xv[e];
+                }
             }
-        first = true;
-        for (int m = 0; m < F; ++m)
-            if (((o + m - 1) & 1) == 0) {
-                T term = tp.g[m] * dp[iw((o + m - 1) / 2, nx) * sd];
-                D = first ? term : (D + term);
-                first = false;
+        }
+        {
+            const int mb = (o & 1) ? 0 : 1;                                 // smallest tap with (o + m - 1) even
+            if (mb < F) {
+                int k = iw((o + mb - 1) / 2, nx);
+                D = tp.g[mb] * dp[k * sd];
+                for (int m0 = mb + 2; m0 < F; m0 += 16) {
+                    T xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 + 2 * e < F) {
+                            if (++k >= nx) k = 0;
+                            xv[e] = dp[k * sd];
+                        }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 + 2 * e < F) D = D + tp.g[m0 + 2 * e] * xv[e];
+                }
             }
+        }
+        (void)first;
     }
     return S + D;
 }
@@ -810,7 +838,8 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             const int64_t blk = two_d ? nq[0] * nq[1] : nq[0];
             const bool fits = two_d ? (((nq[0] | 1) * nq[1]) <= inv_tail_cap<T>() + 256 && nq[1] <= 256)
                                     : (2 * nq[0] <= 2 * (int64_t)inv_tail_cap<T>());
-            if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 4096) && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
+            const int64_t vl_cap = (vlong_filter_ok(taps.F) && i_env("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40);
+            if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 4096) && blk <= vl_cap && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
         }
         if (l_lo <= L) {
             int64_t nq[3];
@@ -932,7 +961,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 const int64_t sls = llsrc ? llsrc_st.s[1] : ldx;
                 done = long_lines_inv_level<T>(st, taps, ss, sls, x + h0, ldx, res, res_st.s[1], n[0], nlines, cu_count, &e);
                 WL_TRYI(e);
-            } else if (two_d && n[0] >= 512 && (n[0] % 8) == 0 && n[1] >= 32 && (n[1] % 32) == 0 && (ldx % VEC) == 0 &&
+            } else if (two_d && long_shape2d_ok(F, n[0], n[1]) && (ldx % VEC) == 0 &&
                        (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) && (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % VEC) == 0))) {
                 // columns (dim 1) into T0, the approximation quadrant from the deeper reconstruction; then rows (dim 2)
                 const T *ss = llsrc ? llsrc : x;
@@ -949,7 +978,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     if (!ok) return WL_EINVAL_ARG;
                 }
             }
-            if (done) dominant = "k_long_lines";
+            if (done) dominant = vlong_filter_ok(F) ? "k_vl_lines" : "k_long_lines";
         }
         if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
             hipError_t e3 = hipSuccess;

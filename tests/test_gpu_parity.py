@@ -540,6 +540,40 @@ def test_lifting_register_tail(gpu, W, oracle, dtype):
     assert W.last_kernel() == "k_tail_lift" and np.array_equal(y0, oracle.dwt_lifting(xs, sch, 11))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_register_tail_2d(gpu, W, oracle, dtype):
+    """k_tail_lift2d_reg (every remaining level of a power-of-two block <= 64 x 64 in one wave: a lane holds a whole row /
+    column in registers, compile-time wrap and in-bounds / boundary summation forms): every block size from 2 to 64, every
+    depth, the three scheme shapes, forward and inverse, in place, as the end of a larger transform -- bit for bit against
+    the oracle and against the LDS workgroup tail it replaces."""
+    for sname in ("cdf97", "db2", "haar"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        n = 2
+        while n <= 64:
+            x = rng_array((n, n), dtype, n + len(sname))
+            Lmax = W.maxtransformlevels(n)
+            for L in range(1, Lmax + 1):
+                ye = oracle.dwt_lifting(x, sch, L)
+                assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L)
+                t = dev(W, x)
+                W.dwt_(t, sch, L)
+                assert np.array_equal(host(W, t), ye), (sname, n, L, "in place")
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "inv")
+                t = dev(W, ye)
+                W.idwt_(t, sch, L)
+                assert np.array_equal(host(W, t), xe), (sname, n, L, "inv in place")
+                with W.options(WL_LIFT_REGTAIL2D=0):
+                    assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "lds tail")
+                    assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "lds tail inv")
+            n *= 2
+        for n, L in ((512, 9), (256, 6), (1024, 5)):
+            x = rng_array((n, n), dtype, n)
+            ye = oracle.dwt_lifting(x, sch, L)
+            assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L)
+            assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), oracle.dwt_lifting(ye, sch, L, fw=False)), (sname, n, L, "inv")
+
+
 def test_lifting_equals_filter_on_gpu(gpu, W):
     """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
     for nd in (1, 2, 3):

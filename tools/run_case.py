@@ -6,6 +6,9 @@ import wavelets_jl_amd as W
 
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+for kv in sys.argv[3:]:                       # per-context options: KEY:VALUE
+    k, v = kv.split(":")
+    W.set_option(k, int(v))
 g = torch.Generator(device="cpu").manual_seed(7)
 db4 = W.wavelet(W.WT.db4)
 if case == "idwt2d":

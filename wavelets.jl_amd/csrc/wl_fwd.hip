@@ -1302,7 +1302,9 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             cur_st.s[0] == 1 && aligned16(cur) && aligned16(y) &&
             (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0))) {
             int NL = L - l + 1;
-            const int nlmax = env_int("WL_NLMAX", 4);
+            // big stages are bandwidth-bound: 4 levels keep the halo (F-2)(2^NL - 1) small; small stages are launch-latency
+            // bound: up to 6 levels per launch saves whole launches (1-D db2 2^20 f64: 23.8 -> 17.3 us)
+            const int nlmax = env_int("WL_NLMAX", (n[0] * nlines >= ((int64_t)1 << 22)) ? 4 : 6);
             if (NL > nlmax) NL = nlmax;
             while (NL > 1 && (n[0] % ((int64_t)(1 << NL) * 4 * VEC)) != 0) --NL;   // alignment of every level's stores
             const bool lastm = (l + NL - 1 == L);

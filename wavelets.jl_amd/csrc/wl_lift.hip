@@ -890,6 +890,173 @@ __global__ void __launch_bounds__(1024) k_tail_lift2d(LiftTail2DArgs<T> a, LiftS
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// Register tail for 2-D lifting: every remaining level of a power-of-two block of <= 64 x 64 in ONE WAVE.  A lane owns a
+// whole line (a row in the dim-2 pass, a column in the dim-1 pass) and keeps it in registers as s[H], d[H]; every step of
+// the scheme is then straight-line code with compile-time indices -- the periodic wrap and the reference's two summation
+// forms (in-bounds: x + (c1 a + c2 b); boundary: (x + c1 a) + c2 b, transforms_lifting.jl:366-483) are decided per element
+// at compile time.  The block lives in LDS between the passes (leading dimension M | 1: conflict-free rows and columns);
+// a single wave needs no barrier, only the LDS wait.  64 x 64 cdf9/7, 6 levels: ~10 us (LDS workgroup tail: 53 us).
+template <typename T>
+struct LiftTailRegArgs {
+    const T *src; int64_t lds;
+    T *y; int64_t ldy;
+    int m0, nlev;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID, int H>
+__device__ __forceinline__ void reg_line_steps(T (&s)[H], T (&d)[H], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF])
+{
+    typedef Shape<ID> SH;
+#pragma unroll
+    for (int k = 0; k < SH::NS; ++k) {
+        const int upd = SH::S[k].upd, nc = SH::S[k].nc, sh = SH::S[k].sh;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int j0 = j - sh;
+            const bool inb = (j0 >= 0) && (j0 + nc - 1 <= H - 1);
+            T x = upd ? d[j] : s[j];
+            if (inb) {
+                T acc = c[k][0] * (upd ? s[((j0 % H) + H) % H] : d[((j0 % H) + H) % H]);
+                if (nc > 1) acc = acc + c[k][1] * (upd ? s[(j0 + 1) % H] : d[(j0 + 1) % H]);
+                if (nc > 2) acc = acc + c[k][2] * (upd ? s[(j0 + 2) % H] : d[(j0 + 2) % H]);
+                x = x + acc;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                    if (kk < nc) {
+                        const int i = (((j0 + kk) % H) + H) % H;
+                        x = x + c[k][kk] * (upd ? s[i] : d[i]);
+                    }
+            }
+            if (upd) d[j] = x; else s[j] = x;
+        }
+    }
+}
+__device__ __forceinline__ void reg_tail_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one forward level of the M x M block in P (split -> steps -> normalize per line; rows pass, then columns pass), details
+// (and the approximation, when this is the last level) copied out with coalesced stores
+template <typename T, int ID, int M>
+__device__ __forceinline__ void reg_tail_fwd_level(T *P, const LiftTailRegArgs<T> &a, bool last, int lane)
+{
+    constexpr int H = M / 2, ld = 64 | 1;
+    if (lane < M) {
+        T s[H], d[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = P[lane + (2 * k) * ld]; d[k] = P[lane + (2 * k + 1) * ld]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { P[lane + k * ld] = s[k] * a.norm1; P[lane + (H + k) * ld] = d[k] * a.norm2; }
+    }
+    reg_tail_sync();
+    if (lane < M) {
+        T s[H], d[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = P[2 * k + lane * ld]; d[k] = P[2 * k + 1 + lane * ld]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { P[k + lane * ld] = s[k] * a.norm1; P[H + k + lane * ld] = d[k] * a.norm2; }
+    }
+    reg_tail_sync();
+#pragma unroll
+    for (int t = 0; t < (M * M + 63) / 64; ++t) {
+        const int idx = lane + 64 * t, i = idx % M, j = idx / M;
+        if (idx < M * M && (last || i >= H || j >= H)) a.y[i + (int64_t)j * a.ldy] = P[i + j * ld];
+    }
+}
+template <typename T, int ID, int M>
+__device__ __forceinline__ void reg_tail_fwd_from(T *P, const LiftTailRegArgs<T> &a, int m0, int nlev, int lane)
+{
+    if (m0 == M) {
+        reg_tail_fwd_level<T, ID, M>(P, a, nlev == 1, lane);
+        if constexpr (M >= 4) {
+            if (nlev > 1) reg_tail_fwd_from<T, ID, M / 2>(P, a, M / 2, nlev - 1, lane);
+        }
+    } else {
+        if constexpr (M >= 4) reg_tail_fwd_from<T, ID, M / 2>(P, a, m0, nlev, lane);
+    }
+}
+// one inverse level with output M x M in P (normalize -> steps -> merge per line; columns pass, then rows pass)
+template <typename T, int ID, int M>
+__device__ __forceinline__ void reg_tail_inv_level(T *P, const LiftTailRegArgs<T> &a, int lane)
+{
+    constexpr int H = M / 2, ld = 64 | 1;
+    if (lane < M) {
+        T s[H], d[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * P[k + lane * ld]; d[k] = a.norm2 * P[H + k + lane * ld]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { P[2 * k + lane * ld] = s[k]; P[2 * k + 1 + lane * ld] = d[k]; }
+    }
+    reg_tail_sync();
+    if (lane < M) {
+        T s[H], d[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * P[lane + k * ld]; d[k] = a.norm2 * P[lane + (H + k) * ld]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { P[lane + (2 * k) * ld] = s[k]; P[lane + (2 * k + 1) * ld] = d[k]; }
+    }
+    reg_tail_sync();
+}
+// levels with outputs m0 >> (nlev-1), ..., m0 (smallest first)
+template <typename T, int ID, int M>
+__device__ __forceinline__ void reg_tail_inv_upto(T *P, const LiftTailRegArgs<T> &a, int m0, int nlev, int lane)
+{
+    // sizes handled by this instance: M, if m0 >> (nlev-1) <= M <= m0
+    if constexpr (M >= 4) reg_tail_inv_upto<T, ID, M / 2>(P, a, m0, nlev, lane);
+    if (M <= m0 && M >= (m0 >> (nlev - 1))) reg_tail_inv_level<T, ID, M>(P, a, lane);
+}
+
+template <typename T, int ID, int FW>
+__global__ void __launch_bounds__(64) k_tail_lift2d_reg(LiftTailRegArgs<T> a)
+{
+    constexpr int ld = 64 | 1;
+    __shared__ T P[ld * 64];
+    const int lane = threadIdx.x;
+    const int m0 = a.m0, lg = 31 - __clz(m0);
+    for (int idx = lane; idx < m0 * m0; idx += 64) {
+        const int i = idx & (m0 - 1), j = idx >> lg;
+        P[i + j * ld] = a.src[i + (int64_t)j * a.lds];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (FW) {
+        reg_tail_fwd_from<T, ID, 64>(P, a, m0, a.nlev, lane);
+    } else {
+        reg_tail_inv_upto<T, ID, 64>(P, a, m0, a.nlev, lane);
+        for (int idx = lane; idx < m0 * m0; idx += 64) {
+            const int i = idx & (m0 - 1), j = idx >> lg;
+            a.y[i + (int64_t)j * a.ldy] = P[i + j * ld];
+        }
+    }
+}
+template <typename T>
+static bool tail_lift2d_reg_ok(int id, int n0) { return id >= 0 && id <= 5 && n0 >= 2 && n0 <= 64 && (n0 & (n0 - 1)) == 0; }
+template <typename T, int FW>
+static hipError_t launch_tail_lift2d_reg(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy,
+                                         int n0, int nlev)
+{
+    LiftTailRegArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.m0 = n0; a.nlev = nlev;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    if (FW) {
+        if (id == 0) hipLaunchKernelGGL((k_tail_lift2d_reg<T, 0, 1>), dim3(1), dim3(64), 0, st, a);
+        else if (id == 2) hipLaunchKernelGGL((k_tail_lift2d_reg<T, 2, 1>), dim3(1), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_tail_lift2d_reg<T, 4, 1>), dim3(1), dim3(64), 0, st, a);
+    } else {
+        if (id == 1) hipLaunchKernelGGL((k_tail_lift2d_reg<T, 1, 0>), dim3(1), dim3(64), 0, st, a);
+        else if (id == 3) hipLaunchKernelGGL((k_tail_lift2d_reg<T, 3, 0>), dim3(1), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_tail_lift2d_reg<T, 5, 0>), dim3(1), dim3(64), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
 template <typename T, int FW>
 static hipError_t launch_tail_lift2d(hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, int n0, int nlev)
 {
@@ -1299,10 +1466,14 @@ __global__ void __launch_bounds__(64) k_lift_axis_stream(LiftAxisArgs<T> a)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
     const int64_t tau0 = p0 - VM;                       // first raw pair of this chunk (may be negative: wraps)
+    // periodic pair index: the arguments stay within a few ring lengths of [0, half), so a subtraction loop (zero or one trip
+    // unless the level is tiny) replaces the emulated 64-bit division that dominated the scalar instruction stream
     auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
-        if (i < 0) { i %= half; if (i < 0) i += half; }
-        else if (i >= half) i %= half;
-        return i;
+        int j = (int)i;
+        const int hh = (int)half;
+        while (j < 0) j += hh;
+        while (j >= hh) j -= hh;
+        return (int64_t)j;
     };
     // pair index tau lives in ring slot (tau - tau0) mod R: static once the loop is unrolled by R
     auto load_pair = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
@@ -1387,12 +1558,15 @@ struct Lift2DArgs {
     T norm1, norm2;
 };
 
-template <typename T, int ID>
+// R: ring slots = steps per unrolled iteration; loads run PF = R - DL + AMIN - 1 column pairs ahead.  8 for the bandwidth-bound
+// levels (registers -> occupancy); 16 for the small, latency-bound ones, where a wave is alone on its SIMD and a short
+// prefetch distance leaves a memory latency exposed in every step (128^2 .. 1024^2: ~20 us per level with R = 8).
+template <typename T, int ID, int R = 8>
 __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
-    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 2;   // even margin: lane pairs store together
+    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 2;   // even margin: lane pairs store together
     constexpr int VR = (64 - 2 * ML) * RPL;
     static_assert(PF >= 2, "ring too small for this scheme");
     const int lane = threadIdx.x;
@@ -1414,10 +1588,14 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
     const int64_t tau0 = p0 - VM;
+    // periodic pair index: the arguments stay within a few ring lengths of [0, h1), so a subtraction loop (zero or one trip
+    // unless the level is tiny) replaces the emulated 64-bit division that dominated the scalar instruction stream
     auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
-        if (i < 0) { i %= h1; if (i < 0) i += h1; }
-        else if (i >= h1) i %= h1;
-        return i;
+        int j = (int)i;
+        const int hh = (int)h1;
+        while (j < 0) j += hh;
+        while (j >= hh) j -= hh;
+        return (int64_t)j;
     };
     auto load_pair = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
         const int64_t iw = wrapi(tau);
@@ -1507,12 +1685,12 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 // The inverse: per step the raw coefficient column pair (left-half column p: approximation rows + detail rows, and
 // right-half column p) is loaded four steps ahead, both columns are reconstructed along dim 1 across the lanes
 // (normalize -> steps -> merge), and the results enter the dim-2 inverse cascade as its (s, d) pair.
-template <typename T, int ID>
+template <typename T, int ID, int R = 8>
 __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
-    constexpr int RPL = 4, R = 8, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = 4, ML = 1;
+    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - 4, ML = 1;
     constexpr int VR = (64 - 2 * ML) * RPL;
     static_assert(R - DL + CS::TAB.AMIN - 1 >= 1, "ring too small for this scheme");
     const int lane = threadIdx.x;
@@ -1543,10 +1721,14 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) { rs[i][q] = (T)0; rd[i][q] = (T)0; }
     const int64_t tau0 = p0 - VM;
+    // periodic pair index: the arguments stay within a few ring lengths of [0, h1), so a subtraction loop (zero or one trip
+    // unless the level is tiny) replaces the emulated 64-bit division that dominated the scalar instruction stream
     auto wrapi = [&](int64_t i) __attribute__((always_inline)) {
-        if (i < 0) { i %= h1; if (i < 0) i += h1; }
-        else if (i >= h1) i %= h1;
-        return i;
+        int j = (int)i;
+        const int hh = (int)h1;
+        while (j < 0) j += hh;
+        while (j >= hh) j -= hh;
+        return (int64_t)j;
     };
     auto load_raw = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
         const int64_t iw = wrapi(tau);
@@ -1626,7 +1808,9 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    hipLaunchKernelGGL((k_lift2d_inv<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    const bool latency_bound = (int64_t)a.nstrips * a.nchunks * nbatch <= (int64_t)cu_count * 8 && opt("WL_LIFT_R16", 0) != 0;
+    if (latency_bound) hipLaunchKernelGGL((k_lift2d_inv<T, ID, 16>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_lift2d_inv<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1642,7 +1826,9 @@ static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    hipLaunchKernelGGL((k_lift2d_fwd<T, ID>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    const bool latency_bound = (int64_t)a.nstrips * a.nchunks * nbatch <= (int64_t)cu_count * 8 && opt("WL_LIFT_R16", 0) != 0;
+    if (latency_bound) hipLaunchKernelGGL((k_lift2d_fwd<T, ID, 16>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_lift2d_fwd<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1872,8 +2058,11 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             T *llbuf = pp ? w.B : w.A;
             T *lld = last ? y : llbuf;
             const int64_t ldd = last ? ldy : h;
-            if (n <= 64 && l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {        // every remaining level inside one workgroup
-                WL_E((launch_tail_lift2d<T, 1>(st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
+            if (n <= 64 && l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {        // every remaining level inside one workgroup / one wave
+                if ((id == 0 || id == 2 || id == 4) && tail_lift2d_reg_ok<T>(id, (int)n) && l_env("WL_LIFT_REGTAIL2D", 1) != 0)
+                    WL_E((launch_tail_lift2d_reg<T, 1>(id, st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
+                else
+                    WL_E((launch_tail_lift2d<T, 1>(st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
                 any_fast = true;
                 break;
             }
@@ -1938,7 +2127,10 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 const int64_t n = n0 >> (l_lo - 1);
                 T *out = (l_lo == 1) ? y : (pp ? w.B : w.A);
                 const int64_t ldo = (l_lo == 1) ? ldy : n;
-                WL_E((launch_tail_lift2d<T, 0>(st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
+                if ((id == 1 || id == 3 || id == 5) && tail_lift2d_reg_ok<T>(id, (int)n) && l_env("WL_LIFT_REGTAIL2D", 1) != 0)
+                    WL_E((launch_tail_lift2d_reg<T, 0>(id, st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
+                else
+                    WL_E((launch_tail_lift2d<T, 0>(st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
                 any_fast = true;
                 llsrc = out; ll_ls = ldo; pp ^= 1;
                 l_start = l_lo - 1;

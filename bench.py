@@ -355,6 +355,11 @@ def secondary_leg(W, device):
     x2 = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t()
     y2 = W.similar(x2)
     extra.append(("2-D idwt db4 filter 8192x8192 f32", 13, x2, lambda: W.idwt_oop_(y2, x2, db4, 13), 2 * x2.numel() * 4))
+    cdf = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    extra.append(("2-D dwt cdf9/7 lifting 8192x8192 f32", 13, x2, lambda: W.dwt_oop_(y2, x2, cdf, 13), 2 * x2.numel() * 4))
+    extra.append(("2-D idwt cdf9/7 lifting 8192x8192 f32", 13, x2, lambda: W.idwt_oop_(y2, x2, cdf, 13), 2 * x2.numel() * 4))
+    batt6 = W.wavelet(W.WT.batt6)
+    extra.append(("2-D dwt batt6 (59 taps) filter 8192x8192 f32", 13, x2, lambda: W.dwt_oop_(y2, x2, batt6, 13), 2 * x2.numel() * 4))
     x3 = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0)
     y3 = W.similar(x3)
     extra.append(("3-D dwt db4 filter 512^3 f32", 9, x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4))

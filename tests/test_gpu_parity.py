@@ -862,8 +862,8 @@ def test_full_size_elementwise_vs_oracle(gpu, W, oracle):
             assert np.array_equal(xr, xe), ("inverse", L, int((xr != xe).sum()))
     # the fast filter-bank path keeps two approximation buffers of N/4 elements: 128 MiB for C3 (round 1: 1 GiB)
     assert W.workspace_held() <= 129 * 2 ** 20, W.workspace_held()
-    yb = W.dwt(x, W.wavelet(W.WT.batt2), 2)                # odd-length filter: generic family, grows to the full workspace
-    assert W.last_kernel().startswith("k_generic") and W.workspace_held() > 3 * xh.nbytes
+    yb = W.dwt(x, W.wavelet(W.WT.batt2), 2)                # 23-tap filter: two-pass family, grows to the full workspace
+    assert W.last_kernel() == "k_vl_lines" and W.workspace_held() > 3 * xh.nbytes
     assert np.array_equal(W.to_host(yb), oracle.dwt2d_filter_mt(xh, W.wavelet(W.WT.batt2).qmf, 2))
     del x, yb
     W.destroy_contexts()

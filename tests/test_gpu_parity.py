@@ -147,7 +147,7 @@ def test_fused_inverse_2d_kernel(gpu, W, oracle, dtype, ppl):
                 y = oracle.dwt_filter(x, wt.qmf, L)
                 xr = host(W, W.idwt(dev(W, y), wt, L))
                 if len(wt.qmf) <= 8 or shape[1] % 16 == 0:      # (blocks of <= 4096 elements: LDS tail kernel instead)
-                    assert W.last_kernel() == ("k_inv2d_stream" if shape[0] * shape[1] > 4096 else "k_tail_inv"), (shape, L)
+                    assert W.last_kernel() in (("k_inv2d_stream",) if shape[0] * shape[1] > 4096 else ("k_tail_inv", "k_tail2_inv")), (shape, L)
                 assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (shape, fname, L)
 
 
@@ -279,6 +279,53 @@ def test_tile_kernel(gpu, W, oracle, nl3max):
                 assert W.last_kernel() == "k_fwd2d_tile", (shape, L, W.last_kernel())
                 ye = oracle.dwt_filter(x, wt.qmf, L)
                 assert np.array_equal(y, ye), (shape, fname, L, nl3max, int((y != ye).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tail2_inverse_kernel(gpu, W, oracle, dtype):
+    """k_tail2_inv (the deepest levels of a reconstruction whose output is a power-of-two block / line <= 16 KiB, one launch,
+    mask wrap, in-place quadrant reuse): every supported filter length, every depth down to 2 x 2, square and non-square
+    blocks, 1-D lines, batched lines, forced thread counts, as the start of a larger reconstruction -- bit for bit against
+    the oracle and against the general inverse tail kernel."""
+    cap = 4096 if dtype == np.float32 else 2048
+    for threads in (0, 64, 256):
+        W.set_option("WL_TAIL2_THREADS", threads)
+        for shape in ((64, 64), (32, 32), (64, 32), (16, 64), (8, 8), (4, 4), (2, 2), (128, 16), (2, 64), (64, 2)):
+            if shape[0] * shape[1] > cap:
+                continue
+            y = rng_array(shape, dtype, sum(shape) + threads)
+            Lmax = W.maxtransformlevels(y)
+            for fname in ("db4", "haar", "db2", "db3", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                for L in sorted({1, 2, Lmax - 1, Lmax} - {0}):
+                    if L > Lmax:
+                        continue
+                    xr = host(W, W.idwt(dev(W, y), wt, L))
+                    assert W.last_kernel() == "k_tail2_inv", (shape, L, W.last_kernel())
+                    assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (shape, fname, L, threads)
+        for n in (2, 4, 8, 64, 512, 2048, 4096):
+            if n > cap:
+                continue
+            y = rng_array((n,), dtype, n + threads)
+            Lmax = W.maxtransformlevels(n)
+            for fname in ("db4", "haar", "db3", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                for L in sorted({1, Lmax // 2, Lmax} - {0}):
+                    xr = host(W, W.idwt(dev(W, y), wt, L))
+                    assert W.last_kernel() == "k_tail2_inv", (n, L, W.last_kernel())
+                    assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (n, fname, L, threads)
+        ym = rng_array((256, 37), dtype, 5)                      # batched lines: one workgroup per line
+        wt = W.wavelet(W.WT.db4)
+        assert np.array_equal(host(W, W.idwtc(dev(W, ym), wt, 8)), oracle.dwtc_filter(ym, wt.qmf, 8, fw=False))
+    W.set_option("WL_TAIL2_THREADS", 0)
+    for shape, L in (((512, 512), 9), ((1024, 256), 8), ((1 << 16,), 16)):          # the tail feeds the streaming levels
+        y = rng_array(shape, dtype, 3)
+        for fname in ("db4", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            xe = oracle.dwt_filter(y, wt.qmf, L, fw=False)
+            assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname)
+            with W.options(WL_TAIL2=0):
+                assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname, "general tail")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

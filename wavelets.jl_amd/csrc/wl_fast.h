@@ -56,6 +56,11 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, co
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
 template <typename T>
+bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item);
+template <typename T>
+hipError_t launch_tail2_inv(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, int64_t x_item, T *out, int64_t ldo,
+                            int64_t out_item, int nitems, int n0, int n1, int nt, int nlev);
+template <typename T>
 bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev);
 template <typename T>
 hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,

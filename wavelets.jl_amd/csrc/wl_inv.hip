@@ -847,11 +847,18 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             const bool to_y = (l_lo == 1);
             T *res = to_y ? y : (pp ? w.B : w.A);
             Strides3 res_st = to_y ? b.full : dense_strides(nq);
-            if (two_d)
-                WL_TRYI(launch_tail_inv<T>(st, taps, x, b.full.s[1], 0, res, res_st.s[1], 0, 1, (int)nq[0], (int)nq[1], 2, L - l_lo + 1));
-            else
-                WL_TRYI(launch_tail_inv<T>(st, taps, x, 0, b.full.s[1], res, 0, res_st.s[1], (int)nlines, (int)nq[0], 1, 1, L - l_lo + 1));
-            dominant = "k_tail_inv";
+            // power-of-two blocks / lines of <= 16 KiB with a <= 10-tap filter: the latency-optimised tail (wl_tail.hip)
+            const bool t2 = i_env("WL_TAIL2", 1) != 0 &&
+                            (two_d ? tail2_inv_ok<T>(F, 2, nq[0], nq[1], L - l_lo + 1, res, 0)
+                                   : tail2_inv_ok<T>(F, 1, nq[0], 1, L - l_lo + 1, res, res_st.s[1]));
+            if (two_d) {
+                if (t2) WL_TRYI(launch_tail2_inv<T>(st, taps, x, b.full.s[1], 0, res, res_st.s[1], 0, 1, (int)nq[0], (int)nq[1], 2, L - l_lo + 1));
+                else WL_TRYI(launch_tail_inv<T>(st, taps, x, b.full.s[1], 0, res, res_st.s[1], 0, 1, (int)nq[0], (int)nq[1], 2, L - l_lo + 1));
+            } else {
+                if (t2) WL_TRYI(launch_tail2_inv<T>(st, taps, x, 0, b.full.s[1], res, 0, res_st.s[1], (int)nlines, (int)nq[0], 1, 1, L - l_lo + 1));
+                else WL_TRYI(launch_tail_inv<T>(st, taps, x, 0, b.full.s[1], res, 0, res_st.s[1], (int)nlines, (int)nq[0], 1, 1, L - l_lo + 1));
+            }
+            dominant = t2 ? "k_tail2_inv" : "k_tail_inv";
             llsrc = res; llsrc_st = dense_strides(nq); pp ^= 1;
             l_start = l_lo - 1;
         }

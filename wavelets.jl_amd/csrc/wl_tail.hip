@@ -192,6 +192,194 @@ hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The inverse: the deepest `nlev` levels of a reconstruction whose last output here is a power-of-two block n0 x n1
+// (<= 4096 f32 elements) / a line of n0 samples, in one launch.  The coefficient corner is staged to LDS once; a 2-D level
+// is the dim-1 reconstruction A -> B (lanes along the output pairs of a column, 8-byte stores) followed by the dim-2
+// reconstruction B -> A (lanes along the rows), in place over the quadrants it has just consumed (reference
+// transforms_filter.jl:173-186: columns first, then rows).  Same masks / compile-time taps as k_tail2_fwd.
+template <typename T, int F>
+struct Tail2InvArgs {
+    const T *x; int64_t ldx; int64_t x_item;
+    T *out; int64_t ldo; int64_t out_item;
+    int lg0, lg1;                   // OUTPUT extents 2^lg0 x 2^lg1 of the last level done here (lg1 = 0 with nt = 1)
+    int nt, nlev;
+    TapsF<T, F> tp;
+};
+
+// (x[2p], x[2p+1]) from sw[q] = s[p - SH + q], dw[q] = d[p + q], q = 0..SH (wl_internal.h closed form, even F)
+template <typename T, int F>
+__device__ __forceinline__ void window_inv(const T (&sw)[(F - 2) / 2 + 1], const T (&dw)[(F - 2) / 2 + 1], const TapsF<T, F> &tp, T &xe, T &xo)
+{
+    constexpr int SH = (F - 2) / 2;
+    T Se = tp.h[F - 2] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
+    T De = tp.g[1] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    xe = Se + De;
+    T So = tp.h[F - 1] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
+    T Do = tp.g[0] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    xo = So + Do;
+}
+
+template <typename T, int F>
+__global__ void __launch_bounds__(512) k_tail2_inv(Tail2InvArgs<T, F> a)
+{
+    typedef typename VecOf<T, 2>::type T2;
+    constexpr int SH = (F - 2) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const bool multi = nthr > 64;
+    const int n0 = 1 << a.lg0, n1 = 1 << a.lg1;
+    const int ld = (n1 > 1) ? (n0 + 2) : n0;
+    T *A = reinterpret_cast<T *>(smem_raw);
+    T *B = A + (size_t)ld * n1 + 8;
+    const T *x = a.x + (int64_t)blockIdx.x * a.x_item;
+    T *out = a.out + (int64_t)blockIdx.x * a.out_item;
+    {
+        constexpr int VW = 16 / sizeof(T);
+        const int total = n0 * n1;
+        const bool vec_ok = (n0 % VW) == 0 && (a.ldx % VW) == 0 && (a.x_item % VW) == 0 && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+        if (vec_ok) {
+            const int totalv = total / VW, lgv = a.lg0 - (VW == 4 ? 2 : 1);
+            for (int idx = tid; idx < totalv; idx += 4 * nthr) {
+                T v[4][VW];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int id = idx + r * nthr;
+                    if (id < totalv) vload<T, VW>(x + (id & ((1 << lgv) - 1)) * VW + (int64_t)(id >> lgv) * a.ldx, v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int id = idx + r * nthr;
+                    if (id < totalv) {
+                        T *dst = A + (id & ((1 << lgv) - 1)) * VW + (id >> lgv) * ld;
+#pragma unroll
+                        for (int e = 0; e < VW; e += 2) *reinterpret_cast<T2 *>(dst + e) = T2{v[r][e], v[r][e + 1]};
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += nthr) A[(idx & (n0 - 1)) + (idx >> a.lg0) * ld] = x[(idx & (n0 - 1)) + (int64_t)(idx >> a.lg0) * a.ldx];
+        }
+    }
+    if (multi) lds_barrier_vm(); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    if (a.nt == 2) {
+        for (int t = 0; t < a.nlev; ++t) {
+            const bool last = (t == a.nlev - 1);
+            const int lgo0 = a.lg0 - (a.nlev - 1 - t), lgo1 = a.lg1 - (a.nlev - 1 - t);
+            const int o0 = 1 << lgo0, o1 = 1 << lgo1, h0 = o0 >> 1, h1 = o1 >> 1;
+            // ---- dim-1 reconstruction: A -> B; lanes along the output pairs p of column j ----
+            for (int idx = tid; idx < (o1 << (lgo0 - 1)); idx += nthr) {
+                const int p = idx & (h0 - 1), j = idx >> (lgo0 - 1);
+                const T *sp = A + j * ld, *dp = sp + h0;
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[(p - SH + q) & (h0 - 1)]; dw[q] = dp[(p + q) & (h0 - 1)]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                *reinterpret_cast<T2 *>(B + 2 * p + j * ld) = T2{xe, xo};
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- dim-2 reconstruction: B -> A corner (or the result array); lanes along the rows ----
+            for (int idx = tid; idx < (h1 << lgo0); idx += nthr) {
+                const int i = idx & (o0 - 1), p = idx >> lgo0;
+                const T *sp = B + i, *dp = sp + h1 * ld;
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[((p - SH + q) & (h1 - 1)) * ld]; dw[q] = dp[((p + q) & (h1 - 1)) * ld]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                if (last) {
+                    out[i + (int64_t)(2 * p) * a.ldo] = xe;
+                    out[i + (int64_t)(2 * p + 1) * a.ldo] = xo;
+                } else {
+                    A[i + (2 * p) * ld] = xe;
+                    A[i + (2 * p + 1) * ld] = xo;
+                }
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+        // a line: coefficients stay in A, reconstructions ping-pong between B and B + n0/2 (every non-final one is <= n0/2 long)
+        const T *cur = A;
+        T *P0 = B, *P1 = B + (n0 >> 1) + 8;
+        for (int t = 0; t < a.nlev; ++t) {
+            const bool last = (t == a.nlev - 1);
+            const int lgo = a.lg0 - (a.nlev - 1 - t), o = 1 << lgo, h = o >> 1;
+            const T *sp = cur, *dp = A + h;
+            T *dst = (t & 1) ? P1 : P0;
+            for (int p = tid; p < h; p += nthr) {
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[(p - SH + q) & (h - 1)]; dw[q] = dp[(p + q) & (h - 1)]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                if (last) *reinterpret_cast<T2 *>(out + 2 * p) = T2{xe, xo};
+                else *reinterpret_cast<T2 *>(dst + 2 * p) = T2{xe, xo};
+            }
+            if (multi) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cur = dst;
+        }
+    }
+}
+
+template <typename T>
+bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item)
+{
+    if (!tail2_ok<T>(F, nt, n0, n1, nlev)) return false;
+    // the last level of a line is stored as 8-byte pairs
+    if (nt == 1 && ((reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) != 0 || (out_item % 2) != 0)) return false;
+    return true;
+}
+
+template <typename T, int F>
+static hipError_t launch_tail2_inv_f(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, int64_t x_item, T *out, int64_t ldo,
+                                     int64_t out_item, int nitems, int n0, int n1, int nt, int nlev)
+{
+    Tail2InvArgs<T, F> a;
+    a.x = x; a.ldx = ldx; a.x_item = x_item; a.out = out; a.ldo = ldo; a.out_item = out_item; a.nt = nt; a.nlev = nlev;
+    a.lg0 = 0; a.lg1 = 0;
+    while ((1 << a.lg0) < n0) ++a.lg0;
+    while ((1 << a.lg1) < n1) ++a.lg1;
+    a.tp = shrink<T, F>(taps);
+    const int ld = (n1 > 1) ? (n0 + 2) : n0;
+    const size_t shmem = (2 * ((size_t)ld * n1 + 8) + 16) * sizeof(T);
+    const int pairs = n0 * n1 / 2;
+    int threads = pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64));
+    const int to = (int)opt("WL_TAIL2_THREADS", 0);
+    if (to >= 64 && to <= 512 && (to % 64) == 0) threads = to;
+    hipLaunchKernelGGL((k_tail2_inv<T, F>), dim3((unsigned)nitems), dim3(threads), shmem, st, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_tail2_inv(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, int64_t x_item, T *out, int64_t ldo,
+                            int64_t out_item, int nitems, int n0, int n1, int nt, int nlev)
+{
+    switch (taps.F) {
+    case 2: return launch_tail2_inv_f<T, 2>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 4: return launch_tail2_inv_f<T, 4>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 6: return launch_tail2_inv_f<T, 6>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 8: return launch_tail2_inv_f<T, 8>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 10: return launch_tail2_inv_f<T, 10>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template bool tail2_inv_ok<float>(int, int, int64_t, int64_t, int, const float *, int64_t);
+template bool tail2_inv_ok<double>(int, int, int64_t, int64_t, int, const double *, int64_t);
+template hipError_t launch_tail2_inv<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, float *, int64_t, int64_t, int, int,
+                                            int, int, int);
+template hipError_t launch_tail2_inv<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t, int,
+                                             int, int, int, int);
 template bool tail2_ok<float>(int, int, int64_t, int64_t, int);
 template bool tail2_ok<double>(int, int, int64_t, int64_t, int);
 template hipError_t launch_tail2<float>(hipStream_t, const Taps<float> &, const float *, int64_t, float *, int64_t, int64_t, int64_t, int, int, int,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # price of bit-exactness: the same library built with -ffp-contract=fast (tools/alt/, not shipped) vs the product build
-O=$PWD/gpurun_out/s14; mkdir -p $O
+O=$PWD/gpurun_out/fpc; mkdir -p $O
 R=$PWD
 B=$R/tools/wlbench.bin
 {

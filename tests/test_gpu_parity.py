@@ -137,6 +137,7 @@ def test_fused_inverse_2d_kernel(gpu, W, oracle, dtype, ppl):
     partial strips / chunks, non-square blocks, both lane widths, approximation taken from x (L = 1) and from the
     deeper reconstruction (L > 1)."""
     W.set_option("WL_INV2D_PPL", int(ppl))
+    W.set_option("WL_TILE_INV", 0)            # (blocks <= 1024 would otherwise take the two-level LDS tile kernel)
     for shape, Ls in (((512, 512), (1, 2, 9)), ((1024, 2048), (1, 3)), ((2048, 512), (2, 9)), ((528, 96), (1, 4)),
                       ((4096, 16), (1,)), ((1000, 24), (1, 3)), ((128, 128), (1, 7)), ((256, 64), (1, 2)), ((136, 24), (1, 3)),
                       ((264, 528), (1, 3))):
@@ -279,6 +280,29 @@ def test_tile_kernel(gpu, W, oracle, nl3max):
                 assert W.last_kernel() == "k_fwd2d_tile", (shape, L, W.last_kernel())
                 ye = oracle.dwt_filter(x, wt.qmf, L)
                 assert np.array_equal(y, ye), (shape, fname, L, nl3max, int((y != ye).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_inverse_tile_kernel(gpu, W, oracle, dtype):
+    """k_inv2d_tile2 (two reconstruction levels of a block <= 1024 x 1024 per launch, 64 x 64 output tiles, recomputed one-sided
+    halos in LDS): square and non-square blocks incl. the smallest (128: the tile's halo wraps around the 32-sample
+    quarter extent), every filter length, depths that put the pair at the end, in the middle and after the tail kernel --
+    bit for bit against the oracle and against the single-level streaming kernel."""
+    for shape, Ls in (((128, 128), (2, 3, 7)), ((256, 256), (2, 8)), ((1024, 1024), (2, 4, 10)), ((256, 1024), (2, 3)), ((1024, 128), (2, 7)),
+                      ((192, 320), (2, 3)), ((512, 512), (3, 9)), ((2048, 2048), (3, 11))):
+        if dtype == np.float64 and shape == (2048, 2048):
+            continue
+        y = rng_array(shape, dtype, sum(shape))
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                xe = oracle.dwt_filter(y, wt.qmf, L, fw=False)
+                xr = host(W, W.idwt(dev(W, y), wt, L))
+                if max(shape) <= 1024:
+                    assert W.last_kernel() == "k_inv2d_tile2", (shape, fname, L, W.last_kernel())
+                assert np.array_equal(xr, xe), (shape, fname, L, int((xr != xe).sum()))
+                with W.options(WL_TILE_INV=0):
+                    assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname, L, "streaming")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -17,7 +17,7 @@ done
 for c in c3 c2 c4 c5; do
   $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --no-pipelined --steps 50 --warmup 3
 done
-for k in idwt2d lift2d dwt3d modwt denoise; do
+for k in idwt2d lift2d lift2d_inv dwt3d modwt denoise; do
   $REPO/tools/rp.sh $O/stats_$k $R "--kernel-trace --stats" python $REPO/tools/run_case.py $k 20
 done
 # PMC: the first launch of the headline transform (L = 1 call = exactly that kernel), torch-free harness

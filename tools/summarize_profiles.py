@@ -21,7 +21,7 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
-for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "dwt3d", "modwt", "denoise"):
+for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise"):
     p = find(f"stats_{k}", "*kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(DST, f"{R}_{k}_kernel_stats.csv"))

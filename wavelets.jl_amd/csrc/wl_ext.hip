@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(EXT_THREADS) k_modwt_step(const T *__restrict_
         T w = (T)(tp.h[0] * x), s = (T)(tp.g[0] * x);
         for (int n = 1; n < tp.F; ++n) {
             k -= stride;
-            while (k < 0) k += N;                 // (no emulated 64-bit division: the stride is below N except for tiny signals)
+            if (k < 0) { k += N; if (k < 0) { k %= N; if (k < 0) k += N; } }   // one add unless the stride exceeds N (tiny signals)
             x = (double)v[k];
             w = (T)((double)w + tp.h[n] * x);
             s = (T)((double)s + tp.g[n] * x);
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step(const T *__restrict
         T acc = (T)(tp.h[0] * (double)w[k] + tp.g[0] * (double)v[k]);
         for (int n = 1; n < tp.F; ++n) {
             k += stride;
-            while (k >= N) k -= N;
+            if (k >= N) { k -= N; if (k >= N) k %= N; }
             acc = (T)((double)acc + (tp.h[n] * (double)w[k] + tp.g[n] * (double)v[k]));
         }
         v0[t] = acc;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(EXT_THREADS) k_modwt_step_v(const T *__restric
         for (int e = 0; e < V; ++e) { const double xd = (double)x[e]; w[e] = (T)(tp.h[0] * xd); s[e] = (T)(tp.g[0] * xd); }
         for (int n = 1; n < tp.F; ++n) {
             k -= strideV;
-            while (k < 0) k += NV;
+            if (k < 0) { k += NV; if (k < 0) { k %= NV; if (k < 0) k += NV; } }
             x = vv[k];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step_v(const T *__restri
         for (int e = 0; e < V; ++e) acc[e] = (T)(tp.h[0] * (double)b[e] + tp.g[0] * (double)a[e]);
         for (int n = 1; n < tp.F; ++n) {
             k += strideV;
-            while (k >= NV) k -= NV;
+            if (k >= NV) { k -= NV; if (k >= NV) k %= NV; }
             a = vv[k];
             b = wv[k];
 #pragma unroll

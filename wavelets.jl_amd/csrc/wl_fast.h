@@ -55,6 +55,12 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, co
                              float *ll, int64_t ldll, int M, int N);
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
+// two inverse 2-D levels of a cache-resident block per launch (wl_tile.hip)
+template <typename T>
+bool inv2d_tile2_ok(int F, int64_t M, int64_t N);
+template <typename T>
+hipError_t inv2d_tile2_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl, T *dst, int64_t ldd,
+                              int M, int N);
 template <typename T>
 bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item);
 template <typename T>

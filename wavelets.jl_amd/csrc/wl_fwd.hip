@@ -1276,7 +1276,9 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         // ---- LDS-resident tail: finishes every remaining level in one launch ----
         // (batches of many lines: one workgroup per line is only efficient for short lines -- longer ones take
         //  another pass of the multi-level tile kernel first)
-        const int64_t line_cap = (lines && nlines >= 32 && fastF) ? env_int("WL_TAIL_LINES_CAP", 512) : tail_cap<T>();
+        // single lines: the latency-optimised tail (wl_tail.hip) takes 16 KiB; longer lines get another multi-level pass first
+        const int64_t line_cap = (lines && nlines >= 32 && fastF) ? env_int("WL_TAIL_LINES_CAP", 512)
+                                 : ((lines && fastF && env_int("WL_TAIL2", 1)) ? (int64_t)(16384 / sizeof(T)) : (int64_t)tail_cap<T>());
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
             // filters beyond 24 taps: one workgroup is slow at 2 F multiply-adds per sample -- the chip-wide line / axis
@@ -1304,7 +1306,19 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             int NL = L - l + 1;
             // big stages are bandwidth-bound: 4 levels keep the halo (F-2)(2^NL - 1) small; small stages are launch-latency
             // bound: up to 6 levels per launch saves whole launches (1-D db2 2^20 f64: 23.8 -> 17.3 us)
-            const int nlmax = env_int("WL_NLMAX", (n[0] * nlines >= ((int64_t)1 << 22)) ? 4 : 6);
+            int nl_auto = 4;
+            if (n[0] * nlines < ((int64_t)1 << 22)) {
+                // levels left before the one-workgroup tail can take the line: split them evenly over the fewest launches
+                int lg_n = 0, lg_cap = 0;
+                while (((int64_t)2 << lg_n) <= n[0]) ++lg_n;
+                while (((int64_t)2 << lg_cap) <= line_cap) ++lg_cap;
+                int r = lg_n - lg_cap;
+                if (r > L - l + 1) r = L - l + 1;
+                if (r < 1) r = 1;
+                const int stages = (r + 5) / 6;
+                nl_auto = (r + stages - 1) / stages;
+            }
+            const int nlmax = env_int("WL_NLMAX", nl_auto);
             if (NL > nlmax) NL = nlmax;
             while (NL > 1 && (n[0] % ((int64_t)(1 << NL) * 4 * VEC)) != 0) --NL;   // alignment of every level's stores
             const bool lastm = (l + NL - 1 == L);

@@ -873,6 +873,22 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         Strides3 res_st = (l == 1) ? b.full : box_st;
         bool done = false;
 
+        // ---- small 2-D blocks: two levels (l and l-1) per launch, LDS tiles (wl_tile.hip) ----
+        if (fastF && two_d && path == 0 && l >= 2 && i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
+            int64_t n1[3];
+            level_box(b, l - 1, n1);                        // output extents of the shallower level
+            if (inv2d_tile2_ok<T>(F, n1[0], n1[1]) && n1[0] <= i_env("WL_TILE_INV_MAX", 1024) && n1[1] <= i_env("WL_TILE_INV_MAX", 1024)) {
+                T *res1 = (l - 1 == 1) ? y : (pp ? w.B : w.A);
+                const int64_t r_ld = (l - 1 == 1) ? b.full.s[1] : n1[0];
+                const T *ss = llsrc ? llsrc : x;
+                const int64_t sls = llsrc ? llsrc_st.s[1] : b.full.s[1];
+                WL_TRYI(inv2d_tile2_launch<T>(st, taps, x, b.full.s[1], ss, sls, res1, r_ld, (int)n1[0], (int)n1[1]));
+                dominant = "k_inv2d_tile2";
+                llsrc = res1; llsrc_st = dense_strides(n1); pp ^= 1;
+                --l;                                         // two levels consumed
+                continue;
+            }
+        }
         // ---- lines: two levels (l and l-1) per launch ----
         if (fastF && lines && l >= 2 && i_env("WL_NO_INV1D2", 0) == 0 && n[0] >= 512 && (n[0] % 8) == 0 && b.full.s[0] == 1 &&
             i_al16(x) && i_al16(y) && (nlines == 1 || ((b.full.s[1] % VEC) == 0 && (!llsrc || (llsrc_st.s[1] % VEC) == 0)))) {

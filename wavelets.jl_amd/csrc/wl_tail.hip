@@ -207,27 +207,6 @@ struct Tail2InvArgs {
     TapsF<T, F> tp;
 };
 
-// (x[2p], x[2p+1]) from sw[q] = s[p - SH + q], dw[q] = d[p + q], q = 0..SH (wl_internal.h closed form, even F)
-template <typename T, int F>
-__device__ __forceinline__ void window_inv(const T (&sw)[(F - 2) / 2 + 1], const T (&dw)[(F - 2) / 2 + 1], const TapsF<T, F> &tp, T &xe, T &xo)
-{
-    constexpr int SH = (F - 2) / 2;
-    T Se = tp.h[F - 2] * sw[0];
-#pragma unroll
-    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
-    T De = tp.g[1] * dw[0];
-#pragma unroll
-    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
-    xe = Se + De;
-    T So = tp.h[F - 1] * sw[0];
-#pragma unroll
-    for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
-    T Do = tp.g[0] * dw[0];
-#pragma unroll
-    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
-    xo = So + Do;
-}
-
 template <typename T, int F>
 __global__ void __launch_bounds__(512) k_tail2_inv(Tail2InvArgs<T, F> a)
 {

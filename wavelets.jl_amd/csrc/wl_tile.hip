@@ -214,4 +214,164 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The inverse of the same sizes: TWO reconstruction levels (output M/2 x N/2, then M x N, M, N in 128 .. 1024) per launch,
+// one 64 x 64 piece of the final output per workgroup.  Everything a tile needs -- the (16 + SH2 + SH)^2 corner of the deeper
+// approximation and the matching pieces of the six detail quadrants, one-sided halos: s coefficients reach SH pairs back,
+// d coefficients SH pairs ahead -- is staged to LDS with all loads in flight, then four LDS -> LDS passes (dim 1 / dim 2 of
+// the coarse level, dim 1 / dim 2 of the fine level; reference order transforms_filter.jl:173-186) produce the tile; halos
+// are recomputed, workgroups are independent.  Replaces two ~7 us launches of k_inv2d_stream by one of ~5 us.
+template <typename T, int F>
+struct TileInvArgs {
+    const T *x; int64_t ldx;            // coefficient array
+    const T *ll; int64_t ldl;           // reconstruction of the deeper level (M/4 x N/4, dense)
+    T *dst; int64_t ldd;                // M x N result
+    int M, N;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F>
+__global__ void __launch_bounds__(1024) k_inv2d_tile2(TileInvArgs<T, F> a)
+{
+    constexpr int SH = (F - 2) / 2, SH2 = (SH + 1) / 2, OFF1 = 2 * SH2 - SH;
+    constexpr int NP1 = 32, NP2 = 16 + SH2;                 // output pairs per dimension: fine level, coarse level
+    constexpr int E1 = NP1 + SH, E2 = NP2 + SH;             // staged s / d extents per dimension
+    constexpr int LD2 = E2 | 1, LT2 = (2 * NP2) | 1, LD1 = E1 | 1, LT1 = 65;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *SS2 = reinterpret_cast<T *>(smem_raw);               // [E2 x E2] s rows, s cols (deeper approximation)
+    T *DS2 = SS2 + LD2 * E2, *SD2 = DS2 + LD2 * E2, *DD2 = SD2 + LD2 * E2;
+    T *T2 = DD2 + LD2 * E2;                                 // [2 NP2 rows x (E2 s-cols | E2 d-cols)]
+    T *A1 = T2 + LT2 * 2 * E2;                              // [2 NP2 x 2 NP2] coarse-level output around the tile
+    T *DS1 = A1 + LT2 * 2 * NP2, *SD1 = DS1 + LD1 * E1, *DD1 = SD1 + LD1 * E1;
+    T *T1 = DD1 + LD1 * E1;                                 // [64 rows x (E1 s-cols | E1 d-cols)]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int h0 = a.M >> 1, h1 = a.N >> 1, q0 = a.M >> 2, q1 = a.N >> 2;       // half extents: fine level, coarse level
+    const int P1r = r0 >> 1, P1c = c0 >> 1, P2r = (P1r >> 1) - SH2, P2c = (P1c >> 1) - SH2;
+    auto wrap = [](int i, int n) __attribute__((always_inline)) { if (i < 0) i += n; if (i >= n) i -= n; return i; };
+    // ---- stage (scalar loads, lanes along the rows) ----
+    for (int it = tid; it < E2 * E2; it += nthr) {
+        const int ai = it % E2, bi = it / E2;
+        const int rs = wrap(P2r - SH + ai, q0), rd = wrap(P2r + ai, q0), cs = wrap(P2c - SH + bi, q1), cd = wrap(P2c + bi, q1);
+        SS2[ai + bi * LD2] = a.ll[rs + (int64_t)cs * a.ldl];
+        DS2[ai + bi * LD2] = a.x[q0 + rd + (int64_t)cs * a.ldx];
+        SD2[ai + bi * LD2] = a.x[rs + (int64_t)(q1 + cd) * a.ldx];
+        DD2[ai + bi * LD2] = a.x[q0 + rd + (int64_t)(q1 + cd) * a.ldx];
+    }
+    for (int it = tid; it < E1 * E1; it += nthr) {
+        const int ai = it % E1, bi = it / E1;
+        const int rs = wrap(P1r - SH + ai, h0), rd = wrap(P1r + ai, h0), cs = wrap(P1c - SH + bi, h1), cd = wrap(P1c + bi, h1);
+        DS1[ai + bi * LD1] = a.x[h0 + rd + (int64_t)cs * a.ldx];
+        SD1[ai + bi * LD1] = a.x[rs + (int64_t)(h1 + cd) * a.ldx];
+        DD1[ai + bi * LD1] = a.x[h0 + rd + (int64_t)(h1 + cd) * a.ldx];
+    }
+    lds_barrier_vm();
+    // ---- coarse level, dim 1: columns b of (s-cols | d-cols), pairs p -> T2 rows 2p, 2p+1 ----
+    for (int it = tid; it < NP2 * 2 * E2; it += nthr) {
+        const int p = it % NP2, b = it / NP2;
+        const T *sp = (b < E2) ? SS2 + b * LD2 : SD2 + (b - E2) * LD2;
+        const T *dp = (b < E2) ? DS2 + b * LD2 : DD2 + (b - E2) * LD2;
+        T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+        for (int q = 0; q <= SH; ++q) { sw[q] = sp[p + q]; dw[q] = dp[p + q]; }
+        T xe, xo;
+        window_inv<T, F>(sw, dw, a.tp, xe, xo);
+        T2[2 * p + b * LT2] = xe;
+        T2[2 * p + 1 + b * LT2] = xo;
+    }
+    lds_barrier();
+    // ---- coarse level, dim 2: rows i, column pairs p -> A1 ----
+    for (int it = tid; it < 2 * NP2 * NP2; it += nthr) {
+        const int i = it % (2 * NP2), p = it / (2 * NP2);
+        T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+        for (int q = 0; q <= SH; ++q) { sw[q] = T2[i + (p + q) * LT2]; dw[q] = T2[i + (E2 + p + q) * LT2]; }
+        T xe, xo;
+        window_inv<T, F>(sw, dw, a.tp, xe, xo);
+        A1[i + (2 * p) * LT2] = xe;
+        A1[i + (2 * p + 1) * LT2] = xo;
+    }
+    lds_barrier();
+    // ---- fine level, dim 1: s rows come from A1 (offset OFF1: its region starts at an even row) ----
+    for (int it = tid; it < NP1 * 2 * E1; it += nthr) {
+        const int p = it % NP1, b = it / NP1;
+        T sw[SH + 1], dw[SH + 1];
+        if (b < E1) {
+#pragma unroll
+            for (int q = 0; q <= SH; ++q) { sw[q] = A1[OFF1 + p + q + (OFF1 + b) * LT2]; dw[q] = DS1[p + q + b * LD1]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q <= SH; ++q) { sw[q] = SD1[p + q + (b - E1) * LD1]; dw[q] = DD1[p + q + (b - E1) * LD1]; }
+        }
+        T xe, xo;
+        window_inv<T, F>(sw, dw, a.tp, xe, xo);
+        T1[2 * p + b * LT1] = xe;
+        T1[2 * p + 1 + b * LT1] = xo;
+    }
+    lds_barrier();
+    // ---- fine level, dim 2: rows i, column pairs p -> the result tile ----
+    T *out = a.dst + r0 + (int64_t)c0 * a.ldd;
+    for (int it = tid; it < 64 * NP1; it += nthr) {
+        const int i = it & 63, p = it >> 6;
+        T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+        for (int q = 0; q <= SH; ++q) { sw[q] = T1[i + (p + q) * LT1]; dw[q] = T1[i + (E1 + p + q) * LT1]; }
+        T xe, xo;
+        window_inv<T, F>(sw, dw, a.tp, xe, xo);
+        out[i + (int64_t)(2 * p) * a.ldd] = xe;
+        out[i + (int64_t)(2 * p + 1) * a.ldd] = xo;
+    }
+}
+
+template <typename T>
+bool inv2d_tile2_ok(int F, int64_t M, int64_t N)
+{
+    if (F < 2 || F > 10 || (F & 1)) return false;
+    return M >= 128 && N >= 128 && M <= 1024 && N <= 1024 && (M % 64) == 0 && (N % 64) == 0;
+}
+
+template <typename T, int F>
+static hipError_t launch_inv_tile2_f(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl, T *dst,
+                                     int64_t ldd, int M, int N)
+{
+    constexpr int SH = (F - 2) / 2, SH2 = (SH + 1) / 2, NP1 = 32, NP2 = 16 + SH2, E1 = NP1 + SH, E2 = NP2 + SH;
+    constexpr int LD2 = E2 | 1, LT2 = (2 * NP2) | 1, LD1 = E1 | 1, LT1 = 65;
+    constexpr size_t elems = 4 * LD2 * E2 + LT2 * 2 * E2 + LT2 * 2 * NP2 + 3 * LD1 * E1 + LT1 * 2 * E1 + 16;
+    TileInvArgs<T, F> a;
+    a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.M = M; a.N = N;
+    a.tp = shrink<T, F>(taps);
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_inv2d_tile2<T, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    hipLaunchKernelGGL((k_inv2d_tile2<T, F>), dim3((unsigned)(M / 64), (unsigned)(N / 64)), dim3((unsigned)opt("WL_TILE_THREADS", 1024)),
+                       elems * sizeof(T), st, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t inv2d_tile2_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl, T *dst, int64_t ldd,
+                              int M, int N)
+{
+    switch (taps.F) {
+    case 2: return launch_inv_tile2_f<T, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 4: return launch_inv_tile2_f<T, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 6: return launch_inv_tile2_f<T, 6>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 8: return launch_inv_tile2_f<T, 8>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 10: return launch_inv_tile2_f<T, 10>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    default: return hipErrorInvalidValue;
+    }
+}
+template bool inv2d_tile2_ok<float>(int, int64_t, int64_t);
+template bool inv2d_tile2_ok<double>(int, int64_t, int64_t);
+template hipError_t inv2d_tile2_launch<float>(hipStream_t, const Taps<float> &, const float *, int64_t, const float *, int64_t, float *, int64_t,
+                                              int, int);
+template hipError_t inv2d_tile2_launch<double>(hipStream_t, const Taps<double> &, const double *, int64_t, const double *, int64_t, double *,
+                                               int64_t, int, int);
+
 }  // namespace wl

@@ -9,7 +9,7 @@ import oracle
 import wavelets_jl_amd as W
 
 FILTERS = ["haar", "db2", "db3", "db4", "db5", "db6", "db7", "db8", "db9", "db10", "sym4", "sym5", "sym6", "sym8", "sym10",
-           "coif2", "coif4", "coif6", "coif8", "batt2", "batt4", "vaid", "beyl"]
+           "coif2", "coif4", "coif6", "coif8", "batt2", "batt4", "batt6", "vaid", "beyl"]
 SCHEMES = ["haar", "db2", "cdf97"]
 
 

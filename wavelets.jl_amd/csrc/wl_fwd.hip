@@ -1497,6 +1497,14 @@ bool fwd2d_planes(hipStream_t st, const Taps<T> &taps, const T *src, T *y, int64
     if ((F % 2) != 0 || F > 10 || n0 < 64 * VEC || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 ||
         !aligned16(src) || !aligned16(y) || (ll && !aligned16(ll)) || nplanes > 65535)
         return false;
+    if constexpr (sizeof(T) == 4) {
+        // Float32 planes of >= 256 rows: the LDS-exchange level kernel, batched over blockIdx.y (wl_fwd2d.hip)
+        if (opt("WL_LDS2D", 1) != 0 && n0 >= opt("WL_LDS2D_MIN_ROWS", 256) && fwd2d_lds_ok(F, 1, n0, n1)) {
+            *err = fwd2d_lds_launch(st, taps, 1, false, src, n0, y, y1, ll, n0 >> 1, n0, n1, cu_count, nplanes, n0 * n1, y2,
+                                    (n0 >> 1) * (n1 >> 1), nll);
+            return true;
+        }
+    }
     bool ok = false;
     WL_DISPATCH_F(F, *err = launch_fwd2d_r<T, FF, VEC>(st, taps, false, src, n0, y, y1, ll, n0 >> 1, n0, n1, cu_count, nplanes, n0 * n1, y2,
                                                         (n0 >> 1) * (n1 >> 1), nll);

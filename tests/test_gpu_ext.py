@@ -17,7 +17,8 @@ def host(W, t):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_modwt_bitexact(gpu, W, oracle, dtype):
-    for n, Ls in ((128, (None, 1, 4)), (129, (None, 3)), (1000, (None, 9)), (1 << 16, (None, 5)), (1, ()), (2, (1,)), (3, (1,))):
+    for n, Ls in ((128, (None, 1, 4)), (129, (None, 3)), (1000, (None, 9)), (1 << 16, (None, 5)), (1, ()), (2, (1,)), (3, (1,)), (8, (1, 3)), (12, (2,)),
+                  (4, (1, 2))):
         x = np.cumsum(rng_array((n,), np.float64, n)).astype(dtype)
         for fname in ("db4", "haar", "db2", "sym5", "batt2", "coif6"):
             wt = W.wavelet(getattr(W.WT, fname))
@@ -28,6 +29,9 @@ def test_modwt_bitexact(gpu, W, oracle, dtype):
                 assert np.array_equal(host(W, wg), we), (n, fname, L)
                 xr = host(W, W.imodwt(W.to_device(we), wt))
                 assert np.array_equal(xr, oracle.imodwt(we, wt.qmf)), (n, fname, L, "inv")
+                with W.options(WL_MODWT_SMALL=0):        # levels 1-2 on the scalar kernels instead of the small-stride vector kernels
+                    assert np.array_equal(host(W, W.modwt(W.to_device(x), wt, L)), we), (n, fname, L, "scalar")
+                    assert np.array_equal(host(W, W.imodwt(W.to_device(we), wt)), xr), (n, fname, L, "scalar inv")
                 if fname != "batt2":          # the Battle tables are not orthogonal: imodwt is only the adjoint there
                     assert np.abs(xr - x).max() <= (1e-4 if dtype == np.float32 else 1e-10) * max(1.0, np.abs(x).max())
     wt = W.wavelet(W.WT.db4)

@@ -171,6 +171,82 @@ __global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step_v(const T *__restri
     }
 }
 
+// strides below the vector width (levels 1-2 for Float32, level 1 for Float64; S divides V): a thread still produces V
+// consecutive outputs from aligned 16-byte loads -- the V/S taps that fall into one vector step are served from the register
+// pair [previous chunk | current chunk] with compile-time offsets, then the pair slides by one chunk.  Same tap order and
+// per-tap rounding as k_modwt_step (the scalar kernel issued one 4-byte load per lane and tap: 1.2 TB/s of level traffic).
+template <typename T, int S>
+__global__ void __launch_bounds__(EXT_THREADS) k_modwt_step_s(const T *__restrict__ v, T *__restrict__ v1, T *__restrict__ w1,
+                                                              int64_t NV, ModwtTaps tp)
+{
+    constexpr int V = 16 / sizeof(T), G = V / S;
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const VT *vv = reinterpret_cast<const VT *>(v);
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < NV; t += nthr) {
+        int64_t k = t;
+        VT c = vv[k];
+        int64_t kp = (k == 0) ? NV - 1 : k - 1;
+        VT p = vv[kp];
+        VT w, s;
+        for (int n0 = 0; n0 < tp.F; n0 += G) {
+            T win[2 * V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { win[e] = p[e]; win[V + e] = c[e]; }
+            c = p;                                         // slide: the next group of taps starts one chunk back
+            kp = (kp == 0) ? NV - 1 : kp - 1;
+            p = vv[kp];
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const int n = n0 + r;
+                if (n < tp.F) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const double xd = (double)win[V + e - r * S];
+                        if (n == 0) { w[e] = (T)(tp.h[0] * xd); s[e] = (T)(tp.g[0] * xd); }
+                        else { w[e] = (T)((double)w[e] + tp.h[n] * xd); s[e] = (T)((double)s[e] + tp.g[n] * xd); }
+                    }
+                }
+            }
+        }
+        reinterpret_cast<VT *>(w1)[t] = w;
+        reinterpret_cast<VT *>(v1)[t] = s;
+    }
+}
+template <typename T, int S>
+__global__ void __launch_bounds__(EXT_THREADS) k_imodwt_step_s(const T *__restrict__ v, const T *__restrict__ w, T *__restrict__ v0,
+                                                               int64_t NV, ModwtTaps tp)
+{
+    constexpr int V = 16 / sizeof(T), G = V / S;
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const VT *vv = reinterpret_cast<const VT *>(v), *wv = reinterpret_cast<const VT *>(w);
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < NV; t += nthr) {
+        int64_t kn = (t + 1 == NV) ? 0 : t + 1;
+        VT ca = vv[t], cb = wv[t], na = vv[kn], nb = wv[kn], acc;
+        for (int n0 = 0; n0 < tp.F; n0 += G) {
+            T wa[2 * V], wb[2 * V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { wa[e] = ca[e]; wa[V + e] = na[e]; wb[e] = cb[e]; wb[V + e] = nb[e]; }
+            ca = na; cb = nb;
+            kn = (kn + 1 == NV) ? 0 : kn + 1;
+            na = vv[kn]; nb = wv[kn];
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const int n = n0 + r;
+                if (n < tp.F) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const double term = tp.h[n] * (double)wb[e + r * S] + tp.g[n] * (double)wa[e + r * S];
+                        acc[e] = (n == 0) ? (T)term : (T)((double)acc[e] + term);
+                    }
+                }
+            }
+        }
+        reinterpret_cast<VT *>(v0)[t] = acc;
+    }
+}
+
 template <typename T>
 int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int64_t N, const double *qmf, int flen, int L)
 {
@@ -188,6 +264,12 @@ int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int
         if (vec_base && (stride % V) == 0) {
             hipLaunchKernelGGL((k_modwt_step_v<T>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur, vdst,
                                out + (int64_t)(j - 1) * ldo, N / V, stride / V, tp);
+        } else if (vec_base && stride == 1 && N >= 2 * V && opt("WL_MODWT_SMALL", 1) != 0) {
+            hipLaunchKernelGGL((k_modwt_step_s<T, 1>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur, vdst,
+                               out + (int64_t)(j - 1) * ldo, N / V, tp);
+        } else if (vec_base && stride == 2 && V == 4 && N >= 2 * V && opt("WL_MODWT_SMALL", 1) != 0) {
+            hipLaunchKernelGGL((k_modwt_step_s<T, (sizeof(T) == 4 ? 2 : 1)>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st,
+                               cur, vdst, out + (int64_t)(j - 1) * ldo, N / V, tp);
         } else {
             hipLaunchKernelGGL((k_modwt_step<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur, vdst,
                                out + (int64_t)(j - 1) * ldo, N, stride, tp);
@@ -217,6 +299,12 @@ int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int
         if (vec_base && (stride % V) == 0) {
             hipLaunchKernelGGL((k_imodwt_step_v<T>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur,
                                xw + (int64_t)(j - 1) * ldw, dst, N / V, stride / V, tp);
+        } else if (vec_base && stride == 1 && N >= 2 * V && opt("WL_MODWT_SMALL", 1) != 0) {
+            hipLaunchKernelGGL((k_imodwt_step_s<T, 1>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur,
+                               xw + (int64_t)(j - 1) * ldw, dst, N / V, tp);
+        } else if (vec_base && stride == 2 && V == 4 && N >= 2 * V && opt("WL_MODWT_SMALL", 1) != 0) {
+            hipLaunchKernelGGL((k_imodwt_step_s<T, (sizeof(T) == 4 ? 2 : 1)>), dim3(ext_blocks(N / V, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st,
+                               cur, xw + (int64_t)(j - 1) * ldw, dst, N / V, tp);
         } else {
             hipLaunchKernelGGL((k_imodwt_step<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, cur,
                                xw + (int64_t)(j - 1) * ldw, dst, N, stride, tp);

@@ -320,7 +320,7 @@ def test_tail2_inverse_kernel(gpu, W, oracle, dtype):
     mask wrap, in-place quadrant reuse): every supported filter length, every depth down to 2 x 2, square and non-square
     blocks, 1-D lines, batched lines, forced thread counts, as the start of a larger reconstruction -- bit for bit against
     the oracle and against the general inverse tail kernel."""
-    cap = 4096 if dtype == np.float32 else 2048
+    cap = 4096
     for threads in (0, 64, 256):
         W.set_option("WL_TAIL2_THREADS", threads)
         for shape in ((64, 64), (32, 32), (64, 32), (16, 64), (8, 8), (4, 4), (2, 2), (128, 16), (2, 64), (64, 2)):
@@ -367,7 +367,7 @@ def test_tail2_kernel(gpu, W, oracle, dtype):
     supported filter length, every depth down to 2 x 2 (lines shorter than the filter wrap several times), square and
     non-square blocks, 1-D lines, batched lines, forced thread counts -- bit for bit against the oracle and against the
     general tail kernel."""
-    cap = 4096 if dtype == np.float32 else 2048
+    cap = 4096
     W.set_option("WL_NO_MULTI2D", 1)          # (64 x 64 blocks would otherwise take one pass of the tile kernel first)
     for threads in (0, 64, 256):
         W.set_option("WL_TAIL2_THREADS", threads)

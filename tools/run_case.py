@@ -25,6 +25,14 @@ elif case == "lift2d_inv":
     y = W.similar(x)
     sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
     fn = lambda: W.idwt_oop_(y, x, sch, 13)
+elif case == "dwt2d_f64":
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
+    y = W.similar(x)
+    fn = lambda: W.dwt_oop_(y, x, db4, 13)
+elif case == "idwt2d_f64":
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
+    y = W.similar(x)
+    fn = lambda: W.idwt_oop_(y, x, db4, 13)
 elif case == "dwt3d":
     x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
     y = W.similar(x)

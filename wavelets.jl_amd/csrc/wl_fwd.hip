@@ -1276,9 +1276,9 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         // ---- LDS-resident tail: finishes every remaining level in one launch ----
         // (batches of many lines: one workgroup per line is only efficient for short lines -- longer ones take
         //  another pass of the multi-level tile kernel first)
-        // single lines: the latency-optimised tail (wl_tail.hip) takes 16 KiB; longer lines get another multi-level pass first
+        // single lines: the latency-optimised tail (wl_tail.hip) takes 4096 samples; longer lines get another multi-level pass first
         const int64_t line_cap = (lines && nlines >= 32 && fastF) ? env_int("WL_TAIL_LINES_CAP", 512)
-                                 : ((lines && fastF && env_int("WL_TAIL2", 1)) ? (int64_t)(16384 / sizeof(T)) : (int64_t)tail_cap<T>());
+                                 : ((lines && fastF && env_int("WL_TAIL2", 1)) ? (int64_t)4096 : (int64_t)tail_cap<T>());
         if (path == 0 && (two_d || lines) && b.full.s[0] == 1) {
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
             // filters beyond 24 taps: one workgroup is slow at 2 F multiply-adds per sample -- the chip-wide line / axis

@@ -148,7 +148,7 @@ bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev)
     auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
     if (!pow2(m0) || (nt == 2 && !pow2(m1))) return false;
     if (nt == 1 && m1 != 1) return false;
-    const int64_t cap = 16384 / (int64_t)sizeof(T);                  // 4096 f32 / 2048 f64 elements
+    const int64_t cap = 4096;                                       // elements: 16 KiB of Float32, 32 KiB of Float64
     if (m0 * m1 > cap) return false;
     // every level needs both extents >= 2
     int lg0 = 0, lg1 = 0;
@@ -156,6 +156,22 @@ bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev)
     while (((int64_t)1 << lg1) < m1) ++lg1;
     if (nlev < 1 || nlev > lg0 || (nt == 2 && nlev > lg1)) return false;
     return true;
+}
+
+// blocks of Float64 need more than the default 64 KiB of dynamic LDS: raise the limit once per (kernel, device)
+static hipError_t tail2_lds_attr(const void *fn, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    static thread_local const void *done_fn[16];
+    static thread_local int done_dev[16];
+    static thread_local int ndone = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < ndone; ++i)
+        if (done_fn[i] == fn && done_dev[i] == dev) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && ndone < 16) { done_fn[ndone] = fn; done_dev[ndone] = dev; ++ndone; }
+    return e;
 }
 
 template <typename T, int F>
@@ -174,6 +190,8 @@ static hipError_t launch_tail2_f(hipStream_t st, const Taps<T> &taps, const T *s
     int threads = pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64));
     const int to = (int)opt("WL_TAIL2_THREADS", 0);
     if (to >= 64 && to <= 512 && (to % 64) == 0) threads = to;
+    hipError_t ea = tail2_lds_attr(reinterpret_cast<const void *>(&k_tail2_fwd<T, F>), shmem);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((k_tail2_fwd<T, F>), dim3((unsigned)nitems), dim3(threads), shmem, st, a);
     return hipGetLastError();
 }
@@ -335,6 +353,8 @@ static hipError_t launch_tail2_inv_f(hipStream_t st, const Taps<T> &taps, const 
     int threads = pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64));
     const int to = (int)opt("WL_TAIL2_THREADS", 0);
     if (to >= 64 && to <= 512 && (to % 64) == 0) threads = to;
+    hipError_t ea = tail2_lds_attr(reinterpret_cast<const void *>(&k_tail2_inv<T, F>), shmem);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((k_tail2_inv<T, F>), dim3((unsigned)nitems), dim3(threads), shmem, st, a);
     return hipGetLastError();
 }

@@ -259,10 +259,11 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
                 assert np.array_equal(y, ye), (shape, fname, L, mode, pair, float(np.abs(y - ye).max()))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("nl3max", [0, 4096])
-def test_tile_kernel(gpu, W, oracle, nl3max):
-    """k_fwd2d_tile (1..3 fused levels of a cache-resident block per launch, one-sided halos, 64 x 64 tiles): every supported
-    filter length, one / two / three levels per launch (WL_TILE_NL3_MAX), depths that end inside / after the tiled levels,
+def test_tile_kernel(gpu, W, oracle, nl3max, dtype):
+    """k_fwd2d_tile (1..3 fused levels of a cache-resident block per launch -- Float64: 1..2 --, one-sided halos, 64 x 64 tiles):
+    every supported filter length, one / two / three levels per launch (WL_TILE_NL3_MAX), depths that end inside / after the tiled levels,
     non-square blocks, periodic wrap of the last tiles -- bit for bit against the oracle."""
     W.set_option("WL_TILE_NL3_MAX", nl3max)
     W.set_option("WL_TILE_MAX", 2048)
@@ -270,7 +271,7 @@ def test_tile_kernel(gpu, W, oracle, nl3max):
     shapes = (((128, 128), (1, 2, 3, 7)), ((256, 256), (1, 2, 3, 4, 8)), ((512, 512), (2, 3, 5, 9)), ((1024, 1024), (3, 6)),
               ((256, 128), (1, 2, 3, 7)), ((128, 512), (2, 3)), ((2048, 2048), (2, 3)), ((192, 320), (1, 2, 3)))
     for shape, Ls in shapes:
-        x = rng_array(shape, np.float32, sum(shape) + nl3max)
+        x = rng_array(shape, dtype, sum(shape) + nl3max)
         for fname in ("db4", "haar", "db2", "db3", "sym5"):
             if shape[0] >= 1024 and fname in ("db2", "db3"):
                 continue

@@ -51,8 +51,9 @@ hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, b
 
 // Tile kernel for the cache-resident 2-D levels (wl_tile.hip): NL = 1..3 fused forward levels per launch, Float32, even F <= 10.
 bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N);
-hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, const float *src, int64_t lds, float *y, int64_t ldy,
-                             float *ll, int64_t ldll, int M, int N);
+template <typename T>
+hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
+                             int64_t ldll, int M, int N);
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
 // two inverse 2-D levels of a cache-resident block per launch (wl_tile.hip)

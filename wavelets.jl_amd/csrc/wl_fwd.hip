@@ -1227,21 +1227,21 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 continue;
             }
         }
-        // ---- tile kernel: 1..3 fused levels of a cache-resident block (f32, wl_tile.hip) ----
-        if constexpr (sizeof(T) == 4) {
+        // ---- tile kernel: 1..3 fused levels of a cache-resident block (wl_tile.hip; Float64: up to 2 levels) ----
+        {
+            auto al4 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0; };     // 4-element vectors
             if (fastF && two_d && env_int("WL_TILE", 1) && n[0] <= env_int("WL_TILE_MAX", 1024) && n[1] <= env_int("WL_TILE_MAX", 1024) &&
-                cur_st.s[0] == 1 && (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 && aligned16(y) &&
-                aligned16(llbuf)) {
+                cur_st.s[0] == 1 && (cur_st.s[1] % 4) == 0 && al4(cur) && (b.full.s[1] % 4) == 0 && al4(y) && al4(llbuf)) {
                 int NL = L - l + 1;
                 if (NL > 3) NL = 3;
                 const int64_t nmax = n[0] > n[1] ? n[0] : n[1];
-                if (NL == 3 && nmax > env_int("WL_TILE_NL3_MAX", 0)) NL = 2;
+                if (NL == 3 && (nmax > env_int("WL_TILE_NL3_MAX", 0) || sizeof(T) == 8)) NL = 2;
                 while (NL > 1 && !fwd2d_tile_ok(F, NL, n[0], n[1])) --NL;
                 if (fwd2d_tile_ok(F, NL, n[0], n[1])) {
                     const bool lastt = (l + NL - 1 == L);
                     T *lld = lastt ? y : llbuf;
                     const int64_t ldd = lastt ? b.full.s[1] : (n[0] >> NL);
-                    WL_TRY(fwd2d_tile_launch(st, taps, NL, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, (int)n[0], (int)n[1]));
+                    WL_TRY(fwd2d_tile_launch<T>(st, taps, NL, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, (int)n[0], (int)n[1]));
                     if (!dominant) dominant = "k_fwd2d_tile";
                     lstep = NL;
                     int64_t hn2[3] = {n[0] >> NL, n[1] >> NL, n[2]};

@@ -1,4 +1,4 @@
-// wl_tile.hip -- forward 2-D filter-bank levels of the cache-resident blocks (128^2 .. 2048^2, Float32): NL = 1..3 fused
+// wl_tile.hip -- forward 2-D filter-bank levels of the cache-resident blocks (128^2 .. 2048^2): NL = 1..3 (Float64: 1..2) fused
 // levels per launch, one 64 x 64 piece of the block per workgroup, everything after the first read in LDS.
 //
 // Replaces k_fwd2d_multi (wl_fwd.hip) on these sizes.  Same idea -- recompute halos instead of exchanging them, so that
@@ -16,13 +16,13 @@
 
 namespace wl {
 
-template <int F>
+template <typename T, int F>
 struct TileArgs {
-    const float *src; int64_t lds;      // input block M x N
-    float *y; int64_t ldy;
-    float *ll; int64_t ldll;            // approximation after NL levels (dense buffer or y itself)
+    const T *src; int64_t lds;          // input block M x N
+    T *y; int64_t ldy;
+    T *ll; int64_t ldll;                // approximation after NL levels (dense buffer or y itself)
     int M, N;
-    TapsF<float, F> tp;
+    TapsF<T, F> tp;
 };
 
 // extents of the tile at level l (l = 0: the launch's input), OT = 64 owned input samples per side
@@ -51,22 +51,22 @@ struct TileLds {
     static constexpr int TOTAL = X2 + ldx(R2) * C2 + 16;
 };
 
-typedef float F4t __attribute__((ext_vector_type(4)));
 
 // One level inside the tile.  X: input R x C (leading dimension ldx), T: scratch, XN: next level's input (RN x CN) in LDS.
 // OWN = owned outputs per side at this level (32, 16, 8); (r0h, c0h) = tile origin in this level's OUTPUT coordinates;
 // hm, hn = half extents of this level's block; LAST: the approximation goes to global memory (ll) instead of XN.
-template <int F, int R, int C, int RN, int CN, int OWN, bool LAST>
-__device__ __forceinline__ void tile_level(const float *X, int ldX, float *T, int ldT, float *XN, int ldN, const TapsF<float, F> &tp,
-                                           float *y, int64_t ldy, float *ll, int64_t ldll, int r0h, int c0h, int hm, int hn, int tid,
+template <typename TT, int F, int R, int C, int RN, int CN, int OWN, bool LAST>
+__device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT, TT *XN, int ldN, const TapsF<TT, F> &tp,
+                                           TT *y, int64_t ldy, TT *ll, int64_t ldll, int r0h, int c0h, int hm, int hn, int tid,
                                            int nthr)
 {
+    typedef TT F4t __attribute__((ext_vector_type(4)));
     constexpr int SH = (F - 2) / 2;
     constexpr int RQ = (R + 3) / 4;                 // row quads of the input
     // ---- dim-2 pass: X (R x C) -> T: columns [0, CN) = s (window columns 2k .. 2k+F-1), columns [CN, CN+OWN) = d[k + SH]
     for (int it = tid; it < RQ * CN; it += nthr) {
         const int iq = it % RQ, k = it / RQ;
-        const float *p = X + 4 * iq + (2 * k) * ldX;
+        const TT *p = X + 4 * iq + (2 * k) * ldX;
         F4t x0 = *reinterpret_cast<const F4t *>(p);
         F4t s = tp.h[0] * x0, d = tp.g[F - 1] * x0;
 #pragma unroll
@@ -83,8 +83,8 @@ __device__ __forceinline__ void tile_level(const float *X, int ldX, float *T, in
     constexpr int QG = (RN + 3) / 4;                // groups of four output rows (covers the RN approximation rows needed below)
     for (int it = tid; it < QG * (CN + OWN); it += nthr) {
         const int q = it % QG, c = it / QG;
-        const float *p = T + 8 * q + c * ldT;
-        float E[16];
+        const TT *p = T + 8 * q + c * ldT;
+        TT E[16];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const F4t t = *reinterpret_cast<const F4t *>(p + 4 * v);
@@ -93,10 +93,10 @@ __device__ __forceinline__ void tile_level(const float *X, int ldX, float *T, in
         F4t so, dO;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float s = tp.h[0] * E[2 * j];
+            TT s = tp.h[0] * E[2 * j];
 #pragma unroll
             for (int m = 1; m < F; ++m) s = s + tp.h[m] * E[2 * j + m];
-            float d = tp.g[F - 1] * E[2 * j + 10 - F];
+            TT d = tp.g[F - 1] * E[2 * j + 10 - F];
 #pragma unroll
             for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * E[2 * j + 9 - m];
             so[j] = s; dO[j] = d;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void tile_level(const float *X, int ldX, float *T, in
             else { int kd = c0h + cc + SH; if (kd >= hn) kd -= hn; col = hn + kd; }
             int rd = r0h + 4 * q + 4;
             if (rd >= hm) rd -= hm;
-            float *yc = y + col * ldy;
+            TT *yc = y + col * ldy;
             *reinterpret_cast<F4t *>(yc + hm + rd) = dO;                // ds or dd
             if (!is_s) *reinterpret_cast<F4t *>(yc + (r0h + 4 * q)) = so;  // sd
         }
@@ -123,12 +123,13 @@ __device__ __forceinline__ void tile_level(const float *X, int ldX, float *T, in
     lds_barrier();
 }
 
-template <int F, int NL>
-__global__ void __launch_bounds__(1024) k_fwd2d_tile(TileArgs<F> a)
+template <typename T, int F, int NL>
+__global__ void __launch_bounds__(1024) k_fwd2d_tile(TileArgs<T, F> a)
 {
     typedef TileLds<F, NL> L;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *S = reinterpret_cast<float *>(smem_raw);
+    typedef T F4t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
+    T *S = reinterpret_cast<T *>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     constexpr int ld0 = L::ldx(L::R0), ld1 = L::ldx(L::R1), ld2 = L::ldx(L::R2);
@@ -146,18 +147,18 @@ __global__ void __launch_bounds__(1024) k_fwd2d_tile(TileArgs<F> a)
     lds_barrier_vm();
     const int hm = a.M >> 1, hn = a.N >> 1;
     if constexpr (NL == 1) {
-        tile_level<F, L::R0, L::C0, 32, 32, 32, true>(S + L::X0, ld0, S + L::T, ld0, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 1,
+        tile_level<T, F, L::R0, L::C0, 32, 32, 32, true>(S + L::X0, ld0, S + L::T, ld0, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 1,
                                                       c0 >> 1, hm, hn, tid, nthr);
     } else {
-        tile_level<F, L::R0, L::C0, L::R1, L::C1, 32, false>(S + L::X0, ld0, S + L::T, ld0, S + L::X1, ld1, a.tp, a.y, a.ldy, a.ll, a.ldll,
+        tile_level<T, F, L::R0, L::C0, L::R1, L::C1, 32, false>(S + L::X0, ld0, S + L::T, ld0, S + L::X1, ld1, a.tp, a.y, a.ldy, a.ll, a.ldll,
                                                              r0 >> 1, c0 >> 1, hm, hn, tid, nthr);
         if constexpr (NL == 2) {
-            tile_level<F, L::R1, L::C1, 16, 16, 16, true>(S + L::X1, ld1, S + L::T, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2,
+            tile_level<T, F, L::R1, L::C1, 16, 16, 16, true>(S + L::X1, ld1, S + L::T, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2,
                                                           c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
         } else {
-            tile_level<F, L::R1, L::C1, L::R2, L::C2, 16, false>(S + L::X1, ld1, S + L::T, ld1, S + L::X2, ld2, a.tp, a.y, a.ldy, a.ll,
+            tile_level<T, F, L::R1, L::C1, L::R2, L::C2, 16, false>(S + L::X1, ld1, S + L::T, ld1, S + L::X2, ld2, a.tp, a.y, a.ldy, a.ll,
                                                                  a.ldll, r0 >> 2, c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
-            tile_level<F, L::R2, L::C2, 8, 8, 8, true>(S + L::X2, ld2, S + L::T, ld2, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 3,
+            tile_level<T, F, L::R2, L::C2, 8, 8, 8, true>(S + L::X2, ld2, S + L::T, ld2, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 3,
                                                        c0 >> 3, hm >> 2, hn >> 2, tid, nthr);
         }
     }
@@ -170,49 +171,56 @@ bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N)
     return M >= 128 && N >= 128 && (M % 64) == 0 && (N % 64) == 0 && M <= 4096 && N <= 4096 && (M >> NL) % 4 == 0 && (N >> NL) >= 1;
 }
 
-template <int F, int NL>
-static hipError_t launch_tile_fn(hipStream_t st, const TileArgs<F> &a)
+template <typename T, int F, int NL>
+static hipError_t launch_tile_fn(hipStream_t st, const TileArgs<T, F> &a)
 {
-    constexpr size_t shmem = (size_t)TileLds<F, NL>::TOTAL * sizeof(float);
+    constexpr size_t shmem = (size_t)TileLds<F, NL>::TOTAL * sizeof(T);
     static thread_local int done_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_tile<F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_tile<T, F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((k_fwd2d_tile<F, NL>), dim3((unsigned)(a.M / 64), (unsigned)(a.N / 64)), dim3((unsigned)opt("WL_TILE_THREADS", 1024)), shmem, st, a);
+    hipLaunchKernelGGL((k_fwd2d_tile<T, F, NL>), dim3((unsigned)(a.M / 64), (unsigned)(a.N / 64)), dim3((unsigned)opt("WL_TILE_THREADS", 1024)), shmem, st, a);
     return hipGetLastError();
 }
 
-template <int F>
-static hipError_t launch_tile_f(hipStream_t st, const Taps<float> &taps, int NL, const float *src, int64_t lds, float *y, int64_t ldy,
-                                float *ll, int64_t ldll, int M, int N)
+template <typename T, int F>
+static hipError_t launch_tile_f(hipStream_t st, const Taps<T> &taps, int NL, const T *src, int64_t lds, T *y, int64_t ldy,
+                                T *ll, int64_t ldll, int M, int N)
 {
-    TileArgs<F> a;
+    TileArgs<T, F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.M = M; a.N = N;
-    a.tp = shrink<float, F>(taps);
+    a.tp = shrink<T, F>(taps);
     switch (NL) {
-    case 1: return launch_tile_fn<F, 1>(st, a);
-    case 2: return launch_tile_fn<F, 2>(st, a);
-    default: return launch_tile_fn<F, 3>(st, a);
+    case 1: return launch_tile_fn<T, F, 1>(st, a);
+    case 2: return launch_tile_fn<T, F, 2>(st, a);
+    default:
+        if constexpr (sizeof(T) == 4) return launch_tile_fn<T, F, 3>(st, a);
+        else return hipErrorInvalidValue;          // (three levels of Float64 do not fit the 160 KiB of LDS)
     }
 }
 
-hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<float> &taps, int NL, const float *src, int64_t lds, float *y, int64_t ldy,
-                             float *ll, int64_t ldll, int M, int N)
+template <typename T>
+hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const T *src, int64_t lds, T *y, int64_t ldy,
+                             T *ll, int64_t ldll, int M, int N)
 {
     switch (taps.F) {
-    case 2: return launch_tile_f<2>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
-    case 4: return launch_tile_f<4>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
-    case 6: return launch_tile_f<6>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
-    case 8: return launch_tile_f<8>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
-    case 10: return launch_tile_f<10>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+    case 2: return launch_tile_f<T, 2>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+    case 4: return launch_tile_f<T, 4>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+    case 6: return launch_tile_f<T, 6>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+    case 8: return launch_tile_f<T, 8>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+    case 10: return launch_tile_f<T, 10>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
     default: return hipErrorInvalidValue;
     }
 }
+template hipError_t fwd2d_tile_launch<float>(hipStream_t, const Taps<float> &, int, const float *, int64_t, float *, int64_t, float *, int64_t, int,
+                                             int);
+template hipError_t fwd2d_tile_launch<double>(hipStream_t, const Taps<double> &, int, const double *, int64_t, double *, int64_t, double *, int64_t,
+                                              int, int);
 
 // ---------------------------------------------------------------------------------------------------
 // The inverse of the same sizes: TWO reconstruction levels (output M/2 x N/2, then M x N, M, N in 128 .. 1024) per launch,

@@ -549,7 +549,7 @@ bool long_lines_fwd_level(hipStream_t st, const Taps<T> &taps, const T *src, int
     if (!long_filter_ok(taps.F) || n < (vlong_filter_ok(taps.F) ? 16 : 512) || (n % 8) != 0 || !a_al16(src) || !a_al16(sdst) || !a_al16(ddst) ||
         (nlines > 1 && ((src_ls % VEC) != 0 || (s_ls % VEC) != 0 || (d_ls % VEC) != 0)))
         return false;
-    if (vlong_filter_ok(taps.F)) {
+    if (vlong_only(taps.F) || (vlong_filter_ok(taps.F) && n < 512)) {
         *err = vl_lines_fwd<T>(st, taps, src, src_ls, sdst, s_ls, ddst, d_ls, n, nlines);
         return true;
     }
@@ -571,7 +571,7 @@ bool long_lines_inv_level(hipStream_t st, const Taps<T> &taps, const T *ssrc, in
     if (!long_filter_ok(taps.F) || n < (vlong_filter_ok(taps.F) ? 16 : 512) || (n % 8) != 0 || !a_al16(ssrc) || !a_al16(dsrc) || !a_al16(dst) ||
         (nlines > 1 && ((s_ls % VEC) != 0 || (d_ls % VEC) != 0 || (o_ls % VEC) != 0)))
         return false;
-    if (vlong_filter_ok(taps.F)) {
+    if (vlong_only(taps.F) || (vlong_filter_ok(taps.F) && n < 512)) {
         *err = vl_lines_inv<T>(st, taps, ssrc, s_ls, dsrc, d_ls, dst, o_ls, n, nlines);
         return true;
     }
@@ -594,7 +594,7 @@ bool long_axis_level(hipStream_t st, const Taps<T> &taps, int fw, const T *src, 
     if (!long_filter_ok(taps.F) || (C % (vlong_filter_ok(taps.F) ? 8 : 32)) != 0 || C < (vlong_filter_ok(taps.F) ? 16 : 32) || (R % VEC) != 0 || (lds % VEC) != 0 || (ldd % VEC) != 0 ||
         !a_al16(src) || !a_al16(dst))
         return false;
-    if (vlong_filter_ok(taps.F)) {
+    if (vlong_only(taps.F) || (vlong_filter_ok(taps.F) && ((C % 32) != 0 || C < 32 || R < 512))) {
         *err = vl_axis<T>(st, taps, fw, src, lds, dst, ldd, R, C, cu_count);
         return true;
     }

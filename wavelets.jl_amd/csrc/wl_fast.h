@@ -78,6 +78,7 @@ bool long_filter_ok(int F);
 bool long_shape2d_ok(int F, int64_t n0, int64_t n1);
 // ---- odd-length / up to 64-tap filters (Battle 23, 41, 59): wl_vlong.hip ----
 bool vlong_filter_ok(int F);
+bool vlong_only(int F);
 template <typename T>
 hipError_t vl_lines_fwd(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls, T *ddst,
                         int64_t d_ls, int64_t n, int64_t nlines);

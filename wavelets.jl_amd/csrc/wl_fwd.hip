@@ -1427,7 +1427,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     if (!ok) return WL_EINVAL_ARG;      // (eligibility is identical for the three launches)
                 }
             }
-            if (done && !dominant) dominant = vlong_filter_ok(F) ? "k_vl_lines" : "k_long_lines";
+            if (done && !dominant) dominant = (vlong_only(F) || n[0] < 512) ? "k_vl_lines" : "k_long_lines";
         }
         // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
         if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {

@@ -1001,7 +1001,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     if (!ok) return WL_EINVAL_ARG;
                 }
             }
-            if (done) dominant = vlong_filter_ok(F) ? "k_vl_lines" : "k_long_lines";
+            if (done) dominant = (vlong_only(F) || n[0] < 512) ? "k_vl_lines" : "k_long_lines";
         }
         if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
             hipError_t e3 = hipSuccess;

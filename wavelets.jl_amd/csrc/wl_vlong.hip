@@ -451,13 +451,23 @@ static hipError_t launch_vl_lines(hipStream_t st, const Taps<T> &taps, VlLineArg
 // ---------------------------------------------------------------------------------------------------
 #define WL_DISPATCH_FV(F_, ...)                              \
     switch (F_) {                                            \
+    case 12: { constexpr int FF = 12; __VA_ARGS__; } break;  \
+    case 14: { constexpr int FF = 14; __VA_ARGS__; } break;  \
+    case 16: { constexpr int FF = 16; __VA_ARGS__; } break;  \
+    case 18: { constexpr int FF = 18; __VA_ARGS__; } break;  \
+    case 20: { constexpr int FF = 20; __VA_ARGS__; } break;  \
+    case 24: { constexpr int FF = 24; __VA_ARGS__; } break;  \
     case 23: { constexpr int FF = 23; __VA_ARGS__; } break;  \
     case 41: { constexpr int FF = 41; __VA_ARGS__; } break;  \
     case 59: { constexpr int FF = 59; __VA_ARGS__; } break;  \
     default: break;                                          \
     }
 
-bool vlong_filter_ok(int F) { return F == 23 || F == 41 || F == 59; }
+// instantiated lengths: the Battle-Lemarie filters (no other fast path), and the 12..24-tap families for the levels that
+// are too small for their ring kernels (wl_axis.hip: lines >= 512, axis lengths in multiples of 32)
+bool vlong_filter_ok(int F) { return F == 23 || F == 41 || F == 59 || F == 12 || F == 14 || F == 16 || F == 18 || F == 20 || F == 24; }
+// lengths that never use the ring kernels: the Battle filters, and 24 taps (measured: 8192^2 level 262 us here, 309 us there)
+bool vlong_only(int F) { return F == 23 || F == 41 || F == 59 || F == 24; }
 
 template <typename T>
 hipError_t vl_lines_fwd(hipStream_t st, const Taps<T> &taps, const T *src, int64_t src_ls, T *sdst, int64_t s_ls, T *ddst,

@@ -105,7 +105,7 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 xd = dev(W, x)
                 y = host(W, W.dwt(xd, wt, L))
                 kf = W.last_kernel()
-                assert (kf == "k_fwd_axis_stream") == (len(wt.qmf) <= 10), (n, fname, kf)
+                assert (kf == ("k_tail3" if n ** 3 <= 4096 else "k_fwd_axis_stream")) == (len(wt.qmf) <= 10), (n, fname, kf)
                 if n <= 128:
                     ye = oracle.dwt_filter(x, wt.qmf, L)
                 else:
@@ -117,7 +117,7 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 assert np.array_equal(y, ye), (n, fname, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
                 ki = W.last_kernel()
-                assert (ki == "k_inv_axis_stream") == (len(wt.qmf) <= 10), (n, fname, ki)
+                assert (ki == ("k_tail3" if n ** 3 <= 4096 else "k_inv_axis_stream")) == (len(wt.qmf) <= 10), (n, fname, ki)
                 if n <= 128:
                     xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
                 else:
@@ -314,6 +314,37 @@ def test_inverse_tile_kernel(gpu, W, oracle, dtype):
                 assert np.array_equal(xr, xe), (shape, fname, L, int((xr != xe).sum()))
                 with W.options(WL_TILE_INV=0):
                     assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname, L, "streaming")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tail3_kernel(gpu, W, oracle, dtype):
+    """k_tail3 (3-D: every remaining forward level / the deepest inverse levels of a power-of-two box <= 4096 elements in one
+    workgroup, three LDS passes per level in the reference's order): cubes and non-cubic boxes, every depth, every
+    supported filter length, alone and as the end of a larger transform -- bit for bit against the oracle and against
+    the one-thread-per-output kernels it replaces."""
+    for shape in ((16, 16, 16), (8, 8, 8), (4, 4, 4), (2, 2, 2), (16, 8, 4), (32, 8, 16), (4, 32, 32), (64, 8, 8)):
+        x = rng_array(shape, dtype, sum(shape))
+        Lmax = W.maxtransformlevels(x)
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in range(1, Lmax + 1):
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_tail3", (shape, fname, L, W.last_kernel())
+                assert np.array_equal(y, ye), (shape, fname, L)
+                xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                assert W.last_kernel() == "k_tail3", (shape, fname, L, W.last_kernel())
+                assert np.array_equal(xr, xe), (shape, fname, L, "inv")
+                with W.options(WL_TAIL3=0):
+                    assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (shape, fname, L, "generic")
+                    assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), xe), (shape, fname, L, "generic inv")
+    for shape, L in (((64, 64, 64), 6), ((128, 32, 64), 5), ((32, 32, 32), 3)):
+        x = rng_array(shape, dtype, 11)
+        wt = W.wavelet(W.WT.db4)
+        ye = oracle.dwt_filter(x, wt.qmf, L)
+        assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), shape
+        assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (shape, "inv")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -62,6 +62,12 @@ bool inv2d_tile2_ok(int F, int64_t M, int64_t N);
 template <typename T>
 hipError_t inv2d_tile2_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl, T *dst, int64_t ldd,
                               int M, int N);
+// 3-D boxes of <= 4096 elements: all remaining forward levels / the deepest inverse levels in one workgroup (wl_tail.hip)
+template <typename T>
+bool tail3_ok(int F, int64_t n0, int64_t n1, int64_t n2, int nlev);
+template <typename T>
+hipError_t launch_tail3(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t s1, int64_t s2, T *y, int64_t y1, int64_t y2,
+                        int n0, int n1, int n2, int nlev);
 template <typename T>
 bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item);
 template <typename T>

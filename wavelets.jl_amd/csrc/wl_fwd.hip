@@ -1273,6 +1273,14 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 continue;
             }
         }
+        // ---- 3-D boxes of <= 4096 elements: every remaining level in one workgroup (wl_tail.hip) ----
+        if (path == 0 && b.nd == 3 && b.nt == 3 && env_int("WL_TAIL3", 1) && b.full.s[0] == 1 && cur_st.s[0] == 1 &&
+            tail3_ok<T>(F, n[0], n[1], n[2], L - l + 1)) {
+            WL_TRY(launch_tail3<T>(st, taps, 1, cur, cur_st.s[1], cur_st.s[2], y, b.full.s[1], b.full.s[2], (int)n[0], (int)n[1], (int)n[2],
+                                   L - l + 1));
+            if (!dominant) dominant = "k_tail3";
+            break;
+        }
         // ---- LDS-resident tail: finishes every remaining level in one launch ----
         // (batches of many lines: one workgroup per line is only efficient for short lines -- longer ones take
         //  another pass of the multi-level tile kernel first)

@@ -863,6 +863,27 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             l_start = l_lo - 1;
         }
     }
+    // ---- 3-D: the deepest levels whose output is a power-of-two box of <= 4096 elements, one workgroup (wl_tail.hip) ----
+    if (path == 0 && b.nd == 3 && b.nt == 3 && i_env("WL_TAIL3", 1) != 0 && b.full.s[0] == 1 && l_start == L) {
+        int l_lo = L + 1;
+        for (int q = L; q >= 1; --q) {
+            int64_t nq[3];
+            level_box(b, q, nq);
+            if (tail3_ok<T>(F, nq[0], nq[1], nq[2], L - q + 1)) l_lo = q; else break;
+        }
+        if (l_lo <= L) {
+            int64_t nq[3];
+            level_box(b, l_lo, nq);
+            const bool to_y = (l_lo == 1);
+            T *res = to_y ? y : (pp ? w.B : w.A);
+            Strides3 res_st = to_y ? b.full : dense_strides(nq);
+            WL_TRYI(launch_tail3<T>(st, taps, 0, x, b.full.s[1], b.full.s[2], res, res_st.s[1], res_st.s[2], (int)nq[0], (int)nq[1], (int)nq[2],
+                                    L - l_lo + 1));
+            dominant = "k_tail3";
+            llsrc = res; llsrc_st = dense_strides(nq); pp ^= 1;
+            l_start = l_lo - 1;
+        }
+    }
     for (int l = l_start; l >= 1; --l) {
         int64_t n[3];
         level_box(b, l, n);

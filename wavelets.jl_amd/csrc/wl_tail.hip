@@ -379,6 +379,198 @@ template hipError_t launch_tail2_inv<float>(hipStream_t, const Taps<float> &, co
                                             int, int, int);
 template hipError_t launch_tail2_inv<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t, int,
                                              int, int, int, int);
+// ---------------------------------------------------------------------------------------------------
+// 3-D boxes: every remaining level of a power-of-two box of <= 4096 elements in one workgroup (forward), the deepest
+// levels of a reconstruction whose output is such a box (inverse).  Three dependent passes per level in the reference's
+// order (forward: planes, rows, columns -- transforms_filter.jl:246-287; inverse: the reverse), LDS <-> LDS with mask wrap;
+// replaces three one-thread-per-output launches per level.
+template <typename T, int F>
+struct Tail3Args {
+    const T *src; int64_t s1, s2;   // forward: source box; inverse: coefficient array
+    T *y; int64_t y1, y2;           // forward: coefficient array; inverse: result box
+    int lg0, lg1, lg2;              // extents 2^lg (inverse: OUTPUT extents of the last level done here)
+    int nlev;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F, int FW>
+__global__ void __launch_bounds__(512) k_tail3(Tail3Args<T, F> a)
+{
+    constexpr int NW = (F == 2) ? 2 : 2 * F - 2, SH = (F - 2) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int n0 = 1 << a.lg0, n1 = 1 << a.lg1, n2 = 1 << a.lg2;
+    const int ld1 = n0, ld2 = n0 * n1, total = n0 * n1 * n2;
+    T *A = reinterpret_cast<T *>(smem_raw);
+    T *B = A + total + 8;
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int i = idx & (n0 - 1), j = (idx >> a.lg0) & (n1 - 1), k = idx >> (a.lg0 + a.lg1);
+        A[idx] = a.src[i + (int64_t)j * a.s1 + (int64_t)k * a.s2];
+    }
+    lds_barrier_vm();
+    // one pass along the dimension with element stride `st` (m pairs... see callers): thread = (pair p, the two other indices)
+    if (FW) {
+        for (int lev = 0; lev < a.nlev; ++lev) {
+            const bool last = (lev == a.nlev - 1);
+            const int l0 = a.lg0 - lev, l1 = a.lg1 - lev, l2 = a.lg2 - lev;
+            const int m0 = 1 << l0, m1 = 1 << l1, m2 = 1 << l2, h0 = m0 >> 1, h1 = m1 >> 1, h2 = m2 >> 1;
+            // dim 3: A -> B
+            for (int idx = tid; idx < m0 * m1 * h2; idx += nthr) {
+                const int i = idx & (m0 - 1), j = (idx >> l0) & (m1 - 1), p = idx >> (l0 + l1);
+                const T *q = A + i + j * ld1;
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW; ++e) xv[e] = q[((2 * p - (F - 2) + e) & (m2 - 1)) * ld2];
+                T sv, dv;
+                window_sd<T, F>(xv, a.tp, sv, dv);
+                B[i + j * ld1 + p * ld2] = sv;
+                B[i + j * ld1 + (h2 + p) * ld2] = dv;
+            }
+            lds_barrier();
+            // dim 2: B -> A
+            for (int idx = tid; idx < m0 * h1 * m2; idx += nthr) {
+                const int i = idx & (m0 - 1), p = (idx >> l0) & (h1 - 1), k = idx >> (l0 + l1 - 1);
+                const T *q = B + i + k * ld2;
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW; ++e) xv[e] = q[((2 * p - (F - 2) + e) & (m1 - 1)) * ld1];
+                T sv, dv;
+                window_sd<T, F>(xv, a.tp, sv, dv);
+                A[i + p * ld1 + k * ld2] = sv;
+                A[i + (h1 + p) * ld1 + k * ld2] = dv;
+            }
+            lds_barrier();
+            // dim 1: A -> details to y, the approximation octant to B (next level's input) or y
+            for (int idx = tid; idx < h0 * m1 * m2; idx += nthr) {
+                const int p = idx & (h0 - 1), j = (idx >> (l0 - 1)) & (m1 - 1), k = idx >> (l0 - 1 + l1);
+                const T *q = A + j * ld1 + k * ld2;
+                T xv[NW];
+#pragma unroll
+                for (int e = 0; e < NW; ++e) xv[e] = q[(2 * p - (F - 2) + e) & (m0 - 1)];
+                T sv, dv;
+                window_sd<T, F>(xv, a.tp, sv, dv);
+                T *yc = a.y + (int64_t)j * a.y1 + (int64_t)k * a.y2;
+                yc[h0 + p] = dv;
+                if (!last && j < h1 && k < h2) B[p + j * ld1 + k * ld2] = sv;
+                else yc[p] = sv;
+            }
+            lds_barrier();
+            T *t = A; A = B; B = t;                       // the approximation octant sits in the corner of the new A
+        }
+    } else {
+        for (int t = 0; t < a.nlev; ++t) {
+            const bool last = (t == a.nlev - 1);
+            const int sft = a.nlev - 1 - t;
+            const int l0 = a.lg0 - sft, l1 = a.lg1 - sft, l2 = a.lg2 - sft;
+            const int o0 = 1 << l0, o1 = 1 << l1, o2 = 1 << l2, h0 = o0 >> 1, h1 = o1 >> 1, h2 = o2 >> 1;
+            // dim 1: A -> B
+            for (int idx = tid; idx < h0 * o1 * o2; idx += nthr) {
+                const int p = idx & (h0 - 1), j = (idx >> (l0 - 1)) & (o1 - 1), k = idx >> (l0 - 1 + l1);
+                const T *sp = A + j * ld1 + k * ld2, *dp = sp + h0;
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[(p - SH + q) & (h0 - 1)]; dw[q] = dp[(p + q) & (h0 - 1)]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                B[2 * p + j * ld1 + k * ld2] = xe;
+                B[2 * p + 1 + j * ld1 + k * ld2] = xo;
+            }
+            lds_barrier();
+            // dim 2: B -> A (in place over the octants just consumed)
+            for (int idx = tid; idx < o0 * h1 * o2; idx += nthr) {
+                const int i = idx & (o0 - 1), p = (idx >> l0) & (h1 - 1), k = idx >> (l0 + l1 - 1);
+                const T *sp = B + i + k * ld2, *dp = sp + h1 * ld1;
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[((p - SH + q) & (h1 - 1)) * ld1]; dw[q] = dp[((p + q) & (h1 - 1)) * ld1]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                A[i + (2 * p) * ld1 + k * ld2] = xe;
+                A[i + (2 * p + 1) * ld1 + k * ld2] = xo;
+            }
+            lds_barrier();
+            // dim 3: A -> B (or the result array)
+            for (int idx = tid; idx < o0 * o1 * h2; idx += nthr) {
+                const int i = idx & (o0 - 1), j = (idx >> l0) & (o1 - 1), p = idx >> (l0 + l1);
+                const T *sp = A + i + j * ld1, *dp = sp + h2 * ld2;
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int q = 0; q <= SH; ++q) { sw[q] = sp[((p - SH + q) & (h2 - 1)) * ld2]; dw[q] = dp[((p + q) & (h2 - 1)) * ld2]; }
+                T xe, xo;
+                window_inv<T, F>(sw, dw, a.tp, xe, xo);
+                if (last) {
+                    a.y[i + (int64_t)j * a.y1 + (int64_t)(2 * p) * a.y2] = xe;
+                    a.y[i + (int64_t)j * a.y1 + (int64_t)(2 * p + 1) * a.y2] = xo;
+                } else {
+                    B[i + j * ld1 + (2 * p) * ld2] = xe;
+                    B[i + j * ld1 + (2 * p + 1) * ld2] = xo;
+                }
+            }
+            lds_barrier();
+            if (!last) {                                   // the reconstruction becomes the approximation octant of the next level
+                for (int idx = tid; idx < o0 * o1 * o2; idx += nthr) {
+                    const int i = idx & (o0 - 1), j = (idx >> l0) & (o1 - 1), k = idx >> (l0 + l1);
+                    A[i + j * ld1 + k * ld2] = B[i + j * ld1 + k * ld2];
+                }
+                lds_barrier();
+            }
+        }
+    }
+}
+
+template <typename T>
+bool tail3_ok(int F, int64_t n0, int64_t n1, int64_t n2, int nlev)
+{
+    if (F < 2 || F > 10 || (F & 1)) return false;
+    auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
+    if (!pow2(n0) || !pow2(n1) || !pow2(n2) || n0 * n1 * n2 > 4096) return false;
+    int lg0 = 0, lg1 = 0, lg2 = 0;
+    while (((int64_t)1 << lg0) < n0) ++lg0;
+    while (((int64_t)1 << lg1) < n1) ++lg1;
+    while (((int64_t)1 << lg2) < n2) ++lg2;
+    return nlev >= 1 && nlev <= lg0 && nlev <= lg1 && nlev <= lg2;
+}
+
+template <typename T, int F, int FW>
+static hipError_t launch_tail3_f(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, int64_t s2, T *y, int64_t y1, int64_t y2,
+                                 int n0, int n1, int n2, int nlev)
+{
+    Tail3Args<T, F> a;
+    a.src = src; a.s1 = s1; a.s2 = s2; a.y = y; a.y1 = y1; a.y2 = y2; a.nlev = nlev;
+    a.lg0 = a.lg1 = a.lg2 = 0;
+    while ((1 << a.lg0) < n0) ++a.lg0;
+    while ((1 << a.lg1) < n1) ++a.lg1;
+    while ((1 << a.lg2) < n2) ++a.lg2;
+    a.tp = shrink<T, F>(taps);
+    const int total = n0 * n1 * n2;
+    const size_t shmem = (2 * (size_t)total + 16) * sizeof(T);
+    const int threads = total >= 2048 ? 512 : (total >= 512 ? 256 : 64);
+    hipError_t ea = tail2_lds_attr(reinterpret_cast<const void *>(&k_tail3<T, F, FW>), shmem);
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL((k_tail3<T, F, FW>), dim3(1), dim3(threads), shmem, st, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_tail3(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t s1, int64_t s2, T *y, int64_t y1, int64_t y2,
+                        int n0, int n1, int n2, int nlev)
+{
+#define WL_T3(FF_)                                                                                                        \
+    case FF_: return fw ? launch_tail3_f<T, FF_, 1>(st, taps, src, s1, s2, y, y1, y2, n0, n1, n2, nlev)                   \
+                        : launch_tail3_f<T, FF_, 0>(st, taps, src, s1, s2, y, y1, y2, n0, n1, n2, nlev);
+    switch (taps.F) {
+        WL_T3(2) WL_T3(4) WL_T3(6) WL_T3(8) WL_T3(10)
+    default: return hipErrorInvalidValue;
+    }
+#undef WL_T3
+}
+template bool tail3_ok<float>(int, int64_t, int64_t, int64_t, int);
+template bool tail3_ok<double>(int, int64_t, int64_t, int64_t, int);
+template hipError_t launch_tail3<float>(hipStream_t, const Taps<float> &, int, const float *, int64_t, int64_t, float *, int64_t, int64_t, int, int,
+                                        int, int);
+template hipError_t launch_tail3<double>(hipStream_t, const Taps<double> &, int, const double *, int64_t, int64_t, double *, int64_t, int64_t, int,
+                                         int, int, int);
+
 template bool tail2_ok<float>(int, int, int64_t, int64_t, int);
 template bool tail2_ok<double>(int, int, int64_t, int64_t, int);
 template hipError_t launch_tail2<float>(hipStream_t, const Taps<float> &, const float *, int64_t, float *, int64_t, int64_t, int64_t, int, int, int,

@@ -638,16 +638,30 @@ def test_lifting_register_tail(gpu, W, oracle, dtype):
                 t = dev(W, x)
                 W.dwt_(t, sch, L)
                 assert np.array_equal(host(W, t), ye), (n, sname, L, "in place")
+                # the inverse register tail (k_tail_lift_reg_inv) takes the levels whose deepest approximation is <= 64 samples
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                xr = host(W, W.idwt(dev(W, ye), sch, L))
+                if (n >> L) <= 64:
+                    assert W.last_kernel() == "k_tail_lift_reg_inv", (n, sname, L, W.last_kernel())
+                assert np.array_equal(xr, xe), (n, sname, L, "inv")
+                t = dev(W, ye)
+                W.idwt_(t, sch, L)
+                assert np.array_equal(host(W, t), xe), (n, sname, L, "inv in place")
         n *= 2
     sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
     for shape, L in (((1024, 40), 10), ((4096 if dtype == np.float32 else 2048, 5), 7), ((64, 33), 6), ((1 << 15, 24), 15)):
         xb = rng_array(shape, dtype, shape[1])
         assert np.array_equal(host(W, W.dwtc(dev(W, xb), sch, L)), oracle.dwtc_lifting(xb, sch, L)), shape
+        yb = oracle.dwtc_lifting(xb, sch, L)
+        assert np.array_equal(host(W, W.idwtc(dev(W, yb), sch, L)), oracle.dwtc_lifting(yb, sch, L, fw=False)), (shape, "inv")
     x = rng_array((1 << 20,), dtype, 3)
     ye = oracle.dwt_lifting(x, sch, 20)
+    xe = oracle.dwt_lifting(ye, sch, 20, fw=False)
     assert np.array_equal(host(W, W.dwt(dev(W, x), sch, 20)), ye)
+    assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, 20)), xe)
     W.set_option("WL_LIFT_REGTAIL", 0)
     assert np.array_equal(host(W, W.dwt(dev(W, x), sch, 20)), ye)
+    assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, 20)), xe)
     xs = rng_array((2048,), dtype, 9)
     y0 = host(W, W.dwt(dev(W, xs), sch, 11))
     assert W.last_kernel() == "k_tail_lift" and np.array_equal(y0, oracle.dwt_lifting(xs, sch, 11))

@@ -33,6 +33,11 @@ elif case == "idwt2d_f64":
     x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
     y = W.similar(x)
     fn = lambda: W.idwt_oop_(y, x, db4, 13)
+elif case == "lift1d_inv":
+    x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.idwt_oop_(y, x, sch, 24)
 elif case == "dwt3d":
     x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
     y = W.similar(x)

@@ -705,6 +705,86 @@ __global__ void __launch_bounds__(64) k_tail_lift_reg(LiftRegArgs<T> a)
 #undef WL_REG_CASE
 }
 
+// The inverse of the register tail: the deepest `nlev` levels of a reconstruction whose last output here is a power-of-two
+// line of n0 <= 4096 / 2048 samples, one wave.  Levels run from the short end: one sample per lane (ds_bpermute operands,
+// merge! = a gather) up to 64 samples, then a lane's merged pairs (s[j], d[j]) ARE the next level's approximation values
+// PPL' = 2 PPL -- nothing moves between lanes except the rotating-DPP step operands; details come straight from the
+// coefficient line.  normalize! -> steps -> merge! per level, as the reference (transforms_lifting.jl:57-72).
+template <typename T, int ID, int PPL>
+__device__ __forceinline__ void lift_reg_up(T (&s)[PPL], const LiftRegArgs<T> &a, const T *src, T *out, int lane)
+{
+    constexpr int half = 64 * PPL, m = 2 * half;
+    T d[PPL];
+    ldv_l<T, PPL>(src + half + PPL * lane, d);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { s[j] = a.norm1 * s[j]; d[j] = a.norm2 * d[j]; }
+    lift_steps_wave<T, ID, PPL>(s, d, a.c, lane);
+    T x[2 * PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { x[2 * j] = s[j]; x[2 * j + 1] = d[j]; }
+    if (a.n0 == m) { stv_l<T, 2 * PPL>(out + 2 * PPL * lane, x); return; }
+    if constexpr (2 * PPL <= (sizeof(T) == 4 ? 32 : 16)) lift_reg_up<T, ID, 2 * PPL>(x, a, src, out, lane);
+}
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(64) k_tail_lift_reg_inv(LiftRegArgs<T> a)
+{
+    typedef Shape<ID> SH;
+    const int lane = threadIdx.x;
+    const T *src = a.src + (int64_t)blockIdx.x * a.src_item;       // coefficient line
+    T *out = a.y + (int64_t)blockIdx.x * a.y_item;                 // reconstruction of length n0
+    const int n = a.n0, mstart = n >> a.nlev;                      // deepest approximation: mstart <= 64 samples
+    T v = (lane < mstart) ? src[lane] : (T)0;
+    const int msmall = n < 64 ? n : 64;
+    for (int m = 2 * mstart; m <= msmall; m <<= 1) {
+        const int half = m >> 1;
+        T sv = a.norm1 * v;
+        T dv = a.norm2 * ((lane < half) ? src[half + lane] : (T)0);
+#pragma unroll
+        for (int st = 0; st < SH::NS; ++st) {
+            const int upd = SH::S[st].upd, nc = SH::S[st].nc, sh = SH::S[st].sh;
+            const T opv = upd ? sv : dv;
+            T o[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                o[kk] = (T)0;
+                if (kk < nc) o[kk] = l_gather(opv, (lane + kk - sh) & (half - 1));
+            }
+            const int jg = lane - sh;
+            const bool inb = (jg >= 0) && (jg + nc - 1 <= half - 1);
+            const T x = upd ? dv : sv;
+            T acc = a.c[st][0] * o[0];
+            if (nc > 1) acc = acc + a.c[st][1] * o[1];
+            if (nc > 2) acc = acc + a.c[st][2] * o[2];
+            const T xin = x + acc;
+            T xb = x + a.c[st][0] * o[0];
+            if (nc > 1) xb = xb + a.c[st][1] * o[1];
+            if (nc > 2) xb = xb + a.c[st][2] * o[2];
+            const T r = inb ? xin : xb;
+            if (upd) dv = r; else sv = r;
+        }
+        const T gs = l_gather(sv, lane >> 1), gd = l_gather(dv, lane >> 1);        // Util.merge!
+        v = (lane & 1) ? gd : gs;
+    }
+    if (n <= 64) {
+        if (lane < n) out[lane] = v;
+        return;
+    }
+    T s1[1] = {v};
+    lift_reg_up<T, ID, 1>(s1, a, src, out, lane);
+}
+
+template <typename T>
+static bool lift_reg_inv_ok(int id, int64_t n0, int nlev, const T *src, int64_t src_item, const T *out, int64_t out_item)
+{
+    if (id != 1 && id != 3 && id != 5) return false;                       // inverse shapes
+    if (n0 < 2 || (n0 & (n0 - 1)) != 0 || n0 > (sizeof(T) == 4 ? 4096 : 2048)) return false;
+    if (nlev < 1 || ((int64_t)1 << nlev) > n0 || (n0 >> nlev) > 64) return false;
+    constexpr int VEC = 16 / sizeof(T);
+    if (n0 > 64 && ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (src_item % VEC) || (out_item % VEC))) return false;
+    return true;
+}
+
 template <typename T>
 static bool lift_reg_ok(int id, int64_t n, int nlev, const T *src, int64_t src_item, const T *y, int64_t y_item)
 {
@@ -1185,7 +1265,9 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     int cap = (nlines >= 32) ? lift_tail_cap<T>() : 2048;
     // known forward shapes on power-of-two lines: the single-wave register tail takes over at 4096 / 2048 samples
     const bool reg_tail = fw && l_env("WL_LIFT_REGTAIL", 1) && (id == 0 || id == 2 || id == 4) && (n & (n - 1)) == 0;
-    if (reg_tail) cap = (sizeof(T) == 4) ? 4096 : 2048;
+    const bool reg_tail_inv = !fw && l_env("WL_LIFT_REGTAIL", 1) && (id == 1 || id == 3 || id == 5) && (n & (n - 1)) == 0 &&
+                              (n >> L) <= 64;
+    if (reg_tail || reg_tail_inv) cap = (sizeof(T) == 4) ? 4096 : 2048;
     // every level must be either stream-able (known shape, n_l >= 512, n_l % 8 == 0) or inside the tail
     int l_tail = L + 1;                       // first level (1-based) handled by the tail (fw) ...
     for (int l = 1; l <= L; ++l) {
@@ -1299,7 +1381,25 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
         int l_hi = L;                        // tail covers levels L .. l_lo
         int l_lo = L + 1;
         for (int q = L; q >= 1; --q) { if ((n >> (q - 1)) <= cap) l_lo = q; else break; }
-        if (l_lo <= L) {
+        if (l_lo <= L && l_env("WL_LIFT_REGTAIL", 1) != 0 &&
+            lift_reg_inv_ok<T>(id, n >> (l_lo - 1), L - l_lo + 1, x, ld, (l_lo == 1) ? y : (pp ? w.B : w.A), (l_lo == 1) ? ld : (n >> (l_lo - 1)))) {
+            // known inverse shapes on power-of-two lines: the single-wave register tail
+            const int64_t nout = n >> (l_lo - 1);
+            const bool to_y = (l_lo == 1);
+            T *out = to_y ? y : (pp ? w.B : w.A);
+            LiftRegArgs<T> r;
+            r.src = x; r.src_item = ld; r.y = out; r.y_item = to_y ? ld : nout; r.n0 = (int)nout; r.nlev = L - l_lo + 1;
+            for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+                for (int k = 0; k < WL_MAX_NCOEF; ++k) r.c[i][k] = a.c[i][k];
+            r.norm1 = a.norm1; r.norm2 = a.norm2;
+            if (id == 1) hipLaunchKernelGGL((k_tail_lift_reg_inv<T, 1>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            else if (id == 3) hipLaunchKernelGGL((k_tail_lift_reg_inv<T, 3>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            else hipLaunchKernelGGL((k_tail_lift_reg_inv<T, 5>), dim3((unsigned)nlines), dim3(64), 0, st, r);
+            WL_CHECK_LAUNCH();
+            if (!dom) dom = "k_tail_lift_reg_inv";
+            llsrc = out; ll_ls = r.y_item; pp ^= 1;
+            l = l_lo - 1;
+        } else if (l_lo <= L) {
             LiftTailArgs<T> t;
             const int64_t nout = n >> (l_lo - 1);
             const bool to_y = (l_lo == 1);

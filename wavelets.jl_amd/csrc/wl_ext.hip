@@ -749,55 +749,88 @@ __device__ __forceinline__ void ti_shift_of(const TiGeom &g, int64_t spin0, int6
 template <typename T>
 __global__ void __launch_bounds__(256) k_ti_shift(T *__restrict__ Z, const T *__restrict__ x, TiGeom g)
 {
-    const int64_t b = blockIdx.z, i1 = blockIdx.y;
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    const int64_t b = blockIdx.z;
     int64_t s0, s1;
     ti_shift_of(g, g.b0 + b, s0, s1);
-    int64_t j1 = i1 - s1;
-    if (j1 < 0) j1 += g.n1;
-    const T *src = x + g.n0 * j1;
-    T *dst = Z + b * g.N + g.n0 * i1;
-    for (int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i0 < g.n0; i0 += 4 * (int64_t)gridDim.x * blockDim.x) {
-        T v[4];
+    const int n0 = (int)g.n0, sh = (int)s0;
+    const bool vec = (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(Z) % (4 * sizeof(T))) == 0;
+    // eight columns per workgroup (a workgroup per column is a single 16-byte store per thread: launch-rate bound)
+    for (int64_t i1 = (int64_t)blockIdx.y * 8; i1 < g.n1 && i1 < (int64_t)blockIdx.y * 8 + 8; ++i1) {
+        int64_t j1 = i1 - s1;
+        if (j1 < 0) j1 += g.n1;
+        const T *src = x + g.n0 * j1;
+        T *dst = Z + b * g.N + g.n0 * i1;
+        for (int i0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); i0 < n0; i0 += 4 * (int)(gridDim.x * blockDim.x)) {
+            T v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int64_t j0 = i0 + e - s0;
-            if (j0 < 0) j0 += g.n0;
-            v[e] = (i0 + e < g.n0) ? src[j0] : (T)0;
-        }
-        if (i0 + 3 < g.n0 && (g.n0 & 3) == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[i0 + e] = v[e];
-        } else {
-            for (int e = 0; e < 4 && i0 + e < g.n0; ++e) dst[i0 + e] = v[e];
+            for (int e = 0; e < 4; ++e) {
+                int j0 = i0 + e - sh;
+                if (j0 < 0) j0 += n0;
+                v[e] = (i0 + e < n0) ? src[j0] : (T)0;
+            }
+            if (vec) {
+                *reinterpret_cast<V4 *>(dst + i0) = V4{v[0], v[1], v[2], v[3]};
+            } else {
+                for (int e = 0; e < 4 && i0 + e < n0; ++e) dst[i0 + e] = v[e];
+            }
         }
     }
 }
 // y += circshift(Z[b], -shift(b0 + b)) for b = 0 .. nb-1 IN THAT ORDER (arrayadd! once per spin: the summation order
-// of the reference, so the sums carry the same roundings).  grid: x = groups of 4 rows, y = column.
+// of the reference, so the sums carry the same roundings).  grid: x = groups of 4 rows, y = column.  The shifts of the
+// batch sit in LDS (no integer division per spin and lane); the spins are read eight at a time, loads before the adds.
 template <typename T>
 __global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const T *__restrict__ Z, TiGeom g, int64_t nb, int first)
 {
-    const int64_t i1 = blockIdx.y;
-    for (int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i0 < g.n0; i0 += 4 * (int64_t)gridDim.x * blockDim.x) {
-        T acc[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = (first || i0 + e >= g.n0) ? (T)0 : y[i0 + e + g.n0 * i1];
-        for (int64_t b = 0; b < nb; ++b) {
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    __shared__ int sh0[256], sh1[256];
+    const int n0 = (int)g.n0, n1 = (int)g.n1, i1 = (int)blockIdx.y;
+    const bool vec = (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T))) == 0;
+    for (int64_t bb0 = 0; bb0 < nb; bb0 += 256) {
+        const int nbb = (int)((nb - bb0 < 256) ? (nb - bb0) : 256);
+        __syncthreads();
+        if ((int)threadIdx.x < nbb) {
             int64_t s0, s1;
-            ti_shift_of(g, g.b0 + b, s0, s1);
-            int64_t j1 = i1 + s1;
-            if (j1 >= g.n1) j1 -= g.n1;
-            const T *zp = Z + b * g.N + g.n0 * j1;
+            ti_shift_of(g, g.b0 + bb0 + threadIdx.x, s0, s1);
+            sh0[threadIdx.x] = (int)s0;
+            sh1[threadIdx.x] = (int)s1;
+        }
+        __syncthreads();
+        for (int i0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); i0 < n0; i0 += 4 * (int)(gridDim.x * blockDim.x)) {
+            T acc[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int64_t j0 = i0 + e + s0;
-                if (j0 >= g.n0) j0 -= g.n0;
-                if (i0 + e < g.n0) acc[e] = acc[e] + zp[j0];
+            for (int e = 0; e < 4; ++e) acc[e] = ((first && bb0 == 0) || i0 + e >= n0) ? (T)0 : y[i0 + e + (int64_t)n0 * i1];
+            for (int b8 = 0; b8 < nbb; b8 += 8) {
+                T v[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (b8 + u < nbb) {
+                        int j1 = i1 + sh1[b8 + u];
+                        if (j1 >= n1) j1 -= n1;
+                        const T *zp = Z + (bb0 + b8 + u) * g.N + (int64_t)n0 * j1;
+                        const int s = sh0[b8 + u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int j0 = i0 + e + s;
+                            if (j0 >= n0) j0 -= n0;
+                            v[u][e] = (i0 + e < n0) ? zp[j0] : (T)0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b8 + u < nbb) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[u][e];
+                    }
+            }
+            if (vec) {
+                *reinterpret_cast<V4 *>(y + i0 + (int64_t)n0 * i1) = V4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
+                for (int e = 0; e < 4 && i0 + e < n0; ++e) y[i0 + e + (int64_t)n0 * i1] = acc[e];
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (i0 + e < g.n0) y[i0 + e + g.n0 * i1] = acc[e];
     }
 }
 // threshold!(x, TH, sigma * t_unit) with sigma = mad / 0.6745 read from the device (noisest, denoising.jl:92-101): the
@@ -881,7 +914,7 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
         bb.full = dense_strides(bb.dims);
         {
             const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
-            hipLaunchKernelGGL((k_ti_shift<T>), dim3(gx, (unsigned)n1, (unsigned)nb), dim3(256), 0, st, Z, x, g);
+            hipLaunchKernelGGL((k_ti_shift<T>), dim3(gx, (unsigned)((n1 + 7) / 8), (unsigned)nb), dim3(256), 0, st, Z, x, g);
         }
         rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
         if (rc != WL_OK) return rc;

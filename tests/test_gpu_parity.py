@@ -317,6 +317,43 @@ def test_inverse_tile_kernel(gpu, W, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_any_even_size_tile_kernels(gpu, W, oracle, dtype):
+    """k_fwd2d_gtile / k_inv2d_gtile (one 2-D level of ANY even extents per launch: 64 x 64 LDS tiles with a two-sided halo,
+    periodic wrap by compare-and-subtract, clipped edges) -- the path of image-like shapes whose levels the streaming / tile /
+    tail kernels decline: odd multiples of 2, 4, 6 ..., blocks smaller than a tile, blocks shorter than the filter, partial
+    edge tiles; every filter length, forward and inverse, alone and below streaming levels -- bit for bit against the oracle
+    and against the one-thread-per-output kernels they replace."""
+    shapes = (((270, 480), (1,)), ((540, 960), (1, 2)), ((1080, 1920), (3,)), ((1000, 1000), (1, 3)), ((6, 10), (1,)), ((2, 2), (1,)),
+              ((2, 130), (1,)), ((66, 62), (1,)), ((130, 258), (1,)), ((100, 36), (2,)), ((1260, 700), (2,)), ((24, 40), (3,)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, dtype, sum(shape))
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            if shape[0] * shape[1] > 600000 and fname in ("db2", "db3"):
+                continue
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                kf = W.last_kernel()
+                assert np.array_equal(y, ye), (shape, fname, L, kf, int((y != ye).sum()))
+                xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                ki = W.last_kernel()
+                assert np.array_equal(xr, xe), (shape, fname, L, ki, "inv")
+                assert "generic" not in kf and "generic" not in ki, (shape, fname, L, kf, ki)
+                with W.options(WL_GTILE=0):
+                    assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (shape, fname, L, "generic")
+                    assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), xe), (shape, fname, L, "generic inv")
+    for shape in ((270, 480), (130, 258), (1260, 700)):        # (blocks of <= 4096 elements go to the one-workgroup tails)
+        x = rng_array(shape, dtype, 5)
+        wt = W.wavelet(W.WT.db4)
+        W.dwt(dev(W, x), wt, 1)
+        assert W.last_kernel() == "k_fwd2d_gtile", (shape, W.last_kernel())
+        W.idwt(dev(W, x), wt, 1)
+        assert W.last_kernel() == "k_inv2d_gtile", (shape, W.last_kernel())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_tail3_kernel(gpu, W, oracle, dtype):
     """k_tail3 (3-D: every remaining forward level / the deepest inverse levels of a power-of-two box <= 4096 elements in one
     workgroup, three LDS passes per level in the reference's order): cubes and non-cubic boxes, every depth, every

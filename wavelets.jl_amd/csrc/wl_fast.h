@@ -56,6 +56,11 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const 
                              int64_t ldll, int M, int N);
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
+// one 2-D level of any even extents (wl_gtile.hip)
+bool gtile_ok(int F, int64_t M, int64_t N);
+template <typename T>
+hipError_t gtile_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t lds, T *y, int64_t ldy, T *ll, int64_t ldll,
+                        int M, int N);
 // two inverse 2-D levels of a cache-resident block per launch (wl_tile.hip)
 template <typename T>
 bool inv2d_tile2_ok(int F, int64_t M, int64_t N);

@@ -1446,6 +1446,12 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             WL_TRY(e3);
             if (done && !dominant) dominant = "k_fwd_axis_stream";
         }
+        // ---- 2-D level of any even extents, F <= 10: one LDS-tile launch instead of two generic passes (wl_gtile.hip) ----
+        if (!done && fastF && two_d && path == 0 && env_int("WL_GTILE", 1) && b.full.s[0] == 1 && cur_st.s[0] == 1 && gtile_ok(F, n[0], n[1])) {
+            WL_TRY(gtile_launch<T>(st, taps, 1, cur, cur_st.s[1], y, b.full.s[1], last ? (T *)nullptr : llbuf, ll_st.s[1], (int)n[0], (int)n[1]));
+            if (!dominant) dominant = "k_fwd2d_gtile";
+            done = true;
+        }
         // ---- generic level (any rank / size / filter) ----
         if (!done) {
             if (b.nt > 1 && !w.T0) return WL_RETRY_GEN;

@@ -71,20 +71,38 @@ k_generic_fwd_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
             continue;
         }
         // both branches walk the line upwards one sample per tap: one modulo for the start, then a conditional wrap
-        // (64-bit % is an emulated division on the GPU; a line shorter than the filter simply wraps several times)
+        // (64-bit % is an emulated division on the GPU; a line shorter than the filter simply wraps several times).
+        // Taps are taken in blocks of 8 with the block's loads issued before its arithmetic: with one dependent load per tap
+        // a pass over a 270 x 480 block took 19 us of pure memory latency.
         // scaling branch: m ascending, samples 2k, 2k+1, ...
         int64_t idx = 2 * k;                                  // < nax
         T s = taps.h[0] * p[idx * sa];
-        for (int m = 1; m < F; ++m) {
-            if (++idx == nax) idx = 0;
-            s = s + taps.h[m] * p[idx * sa];
+        for (int m0 = 1; m0 < F; m0 += 8) {
+            T xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 + e < F) {
+                    if (++idx == nax) idx = 0;
+                    xv[e] = p[idx * sa];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 + e < F) s = s + taps.h[m0 + e] * xv[e];
         }
         // detail branch: m descending, samples 2k+1-(F-1), ..., 2k+1
         idx = pmod(2 * k + 1 - (F - 1), nax);
         T dd = taps.g[F - 1] * p[idx * sa];
-        for (int m = F - 2; m >= 0; --m) {
-            if (++idx == nax) idx = 0;
-            dd = dd + taps.g[m] * p[idx * sa];
+        for (int m0 = F - 2; m0 >= 0; m0 -= 8) {
+            T xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 - e >= 0) {
+                    if (++idx == nax) idx = 0;
+                    xv[e] = p[idx * sa];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m0 - e >= 0) dd = dd + taps.g[m0 - e] * xv[e];
         }
 
         int64_t off_s = 0, off_d = 0;
@@ -140,24 +158,40 @@ k_generic_inv_filter(Taps<T> taps, const T *__restrict__ src, Strides3 sst,
         // One modulo for the start of S (it may be negative), conditional wraps afterwards.
         T S = (T)0, D = (T)0;
         {
-            int m = (((F - 1 - o) & 1) == 0) ? F - 1 : F - 2;
-            if (m >= 0) {
-                int64_t k = pmod((o - m) / 2, nx);            // (o - m) even => exact
-                S = taps.h[m] * ps[k * ss];
-                for (m -= 2; m >= 0; m -= 2) {
-                    if (++k == nx) k = 0;
-                    S = S + taps.h[m] * ps[k * ss];
+            const int mt = (((F - 1 - o) & 1) == 0) ? F - 1 : F - 2;
+            if (mt >= 0) {
+                int64_t k = pmod((o - mt) / 2, nx);           // (o - mt) even => exact
+                S = taps.h[mt] * ps[k * ss];
+                for (int m0 = mt - 2; m0 >= 0; m0 -= 16) {    // blocks of 8 terms, loads before arithmetic (see the forward kernel)
+                    T xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 - 2 * e >= 0) {
+                            if (++k == nx) k = 0;
+                            xv[e] = ps[k * ss];
+                        }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 - 2 * e >= 0) S = S + taps.h[m0 - 2 * e] * xv[e];
                 }
             }
         }
         {
-            int m = (o & 1) ? 0 : 1;
-            if (m < F) {
-                int64_t k = (o + m - 1) / 2;                  // in [0, nx)
-                D = taps.g[m] * pd[k * sd];
-                for (m += 2; m < F; m += 2) {
-                    if (++k == nx) k = 0;
-                    D = D + taps.g[m] * pd[k * sd];
+            const int mb = (o & 1) ? 0 : 1;
+            if (mb < F) {
+                int64_t k = (o + mb - 1) / 2;                 // in [0, nx)
+                D = taps.g[mb] * pd[k * sd];
+                for (int m0 = mb + 2; m0 < F; m0 += 16) {
+                    T xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 + 2 * e < F) {
+                            if (++k == nx) k = 0;
+                            xv[e] = pd[k * sd];
+                        }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m0 + 2 * e < F) D = D + taps.g[m0 + 2 * e] * xv[e];
                 }
             }
         }

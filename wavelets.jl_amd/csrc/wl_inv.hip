@@ -1032,6 +1032,13 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             WL_TRYI(e3);
             if (done) dominant = "k_inv_axis_stream";
         }
+        // ---- 2-D level of any even extents, F <= 10: one LDS-tile launch instead of two generic passes (wl_gtile.hip) ----
+        if (!done && fastF && two_d && path == 0 && i_env("WL_GTILE", 1) && b.full.s[0] == 1 && res_st.s[0] == 1 && gtile_ok(F, n[0], n[1])) {
+            WL_TRYI(gtile_launch<T>(st, taps, 0, x, b.full.s[1], res, res_st.s[1], const_cast<T *>(llsrc), llsrc ? llsrc_st.s[1] : 0, (int)n[0],
+                                    (int)n[1]));
+            dominant = "k_inv2d_gtile";
+            done = true;
+        }
         if (!done) {
             if (b.nt > 1 && !w.T0) return WL_RETRY_GEN;
             const T *in = x;

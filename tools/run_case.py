@@ -46,6 +46,11 @@ elif case == "img1080_inv":
     x = torch.randn(1920, 1080, generator=g, dtype=torch.float32).cuda().t()
     y = W.similar(x)
     fn = lambda: W.idwt_oop_(y, x, db4, 3)
+elif case == "lift1d_1e6":
+    x = torch.randn(1000000, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.dwt_oop_(y, x, sch, 6)
 elif case == "dwt3d":
     x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
     y = W.similar(x)

@@ -738,6 +738,38 @@ def test_lifting_register_tail_2d(gpu, W, oracle, dtype):
             assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), oracle.dwt_lifting(ye, sch, L, fw=False)), (sname, n, L, "inv")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_any_even_size_tile_kernel(gpu, W, oracle, dtype):
+    """k_lift2d_gtile (one 2-D lifting level of ANY even size per launch: one wave per 64 x 64 tile, a lane holds a tile row /
+    column in registers, halo = the scheme's dependency cone, in-bounds / boundary summation forms selected by the global
+    position): sizes that are not multiples of 8, blocks barely larger than a tile, partial edge tiles, levels below the
+    streaming kernels of a larger transform; the three scheme shapes, forward and inverse -- bit for bit against the oracle
+    and against the one-thread-per-element kernels it replaces."""
+    for sname in ("cdf97", "db2", "haar"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        for n, Ls in ((66, (1,)), (100, (1, 2)), (130, (1,)), (250, (1,)), (500, (1, 2)), (1000, (3,)), (132, (2,)), (3000, (3,)), (72, (3,))):
+            if n >= 3000 and (sname != "cdf97" or dtype == np.float64):
+                continue
+            x = rng_array((n, n), dtype, n + len(sname))
+            for L in Ls:
+                ye = oracle.dwt_lifting(x, sch, L)
+                y = host(W, W.dwt(dev(W, x), sch, L))
+                assert np.array_equal(y, ye), (sname, n, L, W.last_kernel(), int((y != ye).sum()))
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                xr = host(W, W.idwt(dev(W, ye), sch, L))
+                assert np.array_equal(xr, xe), (sname, n, L, "inv", W.last_kernel(), int((xr != xe).sum()))
+                if n <= 1000:
+                    with W.options(WL_LIFT_GTILE=0):
+                        assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "generic")
+                        assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "generic inv")
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    x = rng_array((250, 250), dtype, 1)
+    W.dwt(dev(W, x), sch, 1)
+    assert W.last_kernel() == "k_lift2d_gtile", W.last_kernel()
+    W.idwt(dev(W, x), sch, 1)
+    assert W.last_kernel() == "k_lift2d_gtile", W.last_kernel()
+
+
 def test_lifting_equals_filter_on_gpu(gpu, W):
     """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
     for nd in (1, 2, 3):

@@ -1137,6 +1137,204 @@ static hipError_t launch_tail_lift2d_reg(int id, hipStream_t st, const LiftSchem
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------
+// One 2-D lifting level of a block of ANY even size in one launch (known scheme shapes): the levels the streaming / register
+// kernels decline (sizes that are not multiples of 8, small non-power-of-two blocks: 1000 x 1000 and its 500, 250 levels)
+// ran as twelve one-thread-per-element launches per level.  One WAVE per tile: 64 x 64 samples of the block incl. a halo of
+// HP pairs on every side (the dependency cone of the scheme), staged to LDS with periodic wrap; exactly as in the register
+// tail a lane holds a whole tile row (then a whole tile column) in registers and runs split -> steps -> normalize (or the
+// inverse order) as straight-line code -- only the choice between the reference's in-bounds and boundary summation forms
+// depends on the global position and is a wave-uniform select.  Tile edges inside the halo are garbage and never stored.
+template <int ID>
+struct LiftReach {
+    static constexpr int left()
+    {
+        int v = 0;
+        for (int k = 0; k < Shape<ID>::NS; ++k) { const int a = Shape<ID>::S[k].sh; if (a > 0) v += a; }
+        return v;
+    }
+    static constexpr int right()
+    {
+        int v = 0;
+        for (int k = 0; k < Shape<ID>::NS; ++k) { const int b = Shape<ID>::S[k].nc - 1 - Shape<ID>::S[k].sh; if (b > 0) v += b; }
+        return v;
+    }
+    static constexpr int HP = left() > right() ? left() : right();
+};
+
+template <typename T>
+struct LiftGTileArgs {
+    const T *src; int64_t lds;      // fw: block n x n;  inv: coefficient array
+    T *y; int64_t ldy;              // fw: coefficient array;  inv: result block
+    T *ll; int64_t ldl;             // fw: approximation destination or nullptr (-> y);  inv: approximation source or nullptr (-> src)
+    int n;                          // block size (even)
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+// all steps on an open line of 32 pairs whose first pair has the global (periodic) index kg0 of a line with `half` pairs
+template <typename T, int ID>
+__device__ __forceinline__ void tile_line_steps(T (&s)[32], T (&d)[32], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF], int kg0, int half)
+{
+    typedef Shape<ID> SH;
+#pragma unroll
+    for (int k = 0; k < SH::NS; ++k) {
+        const int upd = SH::S[k].upd, nc = SH::S[k].nc, sh = SH::S[k].sh;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int j0 = j - sh;
+            if (j0 < 0 || j0 + nc - 1 > 31) continue;              // operands outside the tile: this pair is halo by then
+            int jg = kg0 + j;                                       // wave-uniform
+            while (jg >= half) jg -= half;
+            const bool inb = (jg - sh >= 0) && (jg - sh + nc - 1 <= half - 1);
+            const T x = upd ? d[j] : s[j];
+            const T o0 = upd ? s[j0] : d[j0];
+            const T o1 = (nc > 1) ? (upd ? s[(j0 + 1) & 31] : d[(j0 + 1) & 31]) : (T)0;
+            const T o2 = (nc > 2) ? (upd ? s[(j0 + 2) & 31] : d[(j0 + 2) & 31]) : (T)0;
+            T acc = c[k][0] * o0;
+            if (nc > 1) acc = acc + c[k][1] * o1;
+            if (nc > 2) acc = acc + c[k][2] * o2;
+            const T xin = x + acc;
+            T xb = x + c[k][0] * o0;
+            if (nc > 1) xb = xb + c[k][1] * o1;
+            if (nc > 2) xb = xb + c[k][2] * o2;
+            const T r = inb ? xin : xb;
+            if (upd) d[j] = r; else s[j] = r;
+        }
+    }
+}
+
+template <typename T, int ID, int FW>
+__global__ void __launch_bounds__(64) k_lift2d_gtile(LiftGTileArgs<T> a)
+{
+    constexpr int HP = LiftReach<ID>::HP, OWN = 32 - 2 * HP, ld = 65;
+    static_assert(OWN >= 8, "scheme reach too large for the tile");
+    __shared__ T P[ld * 64];
+    const int lane = threadIdx.x;
+    const int n = a.n, h = n >> 1;
+    int pr0 = (int)blockIdx.x * OWN - HP, pc0 = (int)blockIdx.y * OWN - HP;       // first pair of the tile per dimension (periodic)
+    while (pr0 < 0) pr0 += h;
+    while (pc0 < 0) pc0 += h;
+    const int own_r0 = (int)blockIdx.x * OWN, own_c0 = (int)blockIdx.y * OWN;      // first OWNED pair
+    auto wrapp = [&](int i) __attribute__((always_inline)) { while (i >= h) i -= h; return i; };
+    if (FW) {
+        // stage: P[i + j*ld] = x[(2 pr0 + i) mod n, (2 pc0 + j) mod n]; lanes along the rows
+        {
+            int gi = 2 * pr0 + lane;
+            while (gi >= n) gi -= n;
+            int gj = 2 * pc0;
+            for (int j = 0; j < 64; ++j) {
+                P[lane + j * ld] = a.src[gi + (int64_t)gj * a.lds];
+                if (++gj >= n) gj -= n;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        {   // dim 2: lane = tile row, line along the columns
+            T s[32], d[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { s[k] = P[lane + (2 * k) * ld]; d[k] = P[lane + (2 * k + 1) * ld]; }
+            tile_line_steps<T, ID>(s, d, a.c, pc0, h);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { P[lane + k * ld] = s[k] * a.norm1; P[lane + (32 + k) * ld] = d[k] * a.norm2; }
+        }
+        reg_tail_sync();
+        {   // dim 1: lane = tile column (32 s-columns, 32 d-columns), line along the rows
+            T s[32], d[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { s[k] = P[2 * k + lane * ld]; d[k] = P[2 * k + 1 + lane * ld]; }
+            tile_line_steps<T, ID>(s, d, a.c, pr0, h);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { P[k + lane * ld] = s[k] * a.norm1; P[32 + k + lane * ld] = d[k] * a.norm2; }
+        }
+        reg_tail_sync();
+        // store the owned pairs: lanes along the rows (s rows then d rows), one tile column per iteration
+        T *const lld = a.ll ? a.ll : a.y;
+        const int64_t ldl = a.ll ? a.ldl : a.ldy;
+        const int kr = lane & 31, rdet = lane >> 5;                 // local row pair, 0: s row, 1: d row
+        const int gk = own_r0 + (kr - HP);
+        const bool row_ok = kr >= HP && kr < 32 - HP && gk < h;
+        for (int c = 0; c < 64; ++c) {
+            const int kc = c & 31, cdet = c >> 5;
+            const int gc = own_c0 + (kc - HP);
+            if (kc >= HP && kc < 32 - HP && gc < h && row_ok) {
+                const T v = P[lane + c * ld];
+                if (!rdet && !cdet) lld[gk + (int64_t)gc * ldl] = v;
+                else a.y[(rdet ? h : 0) + gk + (int64_t)((cdet ? h : 0) + gc) * a.ldy] = v;
+            }
+        }
+    } else {
+        // stage the four quadrant pieces: P[i + j*ld], i < 32: s row pr0 + i, i >= 32: d row pr0 + i - 32 (columns alike)
+        {
+            const int kr = lane & 31, rdet = lane >> 5;
+            const int gr = wrapp(pr0 + kr);
+            const T *lls = a.ll ? a.ll : a.src;
+            const int64_t ldl = a.ll ? a.ldl : a.lds;
+            int gc = pc0;
+            for (int j = 0; j < 32; ++j) {
+                P[lane + j * ld] = rdet ? a.src[h + gr + (int64_t)gc * a.lds] : lls[gr + (int64_t)gc * ldl];
+                P[lane + (32 + j) * ld] = a.src[(rdet ? h : 0) + gr + (int64_t)(h + gc) * a.lds];
+                if (++gc >= h) gc -= h;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        {   // dim 1 first: lane = tile column, line along the rows: normalize -> steps -> merge
+            T s[32], d[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { s[k] = a.norm1 * P[k + lane * ld]; d[k] = a.norm2 * P[32 + k + lane * ld]; }
+            tile_line_steps<T, ID>(s, d, a.c, pr0, h);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { P[2 * k + lane * ld] = s[k]; P[2 * k + 1 + lane * ld] = d[k]; }
+        }
+        reg_tail_sync();
+        {   // dim 2: lane = tile row, line along the columns
+            T s[32], d[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { s[k] = a.norm1 * P[lane + k * ld]; d[k] = a.norm2 * P[lane + (32 + k) * ld]; }
+            tile_line_steps<T, ID>(s, d, a.c, pc0, h);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { P[lane + (2 * k) * ld] = s[k]; P[lane + (2 * k + 1) * ld] = d[k]; }
+        }
+        reg_tail_sync();
+        // sample (i, j) of the tile is x[2 (own_r0 - HP) + i, 2 (own_c0 - HP) + j]; owned: pairs HP .. 32-HP-1
+        const int i = lane, kr = i >> 1;
+        const int gi = 2 * own_r0 + (i - 2 * HP);
+        const bool row_ok = kr >= HP && kr < 32 - HP && gi < n;
+        for (int j = 0; j < 64; ++j) {
+            const int kc = j >> 1;
+            const int gj = 2 * own_c0 + (j - 2 * HP);
+            if (kc >= HP && kc < 32 - HP && gj < n && row_ok) a.y[gi + (int64_t)gj * a.ldy] = P[i + j * ld];
+        }
+    }
+}
+
+template <typename T>
+static bool lift2d_gtile_ok(int id, int64_t n) { return id >= 0 && id <= 5 && n >= 2 && (n % 2) == 0 && n < ((int64_t)1 << 30); }
+template <typename T, int FW>
+static hipError_t launch_lift2d_gtile(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
+                                      int64_t ldl, int64_t n)
+{
+    LiftGTileArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldl = ldl; a.n = (int)n;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    const int64_t h = n >> 1;
+#define WL_LGT(ID_)                                                                                             \
+    {                                                                                                           \
+        constexpr int OWN = 32 - 2 * LiftReach<ID_>::HP;                                                        \
+        const unsigned g = (unsigned)((h + OWN - 1) / OWN);                                                     \
+        if (g > 65535) return hipErrorInvalidValue;                                                             \
+        hipLaunchKernelGGL((k_lift2d_gtile<T, ID_, FW>), dim3(g, g), dim3(64), 0, st, a);                       \
+    }
+    if (FW) {
+        if (id == 0) WL_LGT(0) else if (id == 2) WL_LGT(2) else WL_LGT(4)
+    } else {
+        if (id == 1) WL_LGT(1) else if (id == 3) WL_LGT(3) else WL_LGT(5)
+    }
+#undef WL_LGT
+    return hipGetLastError();
+}
+
 template <typename T, int FW>
 static hipError_t launch_tail_lift2d(hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, int n0, int nlev)
 {
@@ -2127,7 +2325,9 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     *handled = 0;
     constexpr int VEC = 16 / sizeof(T);
     const int id = match_shape<T>(sc);
-    if (id < 0 || L < 1 || n0 < 2 || (ldy % VEC) != 0 || !al16(x) || !al16(y)) return WL_OK;
+    if (id < 0 || L < 1 || n0 < 2) return WL_OK;
+    // the streaming / line kernels use 16-byte accesses; the tile and tail kernels take any leading dimension
+    const bool aligned = (ldy % VEC) == 0 && al16(x) && al16(y);
 #define WL_E(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { if (hip_err) *hip_err = (int)e__; return WL_EHIP; } } while (0)
 #define WL_EL() WL_E(hipGetLastError())
     const int64_t N = n0 * n0;
@@ -2146,7 +2346,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     Strides3 full = {{1, ldy, ldy * n0}};
     auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
     auto fused_ok = [](int64_t n) { return n >= 128 && (n % 8) == 0; };     // k_lift2d_*: a lane's 4 rows wrap at most once
-    bool any_fast = false, fused = false;
+    bool any_fast = false, fused = false, gtile = false;
 
     if (fw) {
         const T *cur = x;
@@ -2166,7 +2366,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 any_fast = true;
                 break;
             }
-            if (fused_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
+            if (aligned && fused_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
                 al16(cur) && al16(llbuf) && cur != y) {      // (in place, level 1 reads y while writing it: two passes via T0)
                 // both passes of the level in one kernel: read the block once, write the four quadrants once
                 Lift2DArgs<T> q2;
@@ -2182,7 +2382,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 cur = llbuf; cur_ls = h; pp ^= 1;
                 continue;
             }
-            if (lines_ok(n) || short_lift_ok(n)) {
+            if (aligned && (lines_ok(n) || short_lift_ok(n))) {
                 any_fast = true;
                 // rows (dim 2): one streaming pass along the strided axis, T0 = [s-columns | d-columns]
                 ax.src = cur; ax.lds = cur_ls; ax.bs_src = 0; ax.dst = w.T0; ax.ldd = n; ax.bs_dst = 0; ax.R = n; ax.C = n;
@@ -2202,6 +2402,10 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     sa.ll = last ? (T *)nullptr : llbuf; sa.ll2 = h; sa.l2 = (int)h; sa.l3 = 1;
                     WL_E((launch_lift_short_id<T, 1>(id, st, sa, (int)n, (int)n, 1)));
                 }
+            } else if ((id == 0 || id == 2 || id == 4) && lift2d_gtile_ok<T>(id, n) && cur != y && l_env("WL_LIFT_GTILE", 1) != 0) {
+                // any even size: one tile launch instead of twelve one-thread-per-element launches
+                WL_E((launch_lift2d_gtile<T, 1>(id, st, sc, cur, cur_ls, y, ldy, last ? (T *)nullptr : llbuf, h, n)));
+                any_fast = true; gtile = true;
             } else {
                 Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
                 Strides3 box = {{1, n, n * n}}, cst = {{1, cur_ls, cur_ls * n}}, lst = {{1, ldd, ldd * h}};
@@ -2240,7 +2444,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
-            if (fused_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
+            if (aligned && fused_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
                 (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {   // (in place, level 1 writes y while reading it)
                 Lift2DArgs<T> q2;
                 for (int i = 0; i < LIFT_FAST_STEPS; ++i)
@@ -2255,7 +2459,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 llsrc = out; ll_ls = ldo; pp ^= 1;
                 continue;
             }
-            if (lines_ok(n) || short_lift_ok(n)) {
+            if (aligned && (lines_ok(n) || short_lift_ok(n))) {
                 any_fast = true;
                 // columns: merged column j -> T0[:, j]
                 if (lines_ok(n)) {
@@ -2274,6 +2478,9 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 // rows (dim 2): streaming pass along the strided axis straight into the result
                 ax.src = w.T0; ax.lds = n; ax.bs_src = 0; ax.dst = out; ax.ldd = ldo; ax.bs_dst = 0; ax.R = n; ax.C = n;
                 WL_E((launch_lift_axis_id<T, 0>(id, st, ax, 1, cu_count)));
+            } else if ((id == 1 || id == 3 || id == 5) && lift2d_gtile_ok<T>(id, n) && out != x && l_env("WL_LIFT_GTILE", 1) != 0) {
+                WL_E((launch_lift2d_gtile<T, 0>(id, st, sc, x, ldy, out, ldo, const_cast<T *>(llsrc), ll_ls, n)));
+                any_fast = true; gtile = true;
             } else {
                 Extent3 ext = {{n, n, 1}}, lo = {{h, h, 1}};
                 Strides3 box = {{1, n, n * n}}, lst = {{1, ll_ls, ll_ls * h}}, ost = {{1, ldo, ldo * n}};
@@ -2288,7 +2495,9 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
         }
     }
     *handled = 1;
-    if (kernel_name) *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : "k_lift_axis_stream+lines") : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
+    if (kernel_name)
+        *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : (gtile ? "k_lift2d_gtile" : "k_lift_axis_stream+lines"))
+                                : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
     return WL_OK;
 }
 

@@ -770,6 +770,38 @@ def test_lifting_any_even_size_tile_kernel(gpu, W, oracle, dtype):
     assert W.last_kernel() == "k_lift2d_gtile", W.last_kernel()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_lines_any_even_length(gpu, W, oracle, dtype):
+    """k_lift1d_gtile (one 1-D lifting level of lines of ANY even length: a lane owns 28 pairs and holds their 32-pair window
+    in registers): lengths that are not multiples of 8 or have a large odd factor, alone, below the streaming kernels and
+    above the LDS tail, in place, batched columns -- bit for bit against the oracle."""
+    for sname in ("cdf97", "db2", "haar"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        for n, L in ((1000000, 6), (3000, 3), (4100, 2), (2100, 1), (6 * 4096, 13), (100004, 2), (2052, 2)):
+            if n >= 1000000 and sname != "cdf97":
+                continue
+            x = rng_array((n,), dtype, n % 1000 + len(sname))
+            ye = oracle.dwt_lifting(x, sch, L)
+            y = host(W, W.dwt(dev(W, x), sch, L))
+            assert "generic" not in W.last_kernel(), (sname, n, L, W.last_kernel())
+            assert np.array_equal(y, ye), (sname, n, L, W.last_kernel(), int((y != ye).sum()))
+            t = dev(W, x)
+            W.dwt_(t, sch, L)
+            assert np.array_equal(host(W, t), ye), (sname, n, L, "in place")
+            xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+            xr = host(W, W.idwt(dev(W, ye), sch, L))
+            assert "generic" not in W.last_kernel(), (sname, n, L, W.last_kernel())
+            assert np.array_equal(xr, xe), (sname, n, L, "inv", int((xr != xe).sum()))
+            t = dev(W, ye)
+            W.idwt_(t, sch, L)
+            assert np.array_equal(host(W, t), xe), (sname, n, L, "inv in place")
+        for shape, L in (((3000, 7), 3), ((1028, 40), 2), ((100, 33), 2)):
+            xb = rng_array(shape, dtype, shape[1])
+            yb = oracle.dwtc_lifting(xb, sch, L)
+            assert np.array_equal(host(W, W.dwtc(dev(W, xb), sch, L)), yb), (sname, shape)
+            assert np.array_equal(host(W, W.idwtc(dev(W, yb), sch, L)), oracle.dwtc_lifting(yb, sch, L, fw=False)), (sname, shape, "inv")
+
+
 def test_lifting_equals_filter_on_gpu(gpu, W):
     """test/transforms.jl:57-128 (tolerance 1e-10*sqrt(len)) on the device results."""
     for nd in (1, 2, 3):

@@ -1448,6 +1448,96 @@ static hipError_t lift_max_lds_once(const void *fn, unsigned char (&done)[64])
     return e;
 }
 
+// One 1-D lifting level of lines of ANY even length (known shapes): a lane owns OWN = 32 - 2 HP consecutive pairs, loads the
+// 32-pair window around them (periodic wrap per sample) straight into registers and runs the level exactly like a tile row of
+// k_lift2d_gtile.  Fallback of the lines the streaming kernels decline (lengths that are not multiples of 8, short
+// non-power-of-two lines) -- a 10^6-sample cdf9/7 transform ran as six one-thread-per-element launches per level before.
+// Arguments as for k_lift1d_stream (fw: a = src, o0 = s destination, o1 = d destination; inv: a = s source, b = d source,
+// o0 = destination).
+template <typename T, int ID, int FW>
+__global__ void __launch_bounds__(256) k_lift1d_gtile(Lift1DArgs<T> a)
+{
+    constexpr int HP = LiftReach<ID>::HP, OWN = 32 - 2 * HP;
+    const int64_t n = a.n, h = n >> 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t own0 = t * OWN;
+    if (own0 >= h) return;
+    const int64_t line = blockIdx.y;
+    int64_t pr0 = own0 - HP;
+    while (pr0 < 0) pr0 += h;
+    T s[32], d[32];
+    if (FW) {
+        const T *src = a.a + line * a.a_ls;
+        int64_t g = 2 * pr0;
+        while (g >= n) g -= n;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            s[k] = src[g];
+            if (++g >= n) g -= n;
+            d[k] = src[g];
+            if (++g >= n) g -= n;
+        }
+    } else {
+        const T *ss = a.a + line * a.a_ls, *ds = a.b + line * a.b_ls;
+        int64_t g = pr0;
+        while (g >= h) g -= h;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            s[k] = a.norm1 * ss[g];
+            d[k] = a.norm2 * ds[g];
+            if (++g >= h) g -= h;
+        }
+    }
+    // the periodic index of the window's first pair fits an int for the step function only when h < 2^31
+    int kg0;
+    {
+        int64_t p = pr0;
+        while (p >= h) p -= h;
+        kg0 = (int)p;
+    }
+    tile_line_steps<T, ID>(s, d, a.c, kg0, (int)h);
+    if (FW) {
+        T *so = a.o0 + line * a.o0_ls, *dO = a.o1 + line * a.o1_ls;
+#pragma unroll
+        for (int k = HP; k < 32 - HP; ++k) {
+            const int64_t gk = own0 + (k - HP);
+            if (gk < h) { so[gk] = s[k] * a.norm1; dO[gk] = d[k] * a.norm2; }
+        }
+    } else {
+        T *out = a.o0 + line * a.o0_ls;
+#pragma unroll
+        for (int k = HP; k < 32 - HP; ++k) {
+            const int64_t gk = own0 + (k - HP);
+            if (gk < h) { out[2 * gk] = s[k]; out[2 * gk + 1] = d[k]; }
+        }
+    }
+}
+template <typename T, int FW>
+static hipError_t launch_lift1d_gtile(int id, hipStream_t st, const Lift1DArgs<T> &a, int64_t nlines)
+{
+    const int64_t h = a.n >> 1;
+    if (h >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+#define WL_L1G(ID_)                                                                                              \
+    {                                                                                                            \
+        constexpr int OWN = 32 - 2 * LiftReach<ID_>::HP;                                                         \
+        const int64_t nthreads = (h + OWN - 1) / OWN;                                                            \
+        for (int64_t l0 = 0; l0 < nlines; l0 += 32768) {                                                         \
+            const int64_t nb = (nlines - l0 < 32768) ? (nlines - l0) : 32768;                                    \
+            Lift1DArgs<T> b = a;                                                                                 \
+            b.a = a.a + l0 * a.a_ls; b.b = a.b ? a.b + l0 * a.b_ls : nullptr;                                    \
+            b.o0 = a.o0 + l0 * a.o0_ls; b.o1 = a.o1 ? a.o1 + l0 * a.o1_ls : nullptr;                             \
+            hipLaunchKernelGGL((k_lift1d_gtile<T, ID_, FW>), dim3((unsigned)((nthreads + 255) / 256), (unsigned)nb), dim3(256), 0, st, b); \
+        }                                                                                                        \
+    }
+    if (FW) {
+        if (id == 0) WL_L1G(0) else if (id == 2) WL_L1G(2) else WL_L1G(4)
+    } else {
+        if (id == 1) WL_L1G(1) else if (id == 3) WL_L1G(3) else WL_L1G(5)
+    }
+#undef WL_L1G
+    return hipGetLastError();
+}
+
 template <typename T>
 int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
                        T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,
@@ -1471,7 +1561,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
     for (int l = 1; l <= L; ++l) {
         const int64_t nl = n >> (l - 1);
         if (nl <= cap) { l_tail = l; break; }
-        if (id < 0 || nl < 512 || (nl % 8) != 0) return WL_OK;
+        if (id < 0) return WL_OK;                 // (known shapes: lines that cannot stream -- nl < 512 or nl % 8 != 0 -- take k_lift1d_gtile)
     }
     const int64_t N = n * nlines;
     Work<T> w = carve<T>(ws, N);
@@ -1531,8 +1621,11 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             a.o0 = (last && !stage) ? y : llbuf; a.o0_ls = (last && !stage) ? ld : hl;
             a.o1 = stage ? w.W : (y + hl); a.o1_ls = stage ? hl : ld;
             a.n = nl; a.ntiles = (hl + 247) / 248;
-            WL_LAUNCH_ID(1);
+            const bool streamable = nl >= 512 && (nl % 8) == 0;
+            if (streamable) { WL_LAUNCH_ID(1); }
+            else { hipError_t eg = launch_lift1d_gtile<T, 1>(id, st, a, nlines); if (eg != hipSuccess) { if (hip_err) *hip_err = (int)eg; return WL_EHIP; } }
             WL_CHECK_LAUNCH();
+            if (!streamable && !dom) dom = "k_lift1d_gtile";
             if (stage) {
                 Extent3 e = {{hl, nlines, 1}};
                 Strides3 s0 = {{1, hl, hl * nlines}}, s1 = {{1, ld, ld * nlines}};
@@ -1656,7 +1749,9 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
             a.o0 = stage ? w.W : out; a.o0_ls = stage ? nl : (to_y ? ld : nl);
             a.o1 = nullptr; a.o1_ls = 0;
             a.n = nl; a.ntiles = (hl + 247) / 248;
-            WL_LAUNCH_ID(0);
+            const bool streamable = nl >= 512 && (nl % 8) == 0;
+            if (streamable) { WL_LAUNCH_ID(0); }
+            else { hipError_t eg = launch_lift1d_gtile<T, 0>(id, st, a, nlines); if (eg != hipSuccess) { if (hip_err) *hip_err = (int)eg; return WL_EHIP; } }
             WL_CHECK_LAUNCH();
             if (stage) {
                 Extent3 e = {{nl, nlines, 1}};
@@ -1664,7 +1759,7 @@ int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_
                 hipError_t e2 = generic_copy_box<T>(st, w.W, s0, y, s1, e);
                 if (e2 != hipSuccess) { if (hip_err) *hip_err = (int)e2; return WL_EHIP; }
             }
-            dom = "k_lift1d_stream";
+            dom = streamable ? "k_lift1d_stream" : "k_lift1d_gtile";
             llsrc = out; ll_ls = nl; pp ^= 1;
         }
     }

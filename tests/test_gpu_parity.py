@@ -354,6 +354,44 @@ def test_any_even_size_tile_kernels(gpu, W, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_any_axis_pass_kernels(gpu, W, oracle, dtype):
+    """k_fwd_any / k_inv_any (one pass along any axis of a box of any even extent, four pairs per thread, compile-time taps):
+    3-D volumes whose sides are not powers of two, batched columns of lengths that are not multiples of 8, lines with a large
+    odd factor -- forward and inverse, bit for bit against the oracle and against the one-thread-per-output kernels."""
+    cases = (((100, 100, 100), 2), ((60, 36, 20), 2), ((10, 6, 14), 1), ((2, 2, 2), 1), ((96, 96, 96), 5), ((240, 120, 40), 3), ((18, 50, 34), 1))
+    for shape, L in cases:
+        x = rng_array(shape, dtype, sum(shape))
+        for fname in ("db4", "haar", "db3", "sym5"):
+            if shape[0] >= 96 and fname in ("haar", "db3"):
+                continue
+            wt = W.wavelet(getattr(W.WT, fname))
+            ye = oracle.dwt_filter(x, wt.qmf, L)
+            y = host(W, W.dwt(dev(W, x), wt, L))
+            kf = W.last_kernel()
+            assert np.array_equal(y, ye), (shape, fname, L, kf, int((y != ye).sum()))
+            xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+            xr = host(W, W.idwt(dev(W, ye), wt, L))
+            ki = W.last_kernel()
+            assert np.array_equal(xr, xe), (shape, fname, L, ki, "inv")
+            assert "generic" not in kf and "generic" not in ki, (shape, fname, kf, ki)
+            with W.options(WL_ANYAXIS=0):
+                assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (shape, fname, "generic")
+                assert "generic" in W.last_kernel() or "tail" in W.last_kernel(), W.last_kernel()
+                assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), xe), (shape, fname, "generic inv")
+    wt = W.wavelet(W.WT.db4)
+    for shape, L in (((44100, 6), 2), ((1004, 33), 2), ((50, 7), 1), ((100004,), 2), ((30,), 1)):
+        x = rng_array(shape, dtype, 3)
+        if len(shape) == 2:
+            ye = oracle.dwtc_filter(x, wt.qmf, L)
+            assert np.array_equal(host(W, W.dwtc(dev(W, x), wt, L)), ye), shape
+            assert np.array_equal(host(W, W.idwtc(dev(W, ye), wt, L)), oracle.dwtc_filter(ye, wt.qmf, L, fw=False)), (shape, "inv")
+        else:
+            ye = oracle.dwt_filter(x, wt.qmf, L)
+            assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), shape
+            assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (shape, "inv")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_tail3_kernel(gpu, W, oracle, dtype):
     """k_tail3 (3-D: every remaining forward level / the deepest inverse levels of a power-of-two box <= 4096 elements in one
     workgroup, three LDS passes per level in the reference's order): cubes and non-cubic boxes, every depth, every

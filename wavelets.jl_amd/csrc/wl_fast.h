@@ -56,6 +56,11 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const 
                              int64_t ldll, int M, int N);
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
+// one filter-bank pass along any axis of a box of any even extent, F <= 10 (wl_anyaxis.hip)
+bool any_axis_ok(int F, const Extent3 &n, int axis);
+template <typename T>
+hipError_t any_axis_pass(hipStream_t st, const Taps<T> &taps, int fw, const T *src, Strides3 sst, T *dst, Strides3 dst_st, T *ll,
+                         Strides3 ll_st, Extent3 n, int axis, Extent3 lo);
 // one 2-D level of any even extents (wl_gtile.hip)
 bool gtile_ok(int F, int64_t M, int64_t N);
 template <typename T>

@@ -1459,15 +1459,19 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             Strides3 in_st = cur_st;
             int tog = 0;
             for (int a = b.nt - 1; a >= 0; --a) {
+                // F <= 10: four pairs per thread from a register window, compile-time taps (wl_anyaxis.hip); else one output per thread
+                const bool any = path == 0 && env_int("WL_ANYAXIS", 1) && any_axis_ok(F, ext, a);
                 if (a != 0) {
                     T *out = tog ? w.T1 : w.T0;
-                    WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
+                    if (any) WL_TRY(any_axis_pass<T>(st, taps, 1, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
+                    else WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, out, box_st, (T *)nullptr, box_st, ext, a, lo));
                     in = out; in_st = box_st; tog ^= 1;
                 } else {
-                    WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+                    if (any) WL_TRY(any_axis_pass<T>(st, taps, 1, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+                    else WL_TRY(generic_fwd_filter_pass<T>(st, taps, in, in_st, y, b.full, last ? (T *)nullptr : llbuf, ll_st, ext, a, lo));
+                    if (!dominant) dominant = any ? "k_fwd_any" : "k_generic_fwd_filter";
                 }
             }
-            if (!dominant) dominant = "k_generic_fwd_filter";
         }
         cur = llbuf; cur_st = ll_st; pp ^= 1;
     }

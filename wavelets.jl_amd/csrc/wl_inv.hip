@@ -1049,11 +1049,14 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 T *out; Strides3 out_st;
                 if (lastp) { out = res; out_st = res_st; }
                 else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
-                WL_TRYI(generic_inv_filter_pass<T>(st, taps, in, in_st, firstp ? llsrc : (const T *)nullptr, llsrc_st,
-                                                   out, out_st, ext, a, lo));
+                const bool any = path == 0 && i_env("WL_ANYAXIS", 1) && any_axis_ok(F, ext, a);
+                if (any)
+                    WL_TRYI(any_axis_pass<T>(st, taps, 0, in, in_st, out, out_st, firstp ? const_cast<T *>(llsrc) : (T *)nullptr, llsrc_st, ext, a, lo));
+                else
+                    WL_TRYI(generic_inv_filter_pass<T>(st, taps, in, in_st, firstp ? llsrc : (const T *)nullptr, llsrc_st, out, out_st, ext, a, lo));
                 in = out; in_st = out_st;
+                if (lastp && !dominant) dominant = any ? "k_inv_any" : "k_generic_inv_filter";
             }
-            if (!dominant) dominant = "k_generic_inv_filter";
         }
         llsrc = res; llsrc_st = box_st; pp ^= 1;
     }

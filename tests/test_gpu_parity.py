@@ -800,6 +800,27 @@ def test_lifting_any_even_size_tile_kernel(gpu, W, oracle, dtype):
                     with W.options(WL_LIFT_GTILE=0):
                         assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "generic")
                         assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "generic inv")
+    # the rank-generic driver (3-D volumes of any even size, in-place 2-D level 1): one k_lift_any launch per axis and level
+    for sname in ("cdf97", "db2", "haar"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        for n, L in ((10, 1), (36, 2), (100, 2), (6, 1)):
+            x = rng_array((n, n, n), dtype, n)
+            ye = oracle.dwt_lifting(x, sch, L)
+            assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "3-D")
+            xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+            assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "3-D inv")
+            with W.options(WL_LIFT_ANY=0):
+                assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "3-D generic")
+                assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "3-D generic inv")
+        for n, L in ((250, 1), (1000, 3), (36, 2)):
+            x = rng_array((n, n), dtype, n)
+            ye = oracle.dwt_lifting(x, sch, L)
+            t = dev(W, x)
+            W.dwt_(t, sch, L)
+            assert np.array_equal(host(W, t), ye), (sname, n, L, "2-D in place")
+            t = dev(W, ye)
+            W.idwt_(t, sch, L)
+            assert np.array_equal(host(W, t), oracle.dwt_lifting(ye, sch, L, fw=False)), (sname, n, L, "2-D in place inv")
     sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
     x = rng_array((250, 250), dtype, 1)
     W.dwt(dev(W, x), sch, 1)

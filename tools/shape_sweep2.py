@@ -35,3 +35,9 @@ for dt, tag in ((torch.float32, "f32"),):
         ti = timeit(lambda: W.idwt_oop_(x, y, db4, L), reps=10); ki = W.last_kernel()
         b = 2 * x.numel() * x.element_size()
         print(f"| 3-D {shape} L={L} db4 | {tag} | {tf:.1f} ({b / tf / 1e3:.0f}) | {ti:.1f} ({b / ti / 1e3:.0f}) | {kf} / {ki} |", flush=True)
+    for n, L in ((100, 2), (240, 4), (96, 5)):
+        x = jl((n, n, n), dt); y = W.similar(x)
+        tf = timeit(lambda: W.dwt_oop_(y, x, cdf, L), reps=10); kf = W.last_kernel()
+        ti = timeit(lambda: W.idwt_oop_(x, y, cdf, L), reps=10); ki = W.last_kernel()
+        b = 2 * x.numel() * x.element_size()
+        print(f"| 3-D lifting {n}^3 L={L} cdf97 | {tag} | {tf:.1f} ({b / tf / 1e3:.0f}) | {ti:.1f} ({b / ti / 1e3:.0f}) | {kf} / {ki} |", flush=True)

@@ -91,6 +91,20 @@ int generic_lifting_fwd(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, con
         Strides3 in_st = cur_st;
         int tog = 0;
         for (int a = b.nt - 1; a >= 0; --a) {
+            // known scheme shapes: the whole pass (split, steps, normalize) in one launch (k_lift_any, wl_lift.hip) unless the
+            // pass would read and write the same array (in-place 1-D level 1)
+            {
+                T *out = (a != 0) ? (tog ? w.T1 : w.T0) : y;
+                hipError_t ea = hipSuccess;
+                if (ctx->path == 0 && (const T *)out != in &&
+                    lift_any_pass<T>(st, sc, 1, in, in_st, out, a != 0 ? box_st : b.full, (a != 0 || last) ? (T *)nullptr : llbuf, ll_st, ext, a,
+                                     lo, &ea)) {
+                    WL_HIP(ctx, ea);
+                    ctx->last_kernel = "k_lift_any";
+                    if (a != 0) { in = out; in_st = box_st; tog ^= 1; }
+                    continue;
+                }
+            }
             WL_HIP(ctx, generic_lift_split<T>(st, in, in_st, w.W, box_st, ext, a));
             for (int s = 0; s < sc.nsteps; ++s)
                 WL_HIP(ctx, generic_lift_step<T>(st, sc.step[s], w.W, box_st, ext, a));
@@ -130,17 +144,24 @@ int generic_lifting_inv(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, con
         T *res = nullptr;
         for (int a = 0; a < b.nt; ++a) {
             const bool firstp = (a == 0), lastp = (a == b.nt - 1);
-            WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc.norm1, sc.norm2, in, in_st,
-                                                 firstp ? llsrc : (const T *)nullptr, llsrc_st, w.W, box_st, ext, a, lo));
-            for (int s = 0; s < sc.nsteps; ++s)
-                WL_HIP(ctx, generic_lift_step<T>(st, sc.step[s], w.W, box_st, ext, a));
             T *out; Strides3 out_st;
             if (lastp) {
                 if (l == 1) { out = y; out_st = b.full; }
                 else { out = pp ? w.B : w.A; out_st = box_st; }
                 res = out;
             } else { out = tog ? w.T1 : w.T0; out_st = box_st; tog ^= 1; }
-            WL_HIP(ctx, generic_lift_merge<T>(st, w.W, box_st, out, out_st, ext, a));
+            hipError_t ea = hipSuccess;
+            if (ctx->path == 0 && (const T *)out != in &&
+                lift_any_pass<T>(st, sc, 0, in, in_st, out, out_st, firstp ? const_cast<T *>(llsrc) : (T *)nullptr, llsrc_st, ext, a, lo, &ea)) {
+                WL_HIP(ctx, ea);                         // normalize, steps and merge of the pass in one launch (k_lift_any)
+                ctx->last_kernel = "k_lift_any";
+            } else {
+                WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc.norm1, sc.norm2, in, in_st,
+                                                     firstp ? llsrc : (const T *)nullptr, llsrc_st, w.W, box_st, ext, a, lo));
+                for (int s = 0; s < sc.nsteps; ++s)
+                    WL_HIP(ctx, generic_lift_step<T>(st, sc.step[s], w.W, box_st, ext, a));
+                WL_HIP(ctx, generic_lift_merge<T>(st, w.W, box_st, out, out_st, ext, a));
+            }
             in = out; in_st = out_st;
         }
         llsrc = res; llsrc_st = box_st; pp ^= 1;

@@ -56,6 +56,10 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const 
                              int64_t ldll, int M, int N);
 
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
+// one lifting pass along any axis of a box of any even extent, known scheme shapes (wl_lift.hip)
+template <typename T>
+bool lift_any_pass(hipStream_t st, const LiftScheme<T> &sc, int fw, const T *src, Strides3 sst, T *dst, Strides3 dst_st, T *ll,
+                   Strides3 ll_st, Extent3 n, int axis, Extent3 lo, hipError_t *err);
 // one filter-bank pass along any axis of a box of any even extent, F <= 10 (wl_anyaxis.hip)
 bool any_axis_ok(int F, const Extent3 &n, int axis);
 template <typename T>

@@ -1538,6 +1538,143 @@ static hipError_t launch_lift1d_gtile(int id, hipStream_t st, const Lift1DArgs<T
     return hipGetLastError();
 }
 
+// One lifting pass (split -> steps -> normalize, or normalize -> steps -> merge) along ANY axis of a box of any even extent,
+// known shapes: what the rank-generic driver (wl_api.hip) runs instead of 6 one-thread-per-element launches per axis and level
+// (3-D volumes of any size, in-place 2-D level 1, ...).  Same register-window scheme as k_lift1d_gtile, arbitrary strides;
+// the approximation of the low corner goes to / comes from the next level's buffer exactly as in the generic kernels.
+template <typename T>
+struct LiftAnyArgs {
+    const T *src; Strides3 sst;
+    T *dst; Strides3 dst_st;
+    T *ll; Strides3 ll_st;          // fw: destination of the low corner's s half (or nullptr); inv: its source (or nullptr)
+    int n[3], lo[3];
+    int axis;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID, int FW>
+__global__ void __launch_bounds__(256) k_lift_any(LiftAnyArgs<T> a)
+{
+    constexpr int HP = LiftReach<ID>::HP, OWN = 32 - 2 * HP;
+    const int axis = a.axis;
+    const int nax = a.n[axis], h = nax >> 1, ntile = (h + OWN - 1) / OWN;
+    int e[3] = {a.n[0], a.n[1], a.n[2]};
+    e[axis] = ntile;
+    const int64_t sa = a.sst.s[axis], da = a.dst_st.s[axis];
+    for (int i2 = blockIdx.z; i2 < e[2]; i2 += gridDim.z)
+        for (int i1 = blockIdx.y * blockDim.y + threadIdx.y; i1 < e[1]; i1 += gridDim.y * blockDim.y)
+            for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < e[0]; i0 += gridDim.x * blockDim.x) {
+                int c[3] = {i0, i1, i2};
+                const int own0 = c[axis] * OWN;
+                int64_t base = 0, dbase = 0, lbase = 0;
+                bool low = (a.ll != nullptr);
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (d != axis) {
+                        base += (int64_t)c[d] * a.sst.s[d];
+                        dbase += (int64_t)c[d] * a.dst_st.s[d];
+                        lbase += (int64_t)c[d] * a.ll_st.s[d];
+                        low = low && (c[d] < a.lo[d]);
+                    }
+                int pr0 = own0 - HP;
+                while (pr0 < 0) pr0 += h;
+                while (pr0 >= h) pr0 -= h;
+                T s[32], d[32];
+                if (FW) {
+                    const T *p = a.src + base;
+                    int g = 2 * pr0;
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        s[k] = p[(int64_t)g * sa];
+                        if (++g >= nax) g -= nax;
+                        d[k] = p[(int64_t)g * sa];
+                        if (++g >= nax) g -= nax;
+                    }
+                } else {
+                    const T *ps = low ? (a.ll + lbase) : (a.src + base);
+                    const int64_t ss = low ? a.ll_st.s[axis] : sa;
+                    const T *pd = a.src + base + (int64_t)h * sa;
+                    int g = pr0;
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        s[k] = a.norm1 * ps[(int64_t)g * ss];
+                        d[k] = a.norm2 * pd[(int64_t)g * sa];
+                        if (++g >= h) g -= h;
+                    }
+                }
+                tile_line_steps<T, ID>(s, d, a.c, pr0, h);
+#pragma unroll
+                for (int k = HP; k < 32 - HP; ++k) {
+                    const int gk = own0 + (k - HP);
+                    if (gk < h) {
+                        if (FW) {
+                            const T sv = s[k] * a.norm1, dv = d[k] * a.norm2;
+                            if (low) a.ll[lbase + (int64_t)gk * a.ll_st.s[axis]] = sv;
+                            else a.dst[dbase + (int64_t)gk * da] = sv;
+                            a.dst[dbase + (int64_t)(h + gk) * da] = dv;
+                        } else {
+                            a.dst[dbase + (int64_t)(2 * gk) * da] = s[k];
+                            a.dst[dbase + (int64_t)(2 * gk + 1) * da] = d[k];
+                        }
+                    }
+                }
+            }
+}
+
+// returns false when the scheme shape / extents are not covered (the caller then uses the one-thread-per-element kernels)
+template <typename T>
+bool lift_any_pass(hipStream_t st, const LiftScheme<T> &sc, int fw, const T *src, Strides3 sst, T *dst, Strides3 dst_st, T *ll,
+                   Strides3 ll_st, Extent3 n, int axis, Extent3 lo, hipError_t *err)
+{
+    *err = hipSuccess;
+    const int id = match_shape<T>(sc);
+    if (id < 0 || (fw ? (id & 1) : !(id & 1))) return false;
+    for (int d = 0; d < 3; ++d)
+        if (n.n[d] < 1 || n.n[d] >= ((int64_t)1 << 30)) return false;
+    if (n.n[axis] < 2 || (n.n[axis] % 2) != 0 || opt("WL_LIFT_ANY", 1) == 0) return false;
+    LiftAnyArgs<T> a;
+    a.src = src; a.sst = sst; a.dst = dst; a.dst_st = dst_st; a.ll = ll; a.ll_st = ll_st; a.axis = axis;
+    for (int d = 0; d < 3; ++d) { a.n[d] = (int)n.n[d]; a.lo[d] = (int)lo.n[d]; }
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+#define WL_LANY(ID_, FW_)                                                                                          \
+    {                                                                                                              \
+        constexpr int OWN = 32 - 2 * LiftReach<ID_>::HP;                                                           \
+        int64_t e[3] = {n.n[0], n.n[1], n.n[2]};                                                                   \
+        e[axis] = ((n.n[axis] >> 1) + OWN - 1) / OWN;                                                              \
+        int bx = 256;                                                                                              \
+        while (bx > 1 && (bx >> 1) >= e[0]) bx >>= 1;                                                              \
+        const int by = 256 / bx;                                                                                   \
+        int64_t gx = (e[0] + bx - 1) / bx, gy = (e[1] + by - 1) / by, gz = e[2];                                   \
+        if (gy > 65535) gy = 65535;                                                                                \
+        if (gz > 65535) gz = 65535;                                                                                \
+        while (gx * gy * gz > 8192) {                                                                              \
+            if (gz > 1 && gz >= gy && gz >= gx) gz = (gz + 1) / 2;                                                 \
+            else if (gy > 1 && gy >= gx) gy = (gy + 1) / 2;                                                        \
+            else gx = (gx + 1) / 2;                                                                                \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_lift_any<T, ID_, FW_>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3((unsigned)bx, (unsigned)by, 1), 0, \
+                           st, a);                                                                                 \
+    }
+    switch (id) {
+    case 0: WL_LANY(0, 1) break;
+    case 2: WL_LANY(2, 1) break;
+    case 4: WL_LANY(4, 1) break;
+    case 1: WL_LANY(1, 0) break;
+    case 3: WL_LANY(3, 0) break;
+    default: WL_LANY(5, 0) break;
+    }
+#undef WL_LANY
+    *err = hipGetLastError();
+    return true;
+}
+template bool lift_any_pass<float>(hipStream_t, const LiftScheme<float> &, int, const float *, Strides3, float *, Strides3, float *, Strides3,
+                                   Extent3, int, Extent3, hipError_t *);
+template bool lift_any_pass<double>(hipStream_t, const LiftScheme<double> &, int, const double *, Strides3, double *, Strides3, double *, Strides3,
+                                    Extent3, int, Extent3, hipError_t *);
+
 template <typename T>
 int lifting_lines_fast(void *ws, int cu_count, hipStream_t st, int64_t n, int64_t nlines, int64_t ld,
                        T *y, const T *x, const LiftScheme<T> &sc, int L, int fw,

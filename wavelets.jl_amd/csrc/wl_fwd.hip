@@ -1026,6 +1026,7 @@ static hipError_t launch_tail(hipStream_t st, const Taps<T> &taps, const T *src,
     case 4: WL_TAIL_LAUNCH(4); break;
     case 6: WL_TAIL_LAUNCH(6); break;
     case 8: WL_TAIL_LAUNCH(8); break;
+    case 10: WL_TAIL_LAUNCH(10); break;
     default: WL_TAIL_LAUNCH(0); break;
     }
 #undef WL_TAIL_LAUNCH

@@ -517,6 +517,7 @@ static hipError_t launch_tail_inv(hipStream_t st, const Taps<T> &taps, const T *
     case 4: WL_TI(4); break;
     case 6: WL_TI(6); break;
     case 8: WL_TI(8); break;
+    case 10: WL_TI(10); break;
     default: WL_TI(0); break;
     }
 #undef WL_TI

@@ -1,4 +1,4 @@
-// wl_anyaxis.hip -- one filter-bank pass along ANY axis of a box of ANY even extent, F <= 10 (compile-time taps): the pass the
+// wl_anyaxis.hip -- one filter-bank pass along ANY axis of a box of ANY even extent, even F <= 24 (compile-time taps): the pass the
 // remaining odd-sized cases use -- 3-D volumes whose sides are not powers of two (100^3, 240 x 240 x 160), batched lines of
 // lengths that are not multiples of 8 (44100-sample columns), 2-D blocks with an odd stride -- instead of the
 // one-thread-per-output kernels of wl_generic.hip (run-time taps, two emulated 64-bit divisions per element, one dependent
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_inv_any(AnyArgs<T, F> a)
 
 bool any_axis_ok(int F, const Extent3 &n, int axis)
 {
-    if (F < 2 || F > 10 || (F & 1)) return false;
+    if (F < 2 || F > 24 || (F & 1) || F == 22) return false;
     for (int d = 0; d < 3; ++d)
         if (n.n[d] < 1 || n.n[d] >= ((int64_t)1 << 30)) return false;
     return n.n[axis] >= 2 && (n.n[axis] % 2) == 0;
@@ -189,7 +189,7 @@ hipError_t any_axis_pass(hipStream_t st, const Taps<T> &taps, int fw, const T *s
     case FF_: return fw ? launch_any_f<T, FF_, 1>(st, taps, src, sst, dst, dst_st, ll, ll_st, n, axis, lo)             \
                         : launch_any_f<T, FF_, 0>(st, taps, src, sst, dst, dst_st, ll, ll_st, n, axis, lo);
     switch (taps.F) {
-        WL_ANY(2) WL_ANY(4) WL_ANY(6) WL_ANY(8) WL_ANY(10)
+        WL_ANY(2) WL_ANY(4) WL_ANY(6) WL_ANY(8) WL_ANY(10) WL_ANY(12) WL_ANY(14) WL_ANY(16) WL_ANY(18) WL_ANY(20) WL_ANY(24)
     default: return hipErrorInvalidValue;
     }
 #undef WL_ANY

@@ -2088,9 +2088,8 @@ struct Lift2DArgs {
     T norm1, norm2;
 };
 
-// R: ring slots = steps per unrolled iteration; loads run PF = R - DL + AMIN - 1 column pairs ahead.  8 for the bandwidth-bound
-// levels (registers -> occupancy); 16 for the small, latency-bound ones, where a wave is alone on its SIMD and a short
-// prefetch distance leaves a memory latency exposed in every step (128^2 .. 1024^2: ~20 us per level with R = 8).
+// R: ring slots = steps per unrolled iteration; loads run PF = R - DL + AMIN - 1 column pairs ahead (R = 8 everywhere: 16 was
+// measured on the small, latency-bound levels and lost).
 template <typename T, int ID, int R = 8>
 __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 {
@@ -2338,9 +2337,8 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    const bool latency_bound = (int64_t)a.nstrips * a.nchunks * nbatch <= (int64_t)cu_count * 8 && opt("WL_LIFT_R16", 0) != 0;
-    if (latency_bound) hipLaunchKernelGGL((k_lift2d_inv<T, ID, 16>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_lift2d_inv<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    // (a 16-slot ring -- loads 12 pairs ahead -- was measured on the small, latency-bound levels: slower, 13.4 vs 12.1 us)
+    hipLaunchKernelGGL((k_lift2d_inv<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -2356,9 +2354,7 @@ static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    const bool latency_bound = (int64_t)a.nstrips * a.nchunks * nbatch <= (int64_t)cu_count * 8 && opt("WL_LIFT_R16", 0) != 0;
-    if (latency_bound) hipLaunchKernelGGL((k_lift2d_fwd<T, ID, 16>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_lift2d_fwd<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_lift2d_fwd<T, ID, 8>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)nbatch), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
@@ -2598,7 +2594,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 any_fast = true;
                 break;
             }
-            if (aligned && fused_ok(n) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
+            if (aligned && fused_ok(n) && n > l_env("WL_LIFT_GTILE_MAX", 0) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
                 al16(cur) && al16(llbuf) && cur != y) {      // (in place, level 1 reads y while writing it: two passes via T0)
                 // both passes of the level in one kernel: read the block once, write the four quadrants once
                 Lift2DArgs<T> q2;
@@ -2614,7 +2610,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 cur = llbuf; cur_ls = h; pp ^= 1;
                 continue;
             }
-            if (aligned && (lines_ok(n) || short_lift_ok(n))) {
+            if (aligned && n > l_env("WL_LIFT_GTILE_MAX", 0) && (lines_ok(n) || short_lift_ok(n))) {
                 any_fast = true;
                 // rows (dim 2): one streaming pass along the strided axis, T0 = [s-columns | d-columns]
                 ax.src = cur; ax.lds = cur_ls; ax.bs_src = 0; ax.dst = w.T0; ax.ldd = n; ax.bs_dst = 0; ax.R = n; ax.C = n;
@@ -2676,7 +2672,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
-            if (aligned && fused_ok(n) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
+            if (aligned && fused_ok(n) && n > l_env("WL_LIFT_GTILE_MAX", 0) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
                 (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {   // (in place, level 1 writes y while reading it)
                 Lift2DArgs<T> q2;
                 for (int i = 0; i < LIFT_FAST_STEPS; ++i)
@@ -2691,7 +2687,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 llsrc = out; ll_ls = ldo; pp ^= 1;
                 continue;
             }
-            if (aligned && (lines_ok(n) || short_lift_ok(n))) {
+            if (aligned && n > l_env("WL_LIFT_GTILE_MAX", 0) && (lines_ok(n) || short_lift_ok(n))) {
                 any_fast = true;
                 // columns: merged column j -> T0[:, j]
                 if (lines_ok(n)) {

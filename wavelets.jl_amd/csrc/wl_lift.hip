@@ -2075,6 +2075,10 @@ __global__ void __launch_bounds__(64) k_lift_axis_stream(LiftAxisArgs<T> a)
 // k_lift_axis_stream (lanes own 4 consecutive rows, the wave marches along the columns); every finished column pair
 // (its s-column and its d-column) is then lifted along dim 1 ACROSS the lanes (2 row pairs per lane, neighbours by
 // DPP exactly as in k_lift1d_stream) and scattered to the four quadrants.  Strips overlap by one lane on each side.
+// halo lanes on either side of a strip: 4, so that the strip pitch is 224 rows = 7 x 128 bytes of Float32 -- strips whose pitch is
+// not a multiple of the 128-byte line were measured ~15 % slower in pure data movement (tools/probes/march_probe.hip: 134 vs
+// 111-118 us for 8192^2), which is what the 240- / 248-row pitches of the first version cost (level 1: 141 -> see DESIGN)
+constexpr int kLift2dML = 4;
 template <typename T>
 struct Lift2DArgs {
     const T *src; int64_t lds;      // fw: block to transform          inv: coefficient array
@@ -2095,7 +2099,7 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
-    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = 2;   // even margin: lane pairs store together
+    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - DL + CS::TAB.AMIN - 1, ML = kLift2dML;   // even margin: lane pairs store together
     constexpr int VR = (64 - 2 * ML) * RPL;
     static_assert(PF >= 2, "ring too small for this scheme");
     const int lane = threadIdx.x;
@@ -2219,7 +2223,7 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
-    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - 4, ML = 1;
+    constexpr int RPL = 4, DL = CS::TAB.DL, VM = CS::TAB.VM, PF = R - 4, ML = kLift2dML;
     constexpr int VR = (64 - 2 * ML) * RPL;
     static_assert(R - DL + CS::TAB.AMIN - 1 >= 1, "ring too small for this scheme");
     const int lane = threadIdx.x;
@@ -2328,7 +2332,7 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 template <typename T, int ID>
 static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_count, int64_t nbatch = 1)
 {
-    constexpr int VR = 62 * 4;
+    constexpr int VR = (64 - 2 * kLift2dML) * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;
@@ -2345,7 +2349,7 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
 template <typename T, int ID>
 static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_count, int64_t nbatch = 1)
 {
-    constexpr int VR = 60 * 4;
+    constexpr int VR = (64 - 2 * kLift2dML) * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
     int TP = 64;

@@ -664,6 +664,15 @@ static hipError_t launch_inv_dim2(hipStream_t st, const Taps<T> &taps, const T *
 // p + SH of the right half (prefetched 4 steps ahead in a static register ring), reconstructs both along
 // dim 1 (DPP neighbour exchange) into two 4-slot rings of dim-1-reconstructed columns, and combines
 // columns p-SH..p / p..p+SH of those rings into output columns 2p, 2p+1.
+// halo lanes on either side of a strip.  With 2 or 4 coefficient pairs per lane the count is rounded up so that the strip pitch
+// (2 * VP output rows) is a multiple of 32 rows = 128 bytes of Float32: strips that start in the middle of a line cost ~7 % in a
+// same-box A/B of the lifting kernels, and the first version's 240-row pitch was exactly that case.
+constexpr int inv2d_halo_lanes(int SH, int PPL)
+{
+    int hl = (SH + PPL - 1) / PPL;
+    if (PPL >= 2) { const int q = 16 / (2 * PPL); while (((64 - 2 * hl) % (2 * q)) != 0) ++hl; }
+    return hl;
+}
 template <typename T, int F>
 struct Inv2DArgs {
     const T *x; int64_t ldx;        // coefficient array (details; approximation quadrant too when ll == nullptr)
@@ -701,7 +710,7 @@ __device__ __forceinline__ void inv_column(const T (&s)[PPL], const T (&d)[PPL],
 template <typename T, int F, int PPL>
 __global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
 {
-    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL, R = (SH <= 3) ? 4 : 8;
+    constexpr int SH = (F - 2) / 2, HL = inv2d_halo_lanes(SH, PPL), VP = (64 - 2 * HL) * PPL, R = (SH <= 3) ? 4 : 8;
     static_assert(SH <= 4, "ring depth");
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
@@ -782,7 +791,7 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
                                T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count,
                                int64_t nbatch = 1, int64_t bs_x = 0, int64_t bs_ll = 0, int64_t bs_dst = 0, int nll = 1)
 {
-    constexpr int SH = (F - 2) / 2, HL = (SH + PPL - 1) / PPL, VP = (64 - 2 * HL) * PPL;
+    constexpr int SH = (F - 2) / 2, HL = inv2d_halo_lanes(SH, PPL), VP = (64 - 2 * HL) * PPL;
     Inv2DArgs<T, F> a;
     a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
     a.bs_x = bs_x; a.bs_ll = bs_ll; a.bs_dst = bs_dst; a.nll = nll;

@@ -170,3 +170,13 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
     # custom estnoise: the same estimate computed by the caller must give the same bits
     y2 = host(W, W.denoise(bd, TI=True, nspin=(4, 3), estnoise=lambda a, w: W.noisest(a, w)))
     assert np.array_equal(y2, e)
+    # sizes that are not powers of two (the batch runs through the any-size per-axis kernels): 2-D image and a long line
+    c = (0.5 * rng_array((200, 200), np.float64, 5)).astype(dtype)
+    Lc = min(W.maxtransformlevels(c), 6)
+    ec = _oracle_denoise(oracle, W, c, wt, Lc, W.VisuShrink(200), True, (3, 2))
+    assert np.array_equal(host(W, W.denoise(W.to_device(c), TI=True, nspin=(3, 2))), ec)
+    assert np.array_equal(host(W, W.denoise(W.to_device(c))), _oracle_denoise(oracle, W, c, wt, Lc, W.VisuShrink(200), False, (8, 8)))
+    v3 = (0.5 * rng_array((3000,), np.float64, 6)).astype(dtype)
+    L3 = min(W.maxtransformlevels(v3), 6)
+    e3 = _oracle_denoise(oracle, W, v3, wt, L3, W.VisuShrink(3000), True, (5,))
+    assert np.array_equal(host(W, W.denoise(W.to_device(v3), TI=True, nspin=5)), e3)

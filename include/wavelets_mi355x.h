@@ -152,6 +152,13 @@ WL_API int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y,
                     int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
                     const int32_t *step_shift, const double *coefs_flat,
                     double norm1, double norm2, int L, int fw, void *stream);
+/* Out-of-place variant (x -> y, same shapes and ld): saves the copy a caller would otherwise make before the in-place call and
+ * the staging copy the in-place first level needs (y == x is allowed and is the in-place call).                              */
+WL_API int wl_dwtc_lifting_oop(wl_ctx *ctx, int dtype, void *y, const void *x,
+                        int64_t len, int64_t nsignals, int64_t ld,
+                        int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                        const int32_t *step_shift, const double *coefs_flat,
+                        double norm1, double norm2, int L, int fw, void *stream);
 
 /* ---- wavelet packet transform (1-D) --------------------------------------------------- */
 /* y = wpt(x, filter, tree) / iwpt.  tree: one byte per node of the BitVector

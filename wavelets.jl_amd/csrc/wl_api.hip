@@ -466,6 +466,23 @@ int wl_dwtc_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t len, 
                            : dwt_filter_impl<double>(ctx, st, b, (double *)y, (const double *)x, qmf, flen, L, fw);
 }
 
+int wl_dwtc_lifting_oop(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t len, int64_t nsignals, int64_t ld,
+                        int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                        const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                        int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    BoxSpec b;
+    int rc = check_dwtc(len, nsignals, ld, L, b);
+    if (rc) return rc;
+    WL_SCOPE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == WL_F32
+               ? dwt_lifting_impl<float>(ctx, st, b, (float *)y, (const float *)x, nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, L, fw)
+               : dwt_lifting_impl<double>(ctx, st, b, (double *)y, (const double *)x, nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, L, fw);
+}
+
 int wl_dwtc_lifting(wl_ctx *ctx, int dtype, void *y, int64_t len, int64_t nsignals, int64_t ld,
                     int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
                     const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,

@@ -390,6 +390,24 @@ k_generic_copy_box(const T *__restrict__ src, Strides3 sst, T *__restrict__ dst,
     }
 }
 
+// the same copy for boxes whose lines are contiguous, 16-byte aligned and a multiple of 16 bytes long (the staging copies of the
+// in-place transforms: 512 MiB for an in-place batched inverse): one 16-byte access per thread and step, lines over
+// blockIdx.y / z with grid-stride loops, no index division (the element-wise kernel above moves 1.3 TB/s)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_copy_lines(const T *__restrict__ src, Strides3 sst, T *__restrict__ dst, Strides3 dst_st, Extent3 n)
+{
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const int64_t nv = n.n[0] / V;
+    for (int64_t i2 = blockIdx.z; i2 < n.n[2]; i2 += gridDim.z)
+        for (int64_t i1 = blockIdx.y; i1 < n.n[1]; i1 += gridDim.y) {
+            const VT *sp = reinterpret_cast<const VT *>(src + i1 * sst.s[1] + i2 * sst.s[2]);
+            VT *dp = reinterpret_cast<VT *>(dst + i1 * dst_st.s[1] + i2 * dst_st.s[2]);
+            for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nv; i0 += (int64_t)gridDim.x * kBlock) dp[i0] = sp[i0];
+        }
+}
+
 // --------------------------------------------------------------------------------------
 // launchers
 template <typename T>
@@ -457,6 +475,21 @@ hipError_t generic_lift_merge(hipStream_t st, const T *w, Strides3 wst, T *dst, 
 template <typename T>
 hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, Strides3 dst_st, Extent3 n)
 {
+    constexpr int V = 16 / sizeof(T);
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (sst.s[0] == 1 && dst_st.s[0] == 1 && (n.n[0] % V) == 0 && (sst.s[1] % V) == 0 && (sst.s[2] % V) == 0 && (dst_st.s[1] % V) == 0 &&
+        (dst_st.s[2] % V) == 0 && al(src) && al(dst) && n.n[0] >= V) {
+        int64_t gx = (n.n[0] / V + kBlock - 1) / kBlock, gy = n.n[1], gz = n.n[2];
+        if (gy > 65535) gy = 65535;
+        if (gz > 65535) gz = 65535;
+        while (gx * gy * gz > 16384) {
+            if (gz > 1 && gz >= gy) gz = (gz + 1) / 2;
+            else if (gy > 1) gy = (gy + 1) / 2;
+            else gx = (gx + 1) / 2;
+        }
+        hipLaunchKernelGGL(k_copy_lines<T>, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(kBlock), 0, st, src, sst, dst, dst_st, n);
+        return hipGetLastError();
+    }
     int64_t total = n.n[0] * n.n[1] * n.n[2];
     hipLaunchKernelGGL(k_generic_copy_box<T>, grid_for(total), dim3(kBlock), 0, st, src, sst, dst, dst_st, n);
     return hipGetLastError();

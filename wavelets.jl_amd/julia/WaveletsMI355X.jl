@@ -154,12 +154,12 @@ end
 
 for (f, fw) in ((:dwtc, true), (:idwtc, false))
     @eval function $f(x::ROCMatrix{T}, scheme::GLS, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T<:Union{Float32,Float64}}
-        y = copy(x)                                 # lifting is in place (transforms_lifting.jl:30)
+        y = similar(x)                              # out of place straight from x: no copy, no in-place staging
         isup, nc, sh, cf = flatten(scheme)
-        check(ccall((:wl_dwtc_lifting, LIB), Cint,
-                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+        check(ccall((:wl_dwtc_lifting_oop, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
                      Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
-                    ctx(), DT[T], pointer(y), size(y, 1), size(y, 2), size(y, 1), length(isup), isup, nc, sh, cf,
+                    ctx(), DT[T], pointer(y), pointer(x), size(y, 1), size(y, 2), size(y, 1), length(isup), isup, nc, sh, cf,
                     scheme.norm1, scheme.norm2, L, $fw, stream()))
         return y
     end

@@ -395,11 +395,11 @@ def _xwtc(x, wt, L, fw, y=None):
     if isinstance(wt, GLS):
         if y is None:
             y = similar(x)
-        y.copy_(x)
         iu, nc, sh, cf = wt.flatten()
-        rc = lib.wl_dwtc_lifting(h, _dtype_code(y), C.c_void_p(y.data_ptr()), length, nsig, length,
-                                 len(iu), _i32p(iu), _i32p(nc), _i32p(sh), _f64p(cf), wt.norm1, wt.norm2,
-                                 L, 1 if fw else 0, st)
+        # out of place straight from x (no copy, no staging of the in-place first level); y is x: the in-place transform
+        rc = lib.wl_dwtc_lifting_oop(h, _dtype_code(y), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), length, nsig, length,
+                                     len(iu), _i32p(iu), _i32p(nc), _i32p(sh), _f64p(cf), wt.norm1, wt.norm2,
+                                     L, 1 if fw else 0, st)
         _check(rc, h)
         return y
     raise TypeError("wt must be an OrthoFilter or a GLS")

@@ -446,7 +446,7 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
     for a fused pair) is exactly one launch of that kernel (its first-level template instance, which
     rocprofv3 --stats reports under its own name).  `frac` uses HIP events on the launch stream around a train of
     such launches (live, this run); `rocprof` repeats the computation from the committed rocprofv3 summary."""
-    Ldom = 2 if main_kernel in ("k_fwd2d_stream2", "k_fwd2d_lds2") else 1
+    Ldom = 2 if main_kernel in ("k_fwd2d_stream2", "k_fwd2d_pair") else 1
     y1 = W.similar(x)
     fn1 = (lambda: W.dwtc_(y1, x, wt, Ldom)) if batched else (lambda: W.dwt_oop_(y1, x, wt, Ldom))
     reps = max(20, min(args.steps, 200))

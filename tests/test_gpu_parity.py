@@ -236,15 +236,13 @@ def test_fused_level_pair_kernel(gpu, W, oracle):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("pair", [1, 0])
-def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
-    """k_fwd2d_lds (one or two fused 2-D levels, dim-1 pass through an LDS exchange): every workgroup shape
+def test_lds_exchange_2d_kernel(gpu, W, oracle, mode):
+    """k_fwd2d_lds (one fused 2-D level per launch, dim-1 pass through an LDS exchange): every workgroup shape
     (mode 0 = exact tiling with the halo helper wave where the row count allows it, 1..4 = overlapped strips of
     1..4 waves), every supported filter length, odd/even depths, non-square blocks, partial strips and chunks,
     row counts that are not multiples of a strip -- bit for bit against the oracle."""
     W.set_option("WL_LDS_MODE", mode)
-    W.set_option("WL_FUSE2", pair)
-    W.set_option("WL_LDS_PAIR_MIN", 0)
+    W.set_option("WL_FUSE2", 0)
     W.set_option("WL_M2D_MAX", 128)      # (the tile kernels would otherwise take everything up to 2048 x 2048)
     W.set_option("WL_TILE", 0)
     shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4, 9)), ((528, 96), (1, 2, 4)), ((4096, 64), (1, 2)),
@@ -255,9 +253,46 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode, pair):
             wt = W.wavelet(getattr(W.WT, fname))
             for L in Ls:
                 y = host(W, W.dwt(dev(W, x), wt, L))
-                assert W.last_kernel() in ("k_fwd2d_lds", "k_fwd2d_lds2"), (shape, L, W.last_kernel())
+                assert W.last_kernel() == "k_fwd2d_lds", (shape, L, W.last_kernel())
                 ye = oracle.dwt_filter(x, wt.qmf, L)
-                assert np.array_equal(y, ye), (shape, fname, L, mode, pair, float(np.abs(y - ye).max()))
+                assert np.array_equal(y, ye), (shape, fname, L, mode, float(np.abs(y - ye).max()))
+
+
+@pytest.mark.parametrize("tj", [32, 64, 128])
+@pytest.mark.parametrize("wmain", [2, 4])
+def test_fused_pair_2d_kernel(gpu, W, oracle, wmain, tj):
+    """k_fwd2d_pair (wl_pair2d.hip: two fused 2-D levels per launch, the second one on a dedicated wave of every workgroup
+    fed from an LDS column ring): strips of 512 / 1024 rows, every chunk length, every supported filter length (the
+    level-2 lag and the number of steps past the chunk depend on it), odd / even depths (pairs followed by a single level),
+    non-square blocks, one strip only (halo rows wrap onto the strip itself), chunks shorter than the others, blocks with
+    64 columns -- bit for bit against the oracle.  Default dispatch uses it from 4096^2 upwards; WL_LDS_PAIR_MIN = 0 forces it."""
+    W.set_option("WL_LDS_PAIR_MIN", 0)
+    W.set_option("WL_PAIR_W", wmain)
+    W.set_option("WL_TJ2", tj)
+    W.set_option("WL_PAIR_WG_PER_CU", 0)  # (keep the requested chunk length)
+    W.set_option("WL_M2D_MAX", 128)
+    W.set_option("WL_TILE", 0)
+    shapes = (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (2, 4, 9)), ((4096, 64), (2,)), ((1536, 160), (2, 3)),
+              ((1024, 96), (2,)), ((512, 1056), (2, 4)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape) + wmain + tj)
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_pair", (shape, L, W.last_kernel())
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                if not np.array_equal(y, ye):
+                    bad = np.argwhere(y != ye)
+                    raise AssertionError((shape, fname, L, wmain, tj, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist(),
+                                          float(np.abs(y - ye).max())))
+    # shapes the pair kernel declines (rows not a multiple of 512, columns not a multiple of 32) fall back to single levels
+    for shape in ((768, 1024), (1024, 80)):
+        x = rng_array(shape, np.float32, 5)
+        wt = W.wavelet(W.WT.db4)
+        y = host(W, W.dwt(dev(W, x), wt, 2))
+        assert W.last_kernel() == "k_fwd2d_lds", (shape, W.last_kernel())
+        assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2)), shape
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

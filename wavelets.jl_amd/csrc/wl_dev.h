@@ -137,4 +137,32 @@ __device__ __forceinline__ void window_inv(const T (&sw)[(F - 2) / 2 + 1], const
 }
 
 
+// ---- hand-placed vector-memory loads / waits of the 2-D marching kernels (wl_fwd2d.hip, wl_pair2d.hip) ----
+__device__ __forceinline__ void wg_lds_sync(bool multi)
+{
+    if (multi) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// LVL1 only gives the launch that consumes the full-size input its own symbol (rocprofv3 --stats then reports the dominant
+// kernel separately from the same code running on the smaller levels).
+// Column loads and their waits are written by hand.  hipcc's own wait-count insertion, given the rotating 16-slot ring, puts
+// vmcnt(1) / vmcnt(0) in front of two of every eight steps (checked in the ISA: tools/probes/waitcnt_probe.hip has the small
+// reproduction): the wave then waits for the loads it issued a few instructions earlier AND for all of its stores, twice per
+// iteration -- the four-step prefetch distance never exists.  Here the load is opaque to the compiler and the wait names the
+// two ring slots it guards, so every consumer depends on the wait through its data.
+typedef float F4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(F4 &dst, const float *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// "at most N vector-memory operations outstanding": loads and stores retire in issue order on gfx9-family counters, so this
+// covers every load that has at least N younger operations behind it.
+template <int N>
+__device__ __forceinline__ void wait_vm(F4 &a, F4 &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+
 }  // namespace wl

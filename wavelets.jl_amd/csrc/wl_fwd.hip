@@ -1351,7 +1351,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
                 int nlev = 0;
                 if ((L - l + 1) >= 2 && env_int("WL_FUSE2", 1) && fwd2d_lds_ok(F, 2, n[0], n[1]) &&
-                    n[0] * n[1] >= (int64_t)opt("WL_LDS_PAIR_MIN", (long long)1 << 62))
+                    n[0] * n[1] >= (int64_t)opt("WL_LDS_PAIR_MIN", (long long)1 << 24))
                     nlev = 2;
                 else if (fwd2d_lds_ok(F, 1, n[0], n[1]))
                     nlev = 1;
@@ -1360,7 +1360,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     T *lld = lastp ? y : llbuf;
                     const int64_t ldd = lastp ? b.full.s[1] : (n[0] >> nlev);
                     WL_TRY(fwd2d_lds_launch(st, taps, nlev, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, n[0], n[1], cu_count));
-                    if (!dominant) dominant = (nlev == 2) ? "k_fwd2d_lds2" : "k_fwd2d_lds";
+                    if (!dominant) dominant = (nlev == 2) ? "k_fwd2d_pair" : "k_fwd2d_lds";
                     lstep = nlev;
                     int64_t hn2[3] = {n[0] >> nlev, n[1] >> nlev, n[2]};
                     cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;

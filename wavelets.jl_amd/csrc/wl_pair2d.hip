@@ -1,0 +1,382 @@
+// wl_pair2d.hip -- TWO fused forward 2-D filter-bank levels per launch, Float32, even F <= 10 (transforms_filter.jl:161-186, two
+// trips of the level loop): the level-l approximation never goes to HBM.
+//
+//   k_fwd2d_pair<F, W, LVL1>
+//
+// A workgroup owns a strip of 256 W rows (W = 4 or 2) and marches along the columns of a chunk exactly like k_fwd2d_lds
+// (wl_fwd2d.hip): W main waves (4 rows per lane, 16-slot column ring in VGPRs filled by hand-placed global_load_dwordx4, dim-2
+// pass in registers, dim-1 pass on 12-row windows read back from a two-slot LDS exchange) and one helper wave that supplies
+// the halo rows above the strip.  Level l+1 is NOT interleaved into those waves (the round-2 attempt: one more dependent LDS
+// round trip on every step's critical path, 143 VGPRs, 135-140 us against 105 + 34 for two launches).  Instead:
+//
+//   * the main waves and the helper park the level-l approximation column they produce at step t (rows 0 .. 128 W + 7 of the
+//     strip: 128 W owned + 8 halo rows from the helper) in slot t % 16 of an LDS column ring -- one ds_write_b64 per lane;
+//   * a dedicated LEVEL-(l+1) WAVE (wave W + 1) owns all 128 W approximation rows (2 W per lane).  At even steps it runs the
+//     dim-2 pass on ring columns t-F .. t-1 and publishes {scaling, detail} pairs in a second exchange buffer; at odd steps it
+//     reads its (2 W + 8)-row window back, runs the dim-1 pass and stores the four level-(l+1) quadrants with 16-byte stores
+//     (W = 4: s2 rows 4j .. 4j+3, d2 rows 4j+4 .. 4j+7 of lane j -- no partner exchange).  Its arithmetic per step equals a
+//     main wave's (a quarter of the samples, all on one wave), so it never is the slowest wave at the step barrier;
+//   * the helper also runs the level-(l+1) dim-2 pass for the 8 halo rows it produced.
+//
+// All waves meet at ONE s_barrier per step (the level-1 exchange's); the level-(l+1) wave needs no other synchronisation: ring
+// slot c is written after barrier c and read after barriers > c, rewritten after barrier c + 16; the second exchange buffer
+// is written after an even barrier and read after the following odd one.
+//
+// A chunk of TJ input columns owns TJ/2 level-l and TJ/4 level-(l+1) output columns.  The last level-(l+1) column needs
+// level-l columns up to TJ/2 + F - 3, so the march runs F steps past the chunk: F - 2 that produce approximation columns only
+// (no detail arithmetic, no stores) and 2 in which only the level-(l+1) wave works.
+// Arithmetic: closed forms of wl_internal.h in the reference's order, no FMA -- bit-identical to two single-level launches.
+#include "wl_fast.h"
+#include "wl_dev.h"
+
+namespace wl {
+
+template <int F>
+struct Pair2DArgs {
+    const float *src; int64_t lds;
+    float *y; int64_t ldy;
+    float *ll; int64_t ldll;          // approximation after both levels: next stage's input buffer, or y itself
+    int64_t ms, ns;                   // level-l block
+    int TJ;                           // owned input columns per chunk (multiple of 32)
+    int nstrips, nchunks;
+    int rev;
+    TapsF<float, F> tp;
+};
+
+template <int F, int W, int LVL1>
+__global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
+{
+    typedef float T;
+    typedef float T2 __attribute__((ext_vector_type(2)));
+    typedef float T4 __attribute__((ext_vector_type(4)));
+    constexpr int SH = (F - 2) / 2;
+    constexpr int R = 16, U = 8, PFD = (R - F) / 2;
+    constexpr int NT1 = 64 * (W + 1);                 // lanes of the level-l exchange (main waves + helper)
+    constexpr int ROWS1 = 4 * NT1 + 16;
+    constexpr int NPL = 64 * W;                       // owned lanes
+    constexpr int NLOAD = NPL + 6;                    // + halo lanes: 24 rows above the strip
+    constexpr int RL = 128 * W + 16;                  // approximation rows per ring slot: 128 W owned + 8 halo (+ 8 pad)
+    constexpr int NSLOT = 16;
+    constexpr int RW = 2 * W;                         // approximation rows per lane of the level-(l+1) wave
+    constexpr int HS = W;                             // its s2 (and d2) rows per lane
+    __shared__ __attribute__((aligned(16))) T2 x1[2 * ROWS1];
+    __shared__ __attribute__((aligned(16))) T ll1[NSLOT * RL];
+    __shared__ __attribute__((aligned(16))) T2 x2[RL];
+
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t first = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1u : 0u);
+    uint32_t logical = first + (b >> 3);
+    if (a.rev) logical = first + (cnt - 1 - (logical - first));
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+
+    const int64_t ms = a.ms, ns = a.ns, nxj = ns >> 1, nxj2 = ns >> 2;
+    const int msi = (int)ms, hmi = msi >> 1, hm2i = msi >> 2;
+    const int64_t j0 = (int64_t)chunk * a.TJ;
+    const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
+    const int S_own = (int)((jend - j0) >> 1);        // steps whose level-l outputs this chunk owns (multiple of 16)
+    const int S = S_own + F;                          // the level-(l+1) column of ring columns c .. c+F-1 is taken up at step c + F
+    T *const yb = a.y;
+    T *const llb = a.ll ? a.ll : a.y;
+    const int64_t ldl = a.ll ? a.ldll : a.ldy;
+
+    if (wv == W + 1) {
+        // =============================== the level-(l+1) wave ===============================
+        const int j = (int)(threadIdx.x & 63);
+        const int s2row = strip * (64 * W) + HS * j;                         // first s2 row of this lane
+        int d2row = s2row + 4;  if (d2row >= hm2i) d2row -= hm2i;            // first d2 row (details are stored shifted by 4)
+        const T *const l1 = ll1 + RW * j;
+        T2 *const xw = x2 + RW * j;
+        const int64_t kbase2 = j0 >> 2;
+        for (int t = 0; t < F; ++t) wg_lds_sync(true);
+        for (int t = F; t < S; t += 2) {
+            wg_lds_sync(true);                                               // barrier t (even): ring columns <= t-1 are visible
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                T sa[RW], da[RW];
+#pragma unroll
+                for (int m = 0; m < F; ++m) {
+                    const T *const col = l1 + ((t - F + m) & (NSLOT - 1)) * RL;
+                    T xm[RW];
+#pragma unroll
+                    for (int c = 0; c < RW / 4; ++c) {
+                        const T4 v = *reinterpret_cast<const T4 *>(col + 4 * c);
+                        xm[4 * c] = v.x; xm[4 * c + 1] = v.y; xm[4 * c + 2] = v.z; xm[4 * c + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        if (m == 0) { sa[r] = a.tp.h[0] * xm[r]; da[r] = a.tp.g[F - 1] * xm[r]; }
+                        else { sa[r] = sa[r] + a.tp.h[m] * xm[r]; da[r] = da[r] + a.tp.g[F - 1 - m] * xm[r]; }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < RW / 2; ++c)
+                    *reinterpret_cast<T4 *>(xw + 2 * c) = T4{sa[2 * c], da[2 * c], sa[2 * c + 1], da[2 * c + 1]};
+            }
+            wg_lds_sync(true);                                               // barrier t + 1 (odd)
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                T2 E[RW + 8];
+#pragma unroll
+                for (int c = 0; c < (RW + 8) / 2; ++c) {
+                    const T4 v = *reinterpret_cast<const T4 *>(xw + 2 * c);
+                    E[2 * c] = T2{v.x, v.y};
+                    E[2 * c + 1] = T2{v.z, v.w};
+                }
+                T2 P[HS], Q[HS];                       // P[q] = {ss2, sd2} of row s2row + q;  Q[q] = {ds2, dd2} of row d2row + q
+#pragma unroll
+                for (int q = 0; q < HS; ++q) {
+                    T2 s = a.tp.h[0] * E[2 * q];
+#pragma unroll
+                    for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
+                    T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+#pragma unroll
+                    for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+                    P[q] = s;
+                    Q[q] = d;
+                }
+                const int64_t k2 = kbase2 + ((t - F) >> 1);
+                int64_t kd2 = k2 + SH;
+                if (kd2 >= nxj2) kd2 -= nxj2;
+                T *const ck = yb + k2 * a.ldy, *const ckd = yb + (nxj2 + kd2) * a.ldy, *const cl = llb + k2 * ldl;   // (uniform)
+                if constexpr (HS == 4) {
+                    *reinterpret_cast<T4 *>(cl + s2row) = T4{P[0].x, P[1].x, P[2].x, P[3].x};
+                    *reinterpret_cast<T4 *>(ck + (hm2i + d2row)) = T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x};
+                    *reinterpret_cast<T4 *>(ckd + s2row) = T4{P[0].y, P[1].y, P[2].y, P[3].y};
+                    *reinterpret_cast<T4 *>(ckd + (hm2i + d2row)) = T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y};
+                } else {
+                    *reinterpret_cast<T2 *>(cl + s2row) = T2{P[0].x, P[1].x};
+                    *reinterpret_cast<T2 *>(ck + (hm2i + d2row)) = T2{Q[0].x, Q[1].x};
+                    *reinterpret_cast<T2 *>(ckd + s2row) = T2{P[0].y, P[1].y};
+                    *reinterpret_cast<T2 *>(ckd + (hm2i + d2row)) = T2{Q[0].y, Q[1].y};
+                }
+            }
+        }
+        return;
+    }
+
+    // =============================== main waves and the helper: level l ===============================
+    const int lp = threadIdx.x;                       // L': lane index within the workgroup's strip (0 .. NT1-1)
+    const int gi = strip * (4 * NPL) + 4 * lp;        // first row of this lane (halo lanes may exceed ms: wrap)
+    int row = gi;
+    if (row >= msi) row -= msi;
+    const bool loader = lp < NLOAD;
+    const bool helper = (wv == W);
+    const int ko = gi >> 1;
+    int kod = ko + 4;  if (kod >= hmi) kod -= hmi;    // first d row of this lane
+    const bool odd = (lp & 1) != 0;
+    const T *base = a.src + row;
+    const int64_t kbase = j0 >> 1;
+
+    T4 ring[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) ring[c] = T4{0.f, 0.f, 0.f, 0.f};
+    if (loader) {
+#pragma unroll
+        for (int c = 0; c < R - 2; ++c) {
+            int64_t jc = j0 + c;
+            if (jc >= ns) jc -= ns;
+            gload16(ring[c], base + jc * a.lds);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
+
+    // FULL: a step inside the chunk (details computed and stored).  !FULL: one of the F - 2 steps past the chunk that only produce
+    // the approximation column (and, for the helper, the level-(l+1) dim-2 pass of its halo rows).
+    auto step = [&](const int t, const int u, const bool prefetch, const bool full, const bool produce) __attribute__((always_inline)) {
+        if (prefetch && loader) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int64_t jc = j0 + 2 * t + (R - 2) + e;
+                if (jc >= ns) jc -= ns;
+                if (jc >= ns) jc -= ns;
+                gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
+            }
+        }
+        if (produce) {
+            if (prefetch) {
+                // The two newest window columns were requested PFD steps ago.  The wait counts LOADS only: "at most 2 PFD vector
+                // memory operations outstanding" is implied by "those two loads have landed" only if every younger operation
+                // counted is a load (loads return in order among themselves).  Counting the younger STORES as well (3 per step
+                // for a main wave) looked equivalent but is not: on some MI355X boxes about one transform in a thousand came
+                // back with a few columns computed from stale ring registers (10-tap filters, PFD = 3) -- stores can be
+                // acknowledged before an older load returns.  Waiting for the older stores too costs nothing measurable
+                // (8192^2 db4 pair: 114.8 vs 115.0 us).
+                wait_vm<2 * PFD>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);
+            } else {
+                wait_vm<0>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);
+            }
+        }
+        T2 *const w1 = x1 + (t & 1) * ROWS1;
+        // the helper's halo rows feed the main lanes' windows with both components inside the chunk; its own outputs are
+        // approximation rows only (helper: wave-uniform run-time flag; !full: compile-time)
+        const bool sonly = !full;
+        if (produce) {
+            // ---- level l, dim-2 pass on row pairs: {A, B}[r] = scaling / detail (column k / kd) of row r ----
+            T2 sa01 = a.tp.h[0] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
+            T2 sa23 = a.tp.h[0] * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
+#pragma unroll
+            for (int m = 1; m < F; ++m) {
+                const T4 xm = ring[(2 * u + m) % R];
+                sa01 = sa01 + a.tp.h[m] * T2{xm.x, xm.y};
+                sa23 = sa23 + a.tp.h[m] * T2{xm.z, xm.w};
+            }
+            T2 da01 = T2{0.f, 0.f}, da23 = T2{0.f, 0.f};
+            if (!sonly) {
+                da01 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
+                da23 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
+#pragma unroll
+                for (int m = 1; m < F; ++m) {
+                    const T4 xm = ring[(2 * u + m) % R];
+                    da01 = da01 + a.tp.g[F - 1 - m] * T2{xm.x, xm.y};
+                    da23 = da23 + a.tp.g[F - 1 - m] * T2{xm.z, xm.w};
+                }
+            }
+            *reinterpret_cast<T4 *>(w1 + 4 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
+            *reinterpret_cast<T4 *>(w1 + 4 * lp + 2) = T4{sa23.x, da23.x, sa23.y, da23.y};
+        }
+        wg_lds_sync(true);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- helper, even steps: level-(l+1) dim-2 pass of the halo rows 128 W + 2i, 128 W + 2i + 1 (lanes i = 0..3) ----
+        if (helper && !(u & 1) && t >= F) {
+            if (lp < NPL + 4) {
+                T2 s2, d2;
+#pragma unroll
+                for (int m = 0; m < F; ++m) {
+                    const T2 xm = *reinterpret_cast<const T2 *>(ll1 + ((t - F + m) & (NSLOT - 1)) * RL + 2 * lp);
+                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = a.tp.g[F - 1] * xm; }
+                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + a.tp.g[F - 1 - m] * xm; }
+                }
+                *reinterpret_cast<T4 *>(x2 + 2 * lp) = T4{s2.x, d2.x, s2.y, d2.y};
+            }
+        }
+        if (!produce) return;
+        T *const slot = ll1 + (t & (NSLOT - 1)) * RL + 2 * lp;
+        if (sonly || helper) {
+            // ---- approximation only: ss rows ko, ko+1 from window rows 4L' .. 4L'+F+1 ----
+            T A[12];
+#pragma unroll
+            for (int c = 0; c < (F + 3) / 2; ++c) {
+                const T4 v = *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
+                A[2 * c] = v.x;
+                A[2 * c + 1] = v.z;
+            }
+            T p0 = a.tp.h[0] * A[0], p1 = a.tp.h[0] * A[2];
+#pragma unroll
+            for (int m = 1; m < F; ++m) { p0 = p0 + a.tp.h[m] * A[m]; p1 = p1 + a.tp.h[m] * A[2 + m]; }
+            if (lp < NPL + 4) *reinterpret_cast<T2 *>(slot) = T2{p0, p1};
+            return;
+        }
+        // ---- level l, dim-1 pass: window rows 4L' .. 4L'+11 as {A, B} pairs ----
+        T2 E[12];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const T4 v = *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
+            E[2 * c] = T2{v.x, v.y};
+            E[2 * c + 1] = T2{v.z, v.w};
+        }
+        T2 P[2], Q[2];                                 // P[q] = {ss, sd} of row ko + q;  Q[q] = {ds, dd} of row kod + q
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            T2 s = a.tp.h[0] * E[2 * q];
+#pragma unroll
+            for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
+            T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+#pragma unroll
+            for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+            P[q] = s;
+            Q[q] = d;
+        }
+        *reinterpret_cast<T2 *>(slot) = T2{P[0].x, P[1].x};             // approximation column kbase + t -> ring
+        const int64_t k = kbase + t;
+        int64_t kd = k + SH;
+        if (kd >= nxj) kd -= nxj;
+        // even lane: ds rows kod..kod+3 of column k;  odd lane: sd rows ko-2..ko+1 and dd rows kod-2..kod+1 of column kd
+        T rA[2], rB[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rA[q] = from_partner(odd ? Q[q].x : P[q].y);
+            rB[q] = from_partner(Q[q].y);
+        }
+        T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy;      // (uniform)
+        if (!odd) {
+            *reinterpret_cast<T4 *>(ck + (hmi + kod)) = T4{Q[0].x, Q[1].x, rA[0], rA[1]};
+        } else {
+            *reinterpret_cast<T4 *>(ckd + (ko - 2)) = T4{rA[0], rA[1], P[0].y, P[1].y};
+            *reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)) = T4{rB[0], rB[1], Q[0].y, Q[1].y};
+        }
+    };
+
+    int t0 = 0;
+    for (; t0 < S_own; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(t0 + u, u, true, true, true);
+    }
+    // F steps past the chunk: columns S_own .. S_own+F-3 of the approximation feed the last level-(l+1) columns; loads are needed
+    // up to step S_own + F - 3 (requested PFD steps ahead)
+#pragma unroll
+    for (int u = 0; u < F; ++u) step(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
+}
+
+// ------------------------------------------------------------------------------------------
+bool fwd2d_pair_ok(int F, int64_t ms, int64_t ns)
+{
+    if (F < 2 || F > 10 || (F & 1)) return false;
+    if (ms >= ((int64_t)1 << 29)) return false;
+    // rows: exact strips of 512 (W = 2) or 1024 (W = 4); columns: level-(l+1) columns come in pairs of steps, chunks of 32
+    return ms >= 512 && (ms % 512) == 0 && ns >= 64 && (ns % 32) == 0;
+}
+
+template <int F, int W>
+static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    Pair2DArgs<F> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
+    a.nstrips = (int)(ms / (256 * W));
+    int TJ = (int)opt("WL_TJ2", 128);
+    if (TJ < 32) TJ = 32;
+    TJ &= ~31;
+    // one resident round of workgroups (W = 2: four 4-wave workgroups per CU): shorter chunks pay 3 (F - 2) halo columns each,
+    // but a chip that is not full is latency-bound (8192^2: 1024 workgroups 116 us, 512 workgroups 129 us; 4096^2: 34.5 vs 39 us)
+    auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
+    while (TJ > 32 && (TJ % 64) == 0 && nwgs(TJ) < (int64_t)cu_count * opt("WL_PAIR_WG_PER_CU", 4)) TJ >>= 1;
+    a.TJ = TJ;
+    a.nchunks = (int)((ns + TJ - 1) / TJ);
+    a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
+    a.tp = shrink<float, F>(taps);
+    const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
+    if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, W, 1>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
+    else hipLaunchKernelGGL((k_fwd2d_pair<F, W, 0>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int F>
+static hipError_t launch_pair_f(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                                float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    // strips of 512 rows by default: 4-wave workgroups, four per CU, beat 6-wave workgroups of 1024 rows (8192^2 db4: 116 vs 135 us)
+    int W = (int)opt("WL_PAIR_W", 2);
+    if (W != 2 && W != 4) W = 2;
+    if ((ms % (256 * W)) != 0) W = 2;
+    if (W == 4) return launch_pair_fw<F, 4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    return launch_pair_fw<F, 2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+}
+
+hipError_t fwd2d_pair_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+{
+    switch (taps.F) {
+    case 2: return launch_pair_f<2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    case 4: return launch_pair_f<4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    case 6: return launch_pair_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    case 8: return launch_pair_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    case 10: return launch_pair_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace wl

@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X DWT backend (driver contract: one JSON line).
+"""bench.py -- headline benchmark of the MI355X DWT backend (driver contract: ONE JSON line, the last line on stdout).
 
-A "step" is one full forward transform (the non-allocating dwt!(y, x, wt, L) entry point) of one
-synthetic array already resident in HBM:
-    default workload  C3 = 2-D dwt, WT.db4 filter bank, 8192 x 8192 Float32, L = 13 (API default)
-                      (BASELINE.json configs[2], the configuration the metric is quoted on)
-With --gpus N > 1 the script runs one rank per GPU over RCCL: under torch.distributed.run (the driver's form) it
-reads RANK / LOCAL_RANK / WORLD_SIZE; started plainly (`python bench.py --gpus N`) it re-launches ITSELF through
-torch.distributed.run with N ranks.  Every rank transforms its own independent 8192 x 8192 array (a batch of N images
-sharded one per GPU: weak scaling, no data-path collective; the filter taps are broadcast from rank 0 over
-RCCL/xGMI before the timed region, as north_star prescribes).  value = whole-job Msamples/s = N * samples /
-max-over-ranks time.  Beside it, `c5_batched` reports BASELINE.json configs[4]: the 65536-signal x 2^16 batch sharded
-65536/N columns per rank (sharding.shard_range), aggregate Msamples/s and GB/s, checksum all-reduced.
+A "step" is one full forward transform through the non-allocating entry point (dwt!(y, x, wt, L) / dwtc) of synthetic
+data already resident in HBM; output array and workspace are allocated once, outside the timed region.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (the level-1 launch of k_fwd2d_stream, which moves 8 B/sample):
-                algorithmic bytes / average launch duration measured with HIP events on the launch
-                stream around single-launch (L = 1) calls; peak = 8000 GB/s (MI355X HBM3E spec)
-  cpu_baseline  the oracle (literal C restatement of the reference's loops, 1 thread -- the
-                reference has no threading) timed on this host on a bounded sample
+  --gpus 1 (default)   workload C3 = BASELINE.json configs[2], the configuration the metric is quoted on:
+                       2-D dwt, WT.db4 filter bank, 8192 x 8192 Float32, L = 13 (API default).  The K timed steps rotate over
+                       THREE distinct input arrays (768 MiB together, beyond the 256 MiB Infinity Cache), so no step finds its
+                       input cached by the previous one.  `by_depth` repeats the measurement at L = 1, 4, 13.
+  --gpus N > 1         workload C5 = configs[4]: batched column-wise dwt, WT.db4, 65536 signals x 2^16 Float32, L = 16, the
+                       batch block-partitioned over the N ranks (one process per GPU, sharding.shard_range; rank 0's taps reach
+                       the other ranks by one RCCL broadcast; no signal data crosses GPUs).  value = whole batch / max-over-ranks
+                       time ("scaling": "strong").  The C3 weak-scaling figure (every rank its own 8192 x 8192 image) is kept
+                       as the nested object `c3_weak_scaling`.
+                       Started plainly (`python bench.py --gpus N`) the script re-launches ITSELF through torch.distributed.run
+                       with N ranks; under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Objects on the JSON line:
+  roofline       the dominant kernel = the launch that consumes the full-size input (C3: k_fwd2d_pair, levels 1-2 fused; it reads
+                 N samples and writes N coefficients = 8 B/sample): algorithmic bytes / average launch duration, HIP events
+                 on the launch stream around a train of such launches; `rocprof` = the same figure from the committed
+                 rocprofv3 summary under profiles/; `traffic` = HBM bytes per launch from the committed PMC passes
+  by_depth       ms per transform and fraction of the 8 TB/s roofline at L = 1, 4, 13
+  cpu_baseline   the oracle's sources (literal C restatement of the reference's single-threaded loops) built -O3 -march=native
+                 on THIS host and timed on a bounded sample: 1 warm-up + 3 repetitions, median; 1 core (the reference has no
+                 threading) and, beside it, the OpenMP-over-lines variant on all host cores
+  secondary_configs   the other BASELINE configs and section-8(f) rows: >= 20 repetitions, one HIP event pair per repetition,
+                 median and minimum (one runtime hiccup cannot poison a figure)
 
 Other workloads (parity-test configs, not the headline): --workload c1|c2|c4|c5.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,6 +45,8 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ROUND = "r03"      # profiles/<round>_c3_kernel_stats.csv is the committed rocprofv3 summary of this command
+NROT = 3                   # distinct input arrays the timed steps rotate over
 
 
 def parse():
@@ -43,14 +54,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=400)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="default: c3 on one GPU, the sharded c5 batch on several")
     ap.add_argument("--levels", type=int, default=None, help="override L (default: maxtransformlevels)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--path", type=int, default=0, help="0 fast kernels, 1 generic kernels only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configs")
-    ap.add_argument("--no-c5", action="store_true", help="skip the sharded C5 batch object")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 batch object of the one-GPU line")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the 4-stream leg (profiling runs: overlapping launches skew per-kernel statistics)")
-    ap.add_argument("--c5-signals", type=int, default=65536, help="total signals of the sharded C5 batch (BASELINE: 65536)")
+    ap.add_argument("--no-depths", action="store_true", help="skip the by_depth object")
+    ap.add_argument("--c5-signals", type=int, default=65536, help="total signals of the C5 batch (BASELINE: 65536)")
     ap.add_argument("--stub-backend", default=None, help=argparse.SUPPRESS)   # tests only: 'gloo' = CPU ranks, stub transform
     return ap.parse_args()
 
@@ -73,8 +86,40 @@ def respawn_command(args, argv):
             "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
 
 
-def make_workload(W, name, device, seed):
-    """returns (label, x (device tensor), wt, default L, sample count, call(x) -> y, dtype tag)"""
+# ---------------------------------------------------------------------------------------------------------------------
+# timing helpers (device side: HIP events on the launch stream = torch's current stream, which is the stream the library
+# launches on)
+def _event_train_ms(fns, reps):
+    """average ms per call of a back-to-back train of `reps` calls (fns are used round-robin), one event pair around it"""
+    for i in range(min(5, reps)):
+        fns[i % len(fns)]()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        fns[i % len(fns)]()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _event_each_ms(fns, reps, warm=5):
+    """one event pair per call, calls enqueued back to back: (median, min, mean) ms"""
+    for i in range(warm):
+        fns[i % len(fns)]()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        fns[i % len(fns)]()
+        b.record()
+    torch.cuda.synchronize()
+    d = sorted(a.elapsed_time(b) for a, b in evs)
+    return statistics.median(d), d[0], sum(d) / len(d)
+
+
+def make_workload(W, name, device, seed, ncols=8192):
+    """returns (label, x (device tensor), wt, default L, dtype tag)"""
     g = torch.Generator(device="cpu").manual_seed(seed)
     WT = W.WT
     if name == "c3":
@@ -90,36 +135,164 @@ def make_workload(W, name, device, seed):
         x = torch.rand(1 << 20, generator=g, dtype=torch.float64).to(device)
         return "1-D dwt db2 filter 2^20 f64", x, W.wavelet(WT.db2), 20, "f64"
     if name == "c5":
-        # per-GPU shard of the 65536 x 2^16 batch on 8 GPUs: 8192 signals of length 2^16
-        x = torch.randn(8192, 1 << 16, generator=g, dtype=torch.float32).to(device).t()
-        return "batched column-wise dwt db4, 8192 signals x 2^16 f32 per GPU", x, W.wavelet(WT.db4), 16, "f32"
+        # a shard of the 65536 x 2^16 batch: `ncols` signals of length 2^16 (8192 = the per-GPU shard on 8 GPUs), generated on the device
+        gd = torch.Generator(device=device).manual_seed(seed)
+        x = torch.randn(ncols, 1 << 16, generator=gd, dtype=torch.float32, device=device).t()
+        return f"batched column-wise dwt db4, {ncols} signals x 2^16 f32", x, W.wavelet(WT.db4), 16, "f32"
     raise ValueError(name)
 
 
-def stub_main(args, rank, world):
-    """Launcher / reduction plumbing on CPU ranks (tests/test_bench_launch.py): gloo backend, the transform replaced by a
-    copy.  Never a measurement: the line says so."""
-    import torch.distributed as dist
-    from wavelets_jl_amd import sharding
-    dist.init_process_group(backend=args.stub_backend)
-    cpu = torch.device("cpu")
-    x = torch.full((64, 64), float(rank + 1))
-    y = torch.empty_like(x)
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+# ---------------------------------------------------------------------------------------------------------------------
+class StubBackend:
+    """CPU stand-in for the transform calls (tests/test_bench_launch.py, gloo ranks): the launcher, rendezvous, shard partition,
+    reductions and the assembly of the multi-GPU JSON line are what is under test; nothing is measured and the line says so."""
+    name = "stub"
+
+    def __init__(self, device, rank):
+        self.device, self.rank = device, rank
+
+    def make_shard(self, ncol, seed):
+        x = torch.full((64, 8), float(self.rank + 1))         # rank r's shard holds r + 1 (the checksum test relies on it)
+        return x, torch.empty_like(x)
+
+    def make_image(self, seed):
+        x = torch.full((64, 64), float(self.rank + 1))
+        return x, torch.empty_like(x)
+
+    def dwtc(self, y, x):
         y.copy_(x)
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dist, cpu)
-    lo, hi = sharding.shard_range(args.c5_signals, rank, dist.get_world_size())
-    cols = sharding.sum_over_ranks(float(hi - lo), dist, cpu)
-    checksum = sharding.sum_over_ranks(float(y.sum()), dist, cpu)
-    dist.barrier()
-    if rank == 0:
-        print(json.dumps({"metric": "STUB (launcher test, no transform ran)", "stub": True, "value": 0.0, "unit": "Msamples/s",
-                          "n_gpus": dist.get_world_size(), "gpus_requested": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / max(1, args.steps) * 1e3, "backend": args.stub_backend,
-                          "c5_signals_covered": cols, "checksum_all_ranks": checksum}), flush=True)
-    dist.destroy_process_group()
+
+    def dwt2(self, y, x):
+        y.copy_(x)
+
+    def sync(self):
+        pass
+
+    def kernel(self):
+        return "stub-copy"
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, W, sharding, dist, device):
+        self.W, self.device = W, device
+        self.db4 = sharding.broadcast_wavelet(W.wavelet(W.WT.db4), dist, device)     # rank 0's taps, over RCCL
+
+    def make_shard(self, ncol, seed):
+        _, x, _, _, _ = make_workload(self.W, "c5", self.device, seed, ncols=ncol)
+        y = self.W.similar(x)
+        self.W.reserve_workspace(x, 16)
+        return x, y
+
+    def make_image(self, seed):
+        _, x, _, _, _ = make_workload(self.W, "c3", self.device, seed)
+        return x, self.W.similar(x)
+
+    def dwtc(self, y, x):
+        self.W.dwtc_(y, x, self.db4, 16)
+
+    def dwt2(self, y, x):
+        self.W.dwt_oop_(y, x, self.db4, 13)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def kernel(self):
+        return self.W.last_kernel()
+
+
+def timed_steps(step, backend, dist, sharding, device, steps, warmup, precondition=0):
+    """The driver's protocol: [untimed conditioning] barrier + synchronize, W warm-up steps, synchronize, K timed steps,
+    synchronize, barrier; returns the MAX over ranks of this rank's wall time for the K steps (seconds)."""
+    for i in range(precondition):
+        step(i)
+    backend.sync()
+    if dist is not None:
+        dist.barrier()                      # all ranks start the warm-up (and with it the timed steps) together
+    backend.sync()
+    # the W warm-up steps run AFTER the barrier: an RCCL barrier idles the GPU for about a millisecond, long enough for the
+    # clocks to drop again, and the timed steps must not start cold
+    for i in range(warmup):
+        step(i)
+    backend.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    backend.sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    backend.sync()
+    return sharding.max_over_ranks(dt, dist, device)
+
+
+def rccl_info(dist, device, backend_name):
+    """What the collective library itself reports: its version, and the number of ranks as counted by an all-reduce of ones
+    (not torch's bookkeeping)."""
+    if dist is None:
+        return {"backend": "single process", "ranks_counted_by_allreduce": 1}
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    info = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""),
+            "ranks_counted_by_allreduce": int(one.item()), "world_size": dist.get_world_size()}
+    if backend_name == "hip":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                       # pragma: no cover
+            info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    return info
+
+
+def multi_gpu_line(args, rank, world, dist, sharding, device, backend):
+    """--gpus N > 1: the sharded C5 batch is the top-level metric; the C3 weak-scaling figure is nested."""
+    n = 1 << 16
+    lo, hi = sharding.shard_range(args.c5_signals, rank, world)
+    ncol = hi - lo
+    x, y = backend.make_shard(ncol, 4242 + 1000 * rank)
+    warm = min(args.warmup, 20)          # a 16 GiB / N shard per step: a handful of warm-up steps reach steady clocks
+    dt = timed_steps(lambda i: backend.dwtc(y, x), backend, dist, sharding, device, args.steps, warm)
+    kernel = backend.kernel()
+    checksum = sharding.sum_over_ranks(float(y.double().sum().item()), dist, device)
+    cols = sharding.sum_over_ranks(float(ncol), dist, device)
+    total = args.c5_signals * n
+    ms = dt / args.steps * 1e3
+    value = total / (dt / args.steps) / 1e6
+    del x, y
+    if backend.name == "hip":
+        backend.W.destroy_contexts()
+        torch.cuda.empty_cache()
+    # nested: every rank its own 8192 x 8192 image, rotating over NROT inputs (weak scaling of independent images)
+    imgs = [backend.make_image(42 + 1000 * rank + 17 * j) for j in range(NROT)]
+    yout = imgs[0][1]
+    steps3 = max(20, min(args.steps * 10, 200))
+    dt3 = timed_steps(lambda i: backend.dwt2(yout, imgs[i % NROT][0]), backend, dist, sharding, device, steps3, min(args.warmup * 10, 100),
+                      precondition=100 if backend.name == "hip" else 0)
+    k3 = backend.kernel()
+    ms3 = dt3 / steps3 * 1e3
+    nimg = imgs[0][0].numel()
+    out = {
+        "metric": "Msamples/s, batched column-wise db4 dwt 65536 x 2^16 f32 sharded over the GPUs (BASELINE.json configs[4])",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+        "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (standard normal, generated on each device, seed 4242 + 1000*rank), resident in HBM",
+        "config": {"workload": f"batched column-wise dwt db4 {args.c5_signals} x 2^16 f32, L=16, {world} shards",
+                   "signals_total": args.c5_signals, "signals_per_rank": ncol, "signals_covered_all_ranks": cols,
+                   "parallelism": f"column block partition over {world} ranks, one process per GPU, no data-path collective",
+                   "collectives": "1 broadcast of the taps (256 B), MAX / SUM all-reduces of 8 B; no signal data crosses GPUs",
+                   "kernel": kernel, "gpus_requested": args.gpus, "warmup_requested": args.warmup},
+        "gpus_requested": args.gpus,
+        "achieved_hbm_GBps_algorithmic": round(8.0 * total / (dt / args.steps) / 1e9, 1),
+        "checksum_all_ranks": checksum, "c5_signals_covered": cols,
+        "rccl": rccl_info(dist, device, backend.name),
+        "c3_weak_scaling": {"workload": "2-D dwt db4 filter 8192x8192 f32, L=13, one independent image per GPU", "scaling": "weak",
+                            "steps": steps3, "ms_per_step": round(ms3, 5), "value": round(world * nimg / ms3 / 1e3, 1),
+                            "unit": "Msamples/s", "kernel": k3, "inputs_rotated": NROT},
+    }
+    if backend.name == "stub":
+        out["stub"] = True
+        out["metric"] = "STUB (launcher test, no transform ran): " + out["metric"]
+    return out
 
 
 def main():
@@ -133,8 +306,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = os.environ.get("WL_BENCH_FORCE_DIST") == "1"     # (exercises the RCCL path on one GPU)
     if args.stub_backend:
-        return stub_main(args, rank, world)
+        import torch.distributed as dist
+        from wavelets_jl_amd import sharding
+        dist.init_process_group(backend=args.stub_backend)
+        device = torch.device("cpu")
+        out = multi_gpu_line(args, rank, world, dist, sharding, device, StubBackend(device, rank))
+        if rank == 0:
+            out["cpu_baseline"] = {"value": 0.0, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": "stub run: not measured"}
+            print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
     if world > torch.cuda.device_count():
@@ -142,7 +325,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("WL_BENCH_FORCE_DIST") == "1":    # (the env knob exercises the RCCL path on one GPU)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -154,93 +337,87 @@ def main():
     W._lib.load()
     W.set_kernel_path(args.path)
 
-    label, x, wt, Ldef, dtag = make_workload(W, args.workload, device, 42 + 1000 * rank)
+    if world > 1 and args.workload is None:
+        out = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device))
+        if rank == 0 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline_leg(W, "c5", W.wavelet(W.WT.db4), 16)
+        finish(out, rank, dist)
+        return
+
+    workload = args.workload or "c3"
+    label, x, wt, Ldef, dtag = make_workload(W, workload, device, 42 + 1000 * rank)
     L = Ldef if args.levels is None else args.levels
     # filter taps / scheme coefficients travel from rank 0 over RCCL (xGMI): the only collective
     wt = sharding.broadcast_wavelet(wt, dist, device)
-    batched = args.workload == "c5"
+    batched = workload == "c5"
+    # C3 rotates over NROT distinct inputs: 3 x 256 MiB do not fit the 256 MiB Infinity Cache, so no step can find its input
+    # (or the previous step's) cached
+    xs = [x]
+    if workload == "c3":
+        for j in range(1, NROT):
+            xs.append(make_workload(W, workload, device, 42 + 1000 * rank + 17 * j)[1])
     # the timed step is the reference's non-allocating entry point dwt!(y, x, wt, L) / dwt_oop!(y, x, scheme, L)
     # (transforms_main.jl:114-117,193-207): output array and workspace are allocated once, outside the timed region
     yout = W.similar(x)
     fn = (lambda t: W.dwtc_(yout, t, wt, L)) if batched else (lambda t: W.dwt_oop_(yout, t, wt, L))
     W.reserve_workspace(x, L)
     nsamples = x.numel()
+    esize = x.element_size()
 
-    # device conditioning before the W warm-up steps (untimed, reported in the JSON line): clocks need about a
-    # millisecond of load to ramp, and the ROCm runtime has a one-off enqueue stall the first time the host runs a few
-    # hundred launches ahead -- neither belongs to the steady-state throughput this line reports
+    class _B:                                   # (timed_steps only needs sync())
+        @staticmethod
+        def sync():
+            torch.cuda.synchronize()
+    # device conditioning before the W warm-up steps (untimed, reported in the JSON line): clocks need about a millisecond of
+    # load to ramp, and the ROCm runtime has a one-off enqueue stall the first time the host runs a few hundred launches
+    # ahead -- neither belongs to the steady-state throughput this line reports
     precondition = max(0, 300 - args.warmup)
-    for _ in range(precondition):
-        y = fn(x)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()                      # all ranks start the warm-up (and with it the timed steps) together
-    torch.cuda.synchronize()
-    # the W warm-up steps run AFTER the barrier: an RCCL barrier idles the GPU for about a millisecond, long enough
-    # for the clocks to drop again, and the timed steps must not start cold
-    for _ in range(args.warmup):
-        y = fn(x)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = fn(x)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0               # this rank's K steps, start aligned by the barrier above
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = sharding.max_over_ranks(dt, dist, device)   # the job is as slow as its slowest rank
+    dt = timed_steps(lambda i: fn(xs[i % len(xs)]), _B, dist, sharding, device, args.steps, args.warmup, precondition)
     kernel = W.last_kernel()
     ms_per_step = dt / args.steps * 1e3
     value = world * nsamples / (dt / args.steps) / 1e6          # whole-job Msamples/s
-    esize = x.element_size()
     gbps = 2 * esize * value * 1e6 / 1e9                        # algorithmic bytes: 2*N*sizeof(T) per call
 
     # device-only time of one step (HIP events on the launch stream), for reference
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nev = min(args.steps, 200)
-    ev0.record()
-    for _ in range(nev):
-        y = fn(x)
-    ev1.record()
-    torch.cuda.synchronize()
-    dev_ms_per_step = ev0.elapsed_time(ev1) / nev
+    dev_ms_per_step = _event_train_ms([(lambda t=t: fn(t)) for t in xs], min(args.steps, 200))
 
     # cross-rank correctness token: sum over all ranks of each rank's coefficient sum, one 8-byte all-reduce
-    # over RCCL after the timed region (single rank: its own sum)
     checksum = sharding.sum_over_ranks(float(yout.sum(dtype=torch.float64).item()), dist, device)
 
     out = {
-        "metric": "Msamples/s, 2-D db4 dwt 8192x8192 f32" if args.workload == "c3" else "Msamples/s, " + label,
+        "metric": "Msamples/s, 2-D db4 dwt 8192x8192 f32" if workload == "c3" else "Msamples/s, " + label,
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtag, "data": "synthetic (standard normal, seed 42 + 1000*rank), resident in HBM",
+        "dtype": dtag, "data": "synthetic (standard normal, seed 42 + 1000*rank + 17*j), resident in HBM",
         "config": {"workload": label, "L": int(L), "arrays": world, "parallelism": f"{world} independent arrays, one per GPU",
-                   "kernel": kernel, "kernel_path": "generic" if args.path else "fast", "gpus_requested": args.gpus,
-                   "world_size": (dist.get_world_size() if dist is not None else 1),
-                   "backend": (dist.get_backend() + " (RCCL)" if dist is not None else "single process"),
-                   "untimed_precondition_steps": precondition},
-        "achieved_hbm_GBps_algorithmic": round(gbps, 1), "precondition_steps": precondition,
-        "checksum_all_ranks": checksum,
+                   "inputs_rotated": len(xs), "kernel": kernel, "kernel_path": "generic" if args.path else "fast",
+                   "gpus_requested": args.gpus, "untimed_precondition_steps": precondition},
+        "gpus_requested": args.gpus,
+        "achieved_hbm_GBps_algorithmic": round(gbps, 1), "hbm_frac_whole_transform": round(gbps / HBM_PEAK_GBPS, 4),
+        "precondition_steps": precondition, "checksum_all_ranks": checksum,
         "device_ms_per_step": round(dev_ms_per_step, 5),
+        "rccl": rccl_info(dist, device, "hip"),
     }
-
-    if args.workload == "c3" and not args.no_c5:
-        # every rank takes part (barriers / reductions inside); the object is kept by rank 0
-        del y
-        c5 = c5_batched_leg(W, sharding, dist, device, rank, world, args)
-        if rank == 0:
-            out["c5_batched"] = c5
+    if rank == 0 and workload == "c3" and not args.no_depths:
+        out["by_depth"] = by_depth_leg(W, xs, yout, wt, esize)
+    if rank == 0:
+        out["roofline"] = roofline_leg(W, xs, wt, batched, esize, args, kernel)
     if rank == 0 and world == 1 and not batched and not args.no_pipelined:
-        out["pipelined"] = pipelined_leg(W, x, wt, L, args)
-    if rank == 0:
-        out["roofline"] = roofline_leg(W, x, wt, batched, esize, args, kernel)
-    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_secondary:
-        del yout
+        out["pipelined"] = pipelined_leg(W, xs, wt, L, args)
+    if workload == "c3" and world == 1 and not args.no_c5:
+        del yout, xs, x
+        torch.cuda.empty_cache()
+        out["c5_batched"] = c5_one_gpu_leg(W, device, args)
+    if rank == 0 and world == 1 and workload == "c3" and not args.no_secondary:
+        xs = x = yout = None
+        torch.cuda.empty_cache()
         out["secondary_configs"] = secondary_leg(W, device)
-    if rank == 0:
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline_leg(W, args.workload, wt, L)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_leg(W, workload, wt, L)
+    finish(out, rank, dist)
+
+
+def finish(out, rank, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -256,175 +433,141 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def c5_batched_leg(W, sharding, dist, device, rank, world, args):
-    """BASELINE.json configs[4]: batched column-wise dwt, WT.db4, `--c5-signals` (65536) signals x 2^16 Float32, L = 16,
-    the batch sharded by columns over the ranks (rank r owns sharding.shard_range(signals, r, world): 65536/N columns, no
-    signal data crosses GPUs); rank 0's filter taps reach the others by one RCCL broadcast.  Strong scaling of a fixed
-    batch: value = signals * 2^16 / max-over-ranks time.  Protocol as the headline: barrier + synchronize, warm-up,
-    K timed steps, synchronize, MAX over ranks; checksum SUM-reduced over RCCL."""
+def by_depth_leg(W, xs, yout, wt, esize):
+    """the C3 transform at L = 1, 4 and 13 -- ms per transform (back-to-back train of 100 calls rotating
+    over the inputs, HIP events) and the fraction of the 8 TB/s roofline for the algorithmic 2*N*sizeof(T) bytes, which do not
+    depend on L."""
+    res = {}
+    alg = 2 * xs[0].numel() * esize
+    for Ld in (1, 4, 13):
+        ms = _event_train_ms([(lambda t=t: W.dwt_oop_(yout, t, wt, Ld)) for t in xs], 100)
+        res[f"L={Ld}"] = {"ms_per_step": round(ms, 5), "Msamples_per_s": round(xs[0].numel() / ms / 1e3, 1),
+                          "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                          "launches": W.last_kernel()}
+    return res
+
+
+def c5_one_gpu_leg(W, device, args):
+    """The whole C5 batch (65536 x 2^16 f32 = 16 GiB in, 16 GiB out, 16 GiB workspace) on ONE GPU: the N = 1 point of the
+    multi-GPU curve (`--gpus N` reports the same batch sharded N ways as its top-level value)."""
     n = 1 << 16
-    lo, hi = sharding.shard_range(args.c5_signals, rank, world)
-    ncol = hi - lo
-    wt = sharding.broadcast_wavelet(W.wavelet(W.WT.db4), dist, device)
-    g = torch.Generator(device=device).manual_seed(4242 + 1000 * rank)
-    x = torch.randn(ncol, n, generator=g, dtype=torch.float32, device=device).t()      # Julia layout: n x ncol, column = signal
+    _, x, wt, L, _ = make_workload(W, "c5", device, 4242, ncols=args.c5_signals)
     y = W.similar(x)
-    fn = lambda: W.dwtc_(y, x, wt, 16)
-    steps, warm = 5, 2
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-    dt = sharding.max_over_ranks(dt, dist, device) / steps
-    checksum = sharding.sum_over_ranks(float(y.sum(dtype=torch.float64).item()), dist, device)
+    W.reserve_workspace(x, L)
+    fn = lambda: W.dwtc_(y, x, wt, L)
+    med, mn, mean = _event_each_ms([fn], 8, warm=2)
     kernel = W.last_kernel()
     total = args.c5_signals * n
     del x, y
     W.destroy_contexts()                     # (the batch's workspace)
     torch.cuda.empty_cache()
-    return {"workload": f"batched column-wise dwt db4, {args.c5_signals} signals x 2^16 f32, L=16, sharded over {world} GPU(s)",
-            "signals_total": args.c5_signals, "signals_per_rank": ncol, "scaling": "strong", "steps": steps, "warmup": warm,
-            "ms_per_step": round(dt * 1e3, 4), "Msamples_per_s": round(total / dt / 1e6, 1),
-            "aggregate_algorithmic_GBps": round(8.0 * total / dt / 1e9, 1), "checksum_all_ranks": checksum, "kernel": kernel,
-            "collectives": "1 broadcast of the taps (256 B), 1 MAX + 1 SUM all-reduce of 8 B; no signal data crosses GPUs"}
+    return {"workload": f"batched column-wise dwt db4, {args.c5_signals} signals x 2^16 f32, L=16, one GPU",
+            "signals_total": args.c5_signals, "reps": 8, "ms_per_step_median": round(med, 4), "ms_per_step_min": round(mn, 4),
+            "Msamples_per_s": round(total / med / 1e3, 1), "aggregate_algorithmic_GBps": round(8.0 * total / med / 1e6, 1),
+            "frac": round(8.0 * total / med / 1e6 / HBM_PEAK_GBPS, 4), "kernel": kernel}
 
 
-def pipelined_leg(W, x, wt, L, args, nstreams=4):
+def pipelined_leg(W, xs, wt, L, args, nstreams=4):
     """Reported beside `value`, never instead of it: the same K transforms issued round-robin on `nstreams` HIP streams
-    (one library context and one output array per stream, same resident input).  Independent transforms -- a sequence of
-    images -- overlap the latency-bound small levels of one with the bandwidth-bound first kernel of the next; `value`
-    above stays the strictly sequential single-stream figure the metric is defined on."""
+    (one library context and one output array per stream).  Independent transforms -- a sequence of images -- overlap the
+    latency-bound small levels of one with the bandwidth-bound first kernel of the next; `value` above stays the strictly
+    sequential single-stream figure the metric is defined on."""
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
-    outs = [W.similar(x) for _ in range(nstreams)]
+    outs = [W.similar(xs[0]) for _ in range(nstreams)]
     steps = max(args.steps, 100)
     for i in range(max(steps, 400)):                  # untimed: creates the contexts, absorbs the runtime's one-off enqueue stall
         with torch.cuda.stream(streams[i % nstreams]):
-            W.dwt_oop_(outs[i % nstreams], x, wt, L)
+            W.dwt_oop_(outs[i % nstreams], xs[i % len(xs)], wt, L)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         with torch.cuda.stream(streams[i % nstreams]):
-            W.dwt_oop_(outs[i % nstreams], x, wt, L)
+            W.dwt_oop_(outs[i % nstreams], xs[i % len(xs)], wt, L)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     del outs
-    W.destroy_contexts()                 # the four per-stream contexts and their workspaces
+    W.destroy_contexts()                 # the per-stream contexts and their workspaces
     torch.cuda.empty_cache()
+    x = xs[0]
     return {"streams": nstreams, "steps": steps, "ms_per_step": round(ms, 5), "value": round(x.numel() / ms / 1e3, 1), "unit": "Msamples/s",
             "achieved_hbm_GBps_algorithmic": round(2 * x.numel() * x.element_size() / ms / 1e6, 1)}
 
 
-def secondary_leg(W, device):
-    """Short device-timed runs of the other BASELINE.json configs (parity-test configs, not the headline):
-    reported for context only."""
+def secondary_leg(W, device, reps=20):
+    """Device-timed runs of the other BASELINE.json configs and of the section-8(f) rows (parity-test configs, not the
+    headline).  Protocol: 5 untimed calls, then `reps` calls enqueued back to back with ONE HIP EVENT PAIR PER CALL; the
+    figure is the MEDIAN (the minimum is printed beside it), so a single runtime hiccup -- the one-off enqueue stall, a
+    first-use code-object load -- cannot poison it."""
     res = []
+
+    def run(label, L, dtag, x, fn, alg_bytes):
+        W.reserve_workspace(x, L, full=True) if _reserve_has_full(W) else W.reserve_workspace(x, L)
+        med, mn, mean = _event_each_ms([fn], reps)
+        res.append({"workload": label, "L": int(L), "dtype": dtag, "reps": reps, "ms_per_step": round(med, 5), "ms_min": round(mn, 5),
+                    "ms_mean": round(mean, 5), "Msamples_per_s": round(x.numel() / med / 1e3, 1),
+                    "algorithmic_GBps": round(alg_bytes / med / 1e6, 1), "frac": round(alg_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
+                    "kernel": W.last_kernel()})
+
     for name in ("c1", "c2", "c4", "c5"):
         label, x, wt, L, dtag = make_workload(W, name, device, 42)
         y = W.similar(x)
         fn = (lambda: W.dwtc_(y, x, wt, L)) if name == "c5" else (lambda: W.dwt_oop_(y, x, wt, L))
-        W.reserve_workspace(x, L)
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        res.append({"workload": label, "L": int(L), "dtype": dtag, "ms_per_step": round(ms, 5),
-                    "Msamples_per_s": round(x.numel() / ms / 1e3, 1),
-                    "algorithmic_GBps": round(2 * x.numel() * x.element_size() / ms / 1e6, 1), "kernel": W.last_kernel()})
+        run(label, L, dtag, x, fn, 2 * x.numel() * x.element_size())
         del x, y
         torch.cuda.empty_cache()
-    # the inverse of the headline config and the section 8(f) rows (3-D, modwt), same protocol
+    # the inverse of the headline config and the section 8(f) rows (3-D, modwt, denoise), same protocol
     g = torch.Generator(device="cpu").manual_seed(7)
     db4 = W.wavelet(W.WT.db4)
-    extra = []
     x2 = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t()
     y2 = W.similar(x2)
-    extra.append(("2-D idwt db4 filter 8192x8192 f32", 13, x2, lambda: W.idwt_oop_(y2, x2, db4, 13), 2 * x2.numel() * 4))
+    a2 = 2 * x2.numel() * 4
+    run("2-D idwt db4 filter 8192x8192 f32", 13, "f32", x2, lambda: W.idwt_oop_(y2, x2, db4, 13), a2)
     cdf = W.wavelet(W.WT.cdf97, W.WT.Lifting)
-    extra.append(("2-D dwt cdf9/7 lifting 8192x8192 f32", 13, x2, lambda: W.dwt_oop_(y2, x2, cdf, 13), 2 * x2.numel() * 4))
-    extra.append(("2-D idwt cdf9/7 lifting 8192x8192 f32", 13, x2, lambda: W.idwt_oop_(y2, x2, cdf, 13), 2 * x2.numel() * 4))
+    run("2-D dwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, cdf, 13), a2)
+    run("2-D idwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2, lambda: W.idwt_oop_(y2, x2, cdf, 13), a2)
+    sym8 = W.wavelet(W.WT.sym8)
+    run("2-D dwt sym8 (16 taps) filter 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, sym8, 13), a2)
     batt6 = W.wavelet(W.WT.batt6)
-    extra.append(("2-D dwt batt6 (59 taps) filter 8192x8192 f32", 13, x2, lambda: W.dwt_oop_(y2, x2, batt6, 13), 2 * x2.numel() * 4))
+    run("2-D dwt batt6 (59 taps) filter 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, batt6, 13), a2)
+    del x2, y2
+    torch.cuda.empty_cache()
+    x2d = torch.randn(8192, 8192, generator=g, dtype=torch.float64).to(device).t()
+    y2d = W.similar(x2d)
+    run("2-D dwt db4 filter 8192x8192 f64", 13, "f64", x2d, lambda: W.dwt_oop_(y2d, x2d, db4, 13), 2 * x2d.numel() * 8)
+    del x2d, y2d
+    torch.cuda.empty_cache()
     x3 = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0)
     y3 = W.similar(x3)
-    extra.append(("3-D dwt db4 filter 512^3 f32", 9, x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4))
+    run("3-D dwt db4 filter 512^3 f32", 9, "f32", x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4)
+    del x3, y3
     xm = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
-    extra.append(("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, xm, lambda: W.modwt(xm, db4, 8), (1 + 9) * xm.numel() * 4))
+    run("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, "f32", xm, lambda: W.modwt(xm, db4, 8), (1 + 9) * xm.numel() * 4)
+    del xm
     # translation-invariant denoise (denoising.jl:36-67), default wavelet sym5, 8 x 8 spins as one device-resident batch:
     # 64 forward + 64 inverse transforms of the image per call; algorithmic bytes = (read + write) per spin and direction
     xd = torch.randn(2048, 2048, generator=g, dtype=torch.float32).to(device).t()
-    extra.append(("2-D denoise TI 8x8 spins sym5 2048x2048 f32 (64 dwt + 64 idwt, fused batch)", 6, xd,
-                  lambda: W.denoise(xd, TI=True), 64 * 2 * 2 * xd.numel() * 4))
-    for label, L, x, fn, alg in extra:
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        res.append({"workload": label, "L": int(L), "dtype": "f32", "ms_per_step": round(ms, 5),
-                    "Msamples_per_s": round(x.numel() / ms / 1e3, 1), "algorithmic_GBps": round(alg / ms / 1e6, 1),
-                    "kernel": W.last_kernel()})
-    del extra, x2, y2, x3, y3, xm, xd
+    run("2-D denoise TI 8x8 spins sym5 2048x2048 f32 (64 dwt + 64 idwt, fused batch)", 6, "f32", xd,
+        lambda: W.denoise(xd, TI=True), 64 * 2 * 2 * xd.numel() * 4)
+    del xd
     W.destroy_contexts()
     torch.cuda.empty_cache()
     return res
 
 
-def _time_launches(fn, reps):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record()
-        fn()
-        b.record()
-    torch.cuda.synchronize()
-    durs = sorted(a.elapsed_time(b) for a, b in evs)
-    return sum(durs) / len(durs), durs[len(durs) // 2], durs[0]
-
-
-def _time_back_to_back(fn, reps):
-    """Average duration of one launch inside a train of `reps` identical launches (one event pair around the train: no host
-    gaps between the launches, which is how the kernel runs inside a transform)."""
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+def _reserve_has_full(W):
+    import inspect
+    try:
+        return "full" in inspect.signature(W.reserve_workspace).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def _rocprof_summary(kname_substr):
     """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this same
-    command (profiles/r02_c3_kernel_stats.csv), so that the line can be checked against profiles/ without a GPU."""
+    command (profiles/<round>_c3_kernel_stats.csv), so that the line can be checked against profiles/ without a GPU."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r02_c3_kernel_stats.csv")
+    rel = os.path.join("profiles", f"{PROFILE_ROUND}_c3_kernel_stats.csv")
+    path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None
     best = None
@@ -434,45 +577,49 @@ def _rocprof_summary(kname_substr):
                 best = r
     if best is None:
         return None
-    return {"file": "profiles/r02_c3_kernel_stats.csv", "kernel": best["Name"], "calls": int(best["Calls"]),
+    return {"file": rel, "kernel": best["Name"], "calls": int(best["Calls"]),
             "avg_launch_ms": round(float(best["AverageNs"]) * 1e-6, 5)}
 
 
-def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
+def roofline_leg(W, xs, wt, batched, esize, args, main_kernel):
     """Dominant kernel = the launch that consumes the full-size input.  Its algorithmic bytes are
     2*N*sizeof(T): it reads every input sample once and writes N coefficients (8 B/sample
-    f32) -- that holds for the single-level kernels and for the fused-pair kernels, which finish TWO levels
-    in the same pass (3/4 N level-1 details + 1/4 N level-2 coefficients).  A call with L = 1 (L = 2
-    for a fused pair) is exactly one launch of that kernel (its first-level template instance, which
-    rocprofv3 --stats reports under its own name).  `frac` uses HIP events on the launch stream around a train of
-    such launches (live, this run); `rocprof` repeats the computation from the committed rocprofv3 summary."""
-    Ldom = 2 if main_kernel in ("k_fwd2d_stream2", "k_fwd2d_pair") else 1
+    f32) -- that holds for the single-level kernels and for the fused-pair kernel, which finishes TWO levels
+    in the same pass (3/4 N level-1 details + 1/4 N level-2 coefficients; the level-1 approximation never leaves the chip).
+    A call with L = 1 (L = 2 for the fused pair; L = 4 for the multi-level line kernel of the batched transform) is exactly
+    one launch of that kernel (its first-level template instance, which rocprofv3 --stats reports under its own name).
+    `frac` uses HIP events on the launch stream around a train of such launches rotating over the inputs (live, this run);
+    `rocprof` repeats the computation from the committed rocprofv3 summary."""
+    Ldom = {"k_fwd2d_stream2": 2, "k_fwd2d_pair": 2, "k_fwd1d_multi": 4}.get(main_kernel, 1)
+    x = xs[0]
     y1 = W.similar(x)
-    fn1 = (lambda: W.dwtc_(y1, x, wt, Ldom)) if batched else (lambda: W.dwt_oop_(y1, x, wt, Ldom))
+    mk = (lambda t: (lambda: W.dwtc_(y1, t, wt, Ldom))) if batched else (lambda t: (lambda: W.dwt_oop_(y1, t, wt, Ldom)))
+    fns = [mk(t) for t in xs]
     reps = max(20, min(args.steps, 200))
-    train_ms = _time_back_to_back(fn1, reps)
-    avg_ms, med_ms, min_ms = _time_launches(fn1, reps)
+    train_ms = _event_train_ms(fns, reps)
+    med_ms, min_ms, avg_ms = _event_each_ms(fns, reps, warm=3)
     kname = W.last_kernel()
     alg_bytes = 2 * x.numel() * esize
     achieved = alg_bytes / (train_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    note = "traffic: no PMC summary committed yet"
+    note = "traffic: no PMC summary committed for this kernel yet"
     if os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
             if j.get("kernel_short") == kname:
                 traffic = j.get("hbm_bytes_per_launch")
-            note = j.get("note", "")
+                note = j.get("note", "") + " (static: read from the committed profiles/pmc_latest.json, not measured by this run)"
         except Exception:
             pass
-    out = {"bound": "hbm", "kernel": f"{kname} (first launch: level{'s 1-2' if Ldom == 2 else ' 1'})",
+    levels = {1: "level 1", 2: "levels 1-2", 4: "levels 1-4"}[Ldom]
+    out = {"bound": "hbm", "kernel": f"{kname} (first launch: {levels})",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(train_ms, 5),
-           "timing": f"HIP events around a train of {reps} launches on the launch stream",
+           "timing": f"HIP events around a train of {reps} launches on the launch stream, {len(xs)} inputs in rotation",
            "isolated_launch_ms": {"avg": round(avg_ms, 5), "median": round(med_ms, 5), "min": round(min_ms, 5),
-                                  "note": "one event pair per launch: includes the idle-stream launch latency"},
+                                  "note": "one event pair per launch"},
            "launches_timed": reps, "traffic_note": note,
            "frac_of_measured_copy_6290GBps": round(achieved / 6290.0, 4)}
     rp = _rocprof_summary(kname)
@@ -484,58 +631,75 @@ def roofline_leg(W, x, wt, batched, esize, args, main_kernel):
 
 
 def cpu_baseline_leg(W, workload, wt, L):
-    extra = {}
-    """The oracle (kind 'port': literal C restatement of the reference's single-threaded loops)
-    on this host's cores, on a bounded sample (about 10-30 s of CPU work)."""
+    """The reference's CPU path, represented by the oracle's sources (literal C restatement of the reference's
+    single-threaded loops) compiled -O3 -march=native -ffp-contract=off ON THIS HOST and timed around
+    the C call itself: 1 warm-up + 3 repetitions, median.  `value` is the 1-core figure (the reference has no threading); the
+    OpenMP-over-lines variant on all host cores is reported beside it for the 2-D case."""
     import oracle                      # the checker / baseline -- never the product path
-    oracle.build()
+    h = oracle.build_native()
     rng = np.random.default_rng(42)
+    ncores = os.cpu_count() or 1
+    extra = {}
+    med = statistics.median
     if workload == "c3":
-        # the full 8192 x 8192 f32 array once (67.1 Msamples; about 5-20 s on one core)
         n = 8192
-        xs = rng.standard_normal((n, n), dtype=np.float32)
-        t0 = time.perf_counter()
-        oracle.dwt_filter(xs, wt.qmf, L)
-        dt = time.perf_counter() - t0
-        sample = f"one full 2-D db4 dwt of the {n}x{n} f32 array, L={L}, 1 thread (the reference has no threading)"
-        ns = xs.size
+        xf = np.asfortranarray(rng.standard_normal((n, n), dtype=np.float32))
+        # warm-up on a quarter-size array (page faults, clocks), then the full 8192 x 8192 transform three times
+        oracle.time_dwt_filter(h, np.asfortranarray(xf[:4096, :4096]), wt.qmf, 12, reps=1, warmup=0)
+        ts = oracle.time_dwt_filter(h, xf, wt.qmf, L, reps=3, warmup=0)
+        dt, ns = med(ts), xf.size
+        sample = (f"the full 2-D db4 dwt of the {n}x{n} f32 array, L={L}: 1 warm-up (4096x4096) + 3 repetitions, median "
+                  f"(min {min(ts):.2f} s, max {max(ts):.2f} s), 1 thread")
+        nt = max(1, min(ncores, int(h.wlo_max_threads())))
+        tm = oracle.time_dwt_filter(h, xf, wt.qmf, L, reps=3, warmup=1, threads=nt)
+        extra["all_cores"] = {"value": round(ns / med(tm) / 1e6, 2), "unit": "Msamples/s", "cores": nt, "seconds": round(med(tm), 3),
+                              "note": "same loops, the independent lines of every level spread over OpenMP threads "
+                                      "(bit-identical result; the reference itself is single-threaded)"}
         # anchor against the one number the reference publishes for this path (README.md:249-250: 1-D db2 dwt of 2^20
-        # Float64, 20 levels, 24.8 ms per call on unstated hardware): the same call through the oracle on this host
-        x1 = rng.random(1 << 20)
+        # Float64, 20 levels, 24.8 ms per call on unstated hardware): the same call through the same build on this host
+        x1 = np.asfortranarray(rng.random(1 << 20))
         db2 = W.wavelet(W.WT.db2)
-        oracle.dwt_filter(x1, db2.qmf, 20)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            oracle.dwt_filter(x1, db2.qmf, 20)
-        c1_ms = (time.perf_counter() - t1) / 5 * 1e3
-        extra = {"c1_anchor": {"workload": "1-D dwt db2 filter 2^20 f64, L=20, 1 thread", "oracle_ms_per_call": round(c1_ms, 2),
-                               "reference_readme_ms_per_call": 24.8, "reference_hardware": "unstated (README.md:249-250)"}}
+        t1 = oracle.time_dwt_filter(h, x1, db2.qmf, 20, reps=5, warmup=1)
+        extra["c1_anchor"] = {"workload": "1-D dwt db2 filter 2^20 f64, L=20, 1 thread, 1 warm-up + 5 repetitions, median",
+                              "oracle_ms_per_call": round(med(t1) * 1e3, 2), "reference_readme_ms_per_call": 24.8,
+                              "reference_hardware": "unstated (README.md:249-250)"}
     else:
-        # parity-test configs: repeat full-size (c5: a 1/64 sub-batch) transforms for about 10 s
         if workload == "c1":
-            xs = rng.standard_normal(1 << 20)
-            fn, what = (lambda: oracle.dwt_filter(xs, wt.qmf, L)), "full-size 1-D db2 f64 transforms"
+            xf, what = np.asfortranarray(rng.standard_normal(1 << 20)), "full-size 1-D db2 f64 transform"
         elif workload == "c2":
-            xs = rng.standard_normal(1 << 24, dtype=np.float32)
-            fn, what = (lambda: oracle.dwt_filter(xs, wt.qmf, L)), "full-size 1-D db4 f32 transforms"
+            xf, what = np.asfortranarray(rng.standard_normal(1 << 24, dtype=np.float32)), "full-size 1-D db4 f32 transform"
         elif workload == "c4":
-            xs = rng.standard_normal(1 << 24, dtype=np.float32)
-            fn, what = (lambda: oracle.dwt_lifting(xs, wt, L)), "full-size 1-D cdf9/7 lifting transforms"
+            xf, what = None, "full-size 1-D cdf9/7 lifting transform"
         else:
-            xs = rng.standard_normal((1 << 16, 128), dtype=np.float32)
-            fn, what = (lambda: oracle.dwtc_filter(xs, wt.qmf, L)), "transforms of 128 of the 8192 signals (1/64 sub-batch)"
-        reps = 0
-        t0 = time.perf_counter()
-        while True:
-            fn()
-            reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 200:
-                break
-        dt = (time.perf_counter() - t0) / reps
-        sample = f"{reps} {what}, 1 thread"
-        ns = xs.size
+            xf, what = None, "1/64 sub-batch: 1024 of the 65536 signals (column-wise 1-D db4 transforms of length 2^16), scaled linearly"
+        if workload == "c4":
+            xs = rng.standard_normal(1 << 24, dtype=np.float32)
+            oracle.dwt_lifting(xs, wt, L)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                oracle.dwt_lifting(xs, wt, L)
+                ts.append(time.perf_counter() - t0)
+            dt, ns = med(ts), xs.size
+            what += " (through the Python wrapper of the -O2 test build: includes two array copies)"
+        elif workload == "c5":
+            # columns are independent 1-D transforms: time them as a (2^16 x 1024) batch of lines, one after the other
+            xcols = np.asfortranarray(rng.standard_normal((1 << 16, 1024), dtype=np.float32))
+            def one_pass():
+                t0 = time.perf_counter()
+                for j in range(0, xcols.shape[1], 1):
+                    oracle.time_dwt_filter(h, xcols[:, j], wt.qmf, L, reps=1, warmup=0)
+                return time.perf_counter() - t0
+            one_pass()
+            ts = [one_pass() for _ in range(3)]
+            dt, ns = med(ts), xcols.size
+        else:
+            ts = oracle.time_dwt_filter(h, xf, wt.qmf, L, reps=3, warmup=1)
+            dt, ns = med(ts), xf.size
+        sample = f"{what}, 1 warm-up + 3 repetitions, median, 1 thread"
     out = {"value": round(ns / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": sample, "seconds": round(dt, 2), "host_cores_available": os.cpu_count()}
+           "build": "gcc -O3 -march=native -ffp-contract=off (oracle sources, built on this host)",
+           "sample": sample, "seconds": round(dt, 3), "host_cores_available": ncores}
     out.update(extra)
     return out
 

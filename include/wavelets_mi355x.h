@@ -83,6 +83,13 @@ typedef enum wl_status {
 
 typedef struct wl_ctx wl_ctx;
 
+/* ---- sharding a batch of independent units over GPUs (dwtc columns, images) --------------------------------- */
+/* Contiguous block partition: rank r of `world` owns units [*lo, *hi).  The path has no exchange step: one process
+ * (or Julia task) per GPU calls wl_dwtc_* on its own column block with its own context; only the wavelet description travels
+ * between ranks.  Host-side arithmetic only: usable without a device.  (replaces: nothing -- the reference has no dwtc,
+ * transforms_main.jl:179-181; north_star defines the multi-GPU batch)                                               */
+WL_API int wl_shard_range(int64_t nunits, int rank, int world, int64_t *lo, int64_t *hi);
+
 /* ---- context -------------------------------------------------------------------- */
 /* Create a context on HIP device `device` (>= 0).  Fails with WL_ENODEVICE when there is
  * no such device or it is not gfx950.  (replaces: nothing -- Julia allocates scratch
@@ -97,6 +104,9 @@ WL_API int wl_ctx_destroy(wl_ctx *ctx);
  * elements: the context grows to that on their first call (grow-only; a call that grows the
  * workspace synchronises the device).  wl_ctx_workspace_held reports the current size.    */
 WL_API size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L);
+/* Upper bound for EVERY entry point on this shape (lifting, long / odd filters, 3-D, the generic kernel family, wpt): reserve
+ * this much and no later transform of that shape allocates or synchronises, whatever path it takes.                      */
+WL_API size_t wl_workspace_bytes_full(int dtype, int ndims, const int64_t *dims, int L);
 WL_API int wl_ctx_reserve(wl_ctx *ctx, size_t bytes);
 WL_API size_t wl_ctx_workspace_held(const wl_ctx *ctx);
 /* hipStreamSynchronize for hosts without their own HIP binding.                        */

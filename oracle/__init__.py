@@ -36,6 +36,48 @@ def build(force: bool = False):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
+def build_native(out_dir: str | None = None) -> C.CDLL:
+    """CPU-BASELINE build (bench.py's cpu_baseline leg only): the same sources compiled `-O3 -march=native
+    -ffp-contract=off` ON THE HOST THAT RUNS THE BENCH, into a scratch directory -- never the
+    library the parity tests use (that one stays -O2 without -march so that it can travel between machines)."""
+    import tempfile
+    out_dir = out_dir or os.path.join(tempfile.gettempdir(), "wl_oracle_native_%d" % os.getuid())
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libwl_oracle_native.so")
+    srcs = [os.path.join(_HERE, f) for f in ("wl_oracle.c", "wl_oracle_ext.c")]
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("wl_oracle.c", "wl_oracle_impl.h", "wl_oracle_ext.c"))
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                               "-fvisibility=hidden", "-std=c11", "-fopenmp", "-shared", "-o", so] + srcs + ["-lm"])
+    return C.CDLL(so)
+
+
+def time_dwt_filter(handle: C.CDLL, xf: np.ndarray, qmf, L: int, reps: int = 3, warmup: int = 1, threads: int = 1):
+    """Wall-clock seconds of each of `reps` calls of the C entry point itself (no Python-side copies inside the timed region):
+    `xf` must be Fortran-ordered (Julia layout).  threads > 1 uses the OpenMP-over-lines variant (2-D only).  Returns the
+    list of per-call seconds after `warmup` untimed calls."""
+    import time
+    assert xf.flags.f_contiguous
+    yf = np.empty_like(xf, order="F")
+    q = np.ascontiguousarray(qmf, dtype=np.float64)
+    qp = q.ctypes.data_as(C.POINTER(C.c_double))
+    if threads > 1:
+        assert xf.ndim == 2
+        call = lambda: handle.wlo_dwt2d_filter_mt(_dt(xf), _p(yf), _p(xf), C.c_int64(xf.shape[0]), C.c_int64(xf.shape[1]), qp, len(q), int(L), 1)
+    else:
+        call = lambda: handle.wlo_dwt_filter(_dt(xf), _p(yf), _p(xf), xf.ndim, _dims(xf), qp, len(q), int(L), 1)
+    out = []
+    for i in range(warmup + reps):
+        t0 = time.perf_counter()
+        rc = call()
+        dt = time.perf_counter() - t0
+        if rc:
+            raise OracleError(rc)
+        if i >= warmup:
+            out.append(dt)
+    return out
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -316,20 +358,25 @@ def noisest(x: np.ndarray, transform, L=1) -> float:
     return mad(dr) / 0.6745
 
 
-def denoise(x: np.ndarray, fwd, inv, L, th_kind, t_unit, TI=False, nspin=None, lifting=False, noise_transform="same"):
+def denoise(x: np.ndarray, fwd, inv, L, th_kind, t_unit, TI=False, nspin=None, lifting=False, noise_transform="same", sigma=None):
     """denoise (denoising.jl:21-81) composed from the oracle pieces in the reference's order.
-    fwd(a, L) / inv(a, L): oracle dwt / idwt for the wavelet (None: wt === nothing); t_unit = dnt.t"""
-    sigma = noisest(x, (lambda a, l: fwd(a, l)) if fwd is not None else None)
+    fwd(a, L) / inv(a, L): oracle dwt / idwt for the wavelet (None: wt === nothing); t_unit = dnt.t; sigma: the value a
+    custom `estnoise` returned (default: noisest, denoising.jl:33)"""
+    if sigma is None:
+        sigma = noisest(x, (lambda a, l: fwd(a, l)) if fwd is not None else None)
     t = sigma * t_unit
     if TI:
         nsp = tuple(nspin) if hasattr(nspin, "__len__") else (int(nspin),)
         pns = int(np.prod(nsp))
         y = np.zeros_like(x)
         for i in range(pns):
-            rem, shift = i, []
-            for d in nsp:                                # CartesianIndices: first dimension fastest
-                shift.append(rem % d)
-                rem //= d
+            if x.ndim == 1:
+                shift = [i]                              # denoising.jl:40-42: vectors are shifted by i - 1 whatever nspin's length
+            else:
+                rem, shift = i, []
+                for d in nsp:                            # CartesianIndices: first dimension fastest (nspin2circ, :113-121)
+                    shift.append(rem % d)
+                    rem //= d
             shift = shift + [0] * (x.ndim - len(shift))
             z = circshift(x, shift)
             xt = threshold(fwd(z, L), th_kind, t)

@@ -37,6 +37,20 @@ def test_hostonly_entry_points(W):
     # the fast filter-bank path of C3 holds two approximation buffers of N/4 elements: 128 MiB (+ padding), not 4 N
     wsb = lib.wl_workspace_bytes(0, 2, dims, 13)
     assert 2 * (8192 * 8192 // 4) * 4 <= wsb <= 129 * 2 ** 20
+    # ... and the upper bound over every entry point (lifting, long filters, generic kernels, wpt) is about 4.5 N elements
+    full = lib.wl_workspace_bytes_full(0, 2, dims, 13)
+    assert 4 * 8192 * 8192 * 4 <= full <= 5 * 8192 * 8192 * 4
+    # block partition of a batch over ranks (the C helper a Julia host uses; sharding.shard_range is the same arithmetic)
+    from wavelets_jl_amd import sharding
+    for nunits, world in ((65536, 8), (65536, 3), (10, 4), (3, 8), (0, 2)):
+        covered = 0
+        for r in range(world):
+            lo, hi = C.c_int64(), C.c_int64()
+            assert lib.wl_shard_range(nunits, r, world, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == sharding.shard_range(nunits, r, world) and lo.value == covered
+            covered = hi.value
+        assert covered == nunits
+    assert lib.wl_shard_range(10, 4, 4, C.byref(lo), C.byref(hi)) == lib.wl_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) != 0
 
 
 def test_header_compiles_as_c():

@@ -37,4 +37,11 @@ def test_gpus_flag_spawns_that_many_ranks():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["gpus_requested"] == 2 and out["stub"] is True
     assert out["c5_signals_covered"] == 65536.0                  # the two shards partition the batch
-    assert out["checksum_all_ranks"] == 64 * 64 * (1 + 2)       # rank r's array holds r + 1
+    assert out["checksum_all_ranks"] == 64 * 8 * (1 + 2)        # rank r's stub shard holds r + 1
+    # with more than one GPU the sharded C5 batch is the top-level metric (BASELINE.json configs[4]); the C3 figure is nested
+    assert "batched column-wise" in out["metric"] and out["scaling"] == "strong" and out["unit"] == "Msamples/s"
+    assert out["config"]["signals_per_rank"] == 32768 and "65536" in out["config"]["workload"]
+    assert out["steps"] == 3 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
+    assert out["c3_weak_scaling"]["scaling"] == "weak" and out["c3_weak_scaling"]["ms_per_step"] > 0
+    assert out["rccl"]["ranks_counted_by_allreduce"] == 2       # counted by an all-reduce of ones, not by torch's bookkeeping
+    assert "cpu_baseline" in out

@@ -102,7 +102,7 @@ def test_circshift_bitexact(gpu, W, oracle, dtype):
         assert np.array_equal(got, oracle.circshift(a, sh)) and np.array_equal(got, np.roll(a, sh, axis=tuple(range(len(sh)))))
 
 
-def _oracle_denoise(oracle, W, x, wt, L, dnt, TI, nspin):
+def _oracle_denoise(oracle, W, x, wt, L, dnt, TI, nspin, sigma=None):
     kind = type(dnt.th).__name__[:-2].lower()
     if wt is None:
         return oracle.denoise(x, None, None, 0, kind, dnt.t)
@@ -112,7 +112,7 @@ def _oracle_denoise(oracle, W, x, wt, L, dnt, TI, nspin):
     else:
         fwd = lambda a, l: oracle.dwt_filter(a, wt.qmf, l)
         inv = lambda a, l: oracle.dwt_filter(a, wt.qmf, l, fw=False)
-    return oracle.denoise(x, fwd, inv, L, kind, dnt.t, TI=TI, nspin=nspin)
+    return oracle.denoise(x, fwd, inv, L, kind, dnt.t, TI=TI, nspin=nspin, sigma=sigma)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -180,3 +180,21 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
     L3 = min(W.maxtransformlevels(v3), 6)
     e3 = _oracle_denoise(oracle, W, v3, wt, L3, W.VisuShrink(3000), True, (5,))
     assert np.array_equal(host(W, W.denoise(W.to_device(v3), TI=True, nspin=5)), e3)
+    # ---- edge cases of the translation-invariant branch (round-2 advice) ----
+    # L = 0: dwt / idwt are copies, so every spin thresholds the shifted signal itself (odd length: no 2^L factor needed)
+    for v0, nsp0 in ((rng_array((37,), dtype, 8), 5), (rng_array((24, 24), dtype, 9), (3, 2))):
+        e0 = _oracle_denoise(oracle, W, v0, wt, 0, W.VisuShrink(W.HardTH(), 0.7), True, (nsp0,) if isinstance(nsp0, int) else nsp0, sigma=1.0)
+        y0 = host(W, W.denoise(W.to_device(v0), L=0, dnt=W.VisuShrink(W.HardTH(), 0.7), TI=True, nspin=nsp0, estnoise=lambda a, w: 1.0))
+        assert W.last_kernel() == "denoise_ti_batch" and np.array_equal(y0, e0) and not np.array_equal(y0, v0)
+    # a vector with a longer nspin tuple: prod(nspin) = 16 spins shifted by 0 .. 15 (denoising.jl:38-42)
+    y4 = host(W, W.denoise(xd, TI=True, nspin=(4, 4)))
+    assert np.array_equal(y4, _oracle_denoise(oracle, W, x, wt, min(W.maxtransformlevels(n), 6), vs, True, (4, 4)))
+    assert np.array_equal(y4, host(W, W.denoise(xd, TI=True, nspin=16)))
+    # PosTH / NegTH take no threshold value: threshold!(xt, th, t) has no such method in the reference
+    for th in (W.PosTH(), W.NegTH()):
+        with pytest.raises(TypeError):
+            W.denoise(xd, dnt=W.VisuShrink(th, 1.0), TI=True)
+    # a custom estimator that returns NaN or a negative value trips @assert t >= 0 instead of being replaced silently
+    for bad in (float("nan"), -1.0, float("inf")):
+        with pytest.raises(AssertionError):
+            W.denoise(xd, TI=True, estnoise=lambda a, w: bad)

@@ -40,7 +40,9 @@ SIGNATURES = {
     "wl_maxtransformlevels": (C.c_int, [C.c_int64]),
     "wl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "wl_ctx_destroy": (C.c_int, [_vp]),
+    "wl_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, _i64p, _i64p]),
     "wl_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, _i64p, C.c_int]),
+    "wl_workspace_bytes_full": (C.c_size_t, [C.c_int, C.c_int, _i64p, C.c_int]),
     "wl_ctx_reserve": (C.c_int, [_vp, C.c_size_t]),
     "wl_ctx_workspace_held": (C.c_size_t, [_vp]),
     "wl_stream_sync": (C.c_int, [_vp, _vp]),

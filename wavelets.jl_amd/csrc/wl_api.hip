@@ -328,6 +328,15 @@ int wl_ctx_destroy(wl_ctx *ctx)
     return WL_OK;
 }
 
+int wl_shard_range(int64_t nunits, int rank, int world, int64_t *lo, int64_t *hi)
+{
+    if (!lo || !hi || nunits < 0 || world < 1 || rank < 0 || rank >= world) return WL_EINVAL_ARG;
+    const int64_t base = nunits / world, rem = nunits % world;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return WL_OK;
+}
+
 size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L)
 {
     (void)L;
@@ -338,6 +347,15 @@ size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L)
     // (dwtc: pass ndims = 1 with dims[0] = len * nsignals.)  Lifting, long / odd filters, 3-D boxes and the generic
     // family use up to 4 N elements more; the context grows to that on their first call.
     return ws_ab_elems(N, ndims) * (dtype == WL_F64 ? 8 : 4);
+}
+size_t wl_workspace_bytes_full(int dtype, int ndims, const int64_t *dims, int L)
+{
+    (void)L;
+    if (!dims || ndims < 1 || ndims > 3) return 0;
+    int64_t N = 1;
+    for (int d = 0; d < ndims; ++d) N *= dims[d];
+    // ping-pong + T0 / T1 / W of the general families (ws_elems); the packet transforms add a depth table of N bytes
+    return ws_elems(N, 1) * (dtype == WL_F64 ? 8 : 4) + (size_t)N + 256;
 }
 size_t wl_ctx_workspace_held(const wl_ctx *ctx) { return ctx ? ctx->ws_bytes : 0; }
 

@@ -156,8 +156,9 @@ __device__ __forceinline__ void gload16(F4 &dst, const float *p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
-// "at most N vector-memory operations outstanding": loads and stores retire in issue order on gfx9-family counters, so this
-// covers every load that has at least N younger operations behind it.
+// "at most N vector-memory operations outstanding".  Loads return in issue order among themselves, so this covers every load
+// that has at least N younger LOADS behind it.  Do not count younger stores towards N: round 3 measured (one transform in
+// about a thousand, some boxes only) that a store can be acknowledged while an older load is still in flight.
 template <int N>
 __device__ __forceinline__ void wait_vm(F4 &a, F4 &b)
 {

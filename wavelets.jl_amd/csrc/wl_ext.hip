@@ -916,13 +916,19 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
             const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
             hipLaunchKernelGGL((k_ti_shift<T>), dim3(gx, (unsigned)((n1 + 7) / 8), (unsigned)nb), dim3(256), 0, st, Z, x, g);
         }
-        rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
-        if (rc != WL_OK) return rc;
-        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, XT, N * nb, th, &sel->result, t_unit, sigma_host,
-                           vec_ok16(XT));
-        const char *kn = nullptr;
-        rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, Z, XT, taps, L, &kn, &ctx->last_hip);
-        if (rc != WL_OK) return rc;
+        // L == 0: dwt / idwt are copies (transforms_filter.jl:36-38), so the shifted signal itself is thresholded
+        T *const coef = (L == 0) ? Z : XT;
+        if (L > 0) {
+            rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
+            if (rc != WL_OK) return rc;
+        }
+        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, coef, N * nb, th, &sel->result, t_unit, sigma_host,
+                           vec_ok16(coef));
+        if (L > 0) {
+            const char *kn = nullptr;
+            rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, Z, XT, taps, L, &kn, &ctx->last_hip);
+            if (rc != WL_OK) return rc;
+        }
         {
             const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
             hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(gx, (unsigned)n1), dim3(256), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
@@ -1061,7 +1067,9 @@ int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndi
     if (!y || !x || !dims || !qmf || !nspin) return WL_EINVAL_ARG;
     if (ndims < 1 || ndims > 2) return WL_EDIMS;
     if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
-    if (th < WL_TH_HARD || th > WL_TH_NEG) return WL_EINVAL_ARG;
+    // threshold!(xt, dnt.th, sigma*t) (denoising.jl:58) has methods for Hard / Soft / Semisoft / Stein only (threshold_main.jl:21-80)
+    if (th < WL_TH_HARD || th > WL_TH_STEIN) return WL_EINVAL_ARG;
+    if (sigma_host != sigma_host || sigma_host == HUGE_VAL) return WL_EINVAL_ARG;    // NaN / +Inf from a custom estimator: @assert t >= 0 territory
     for (int d = 0; d < ndims; ++d)
         if (dims[d] < 1 || nspin[d] < 1) return WL_EDIMS;
     if (ndims == 2 && dims[0] != dims[1]) return WL_EINVAL_CUBE;            // iscube(x) (denoising.jl:29)

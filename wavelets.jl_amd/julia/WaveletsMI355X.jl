@@ -165,6 +165,40 @@ for (f, fw) in ((:dwtc, true), (:idwtc, false))
     end
 end
 
+# ---- multi-GPU dwtc: shard the columns of a batch over the devices of one node --------------------------------------
+# The path has no exchange step (SURVEY.md 8e): columns are independent, so rank r of `world` transforms the contiguous
+# column block `shard_range(nsignals, r, world)` on its own GPU with its own context; only the wavelet description (a few
+# dozen Float64) is shared -- inside one Julia process that is the `filter` object itself, across processes (MPI.jl / RCCL)
+# it is one broadcast of `filter.qmf`.  No signal data crosses GPUs.
+"""`shard_range(nunits, rank, world)` -> 1-based `lo:hi` column range of rank `rank` (0-based), contiguous block partition
+(the library's own arithmetic: `wl_shard_range`)."""
+function shard_range(nunits::Integer, rank::Integer, world::Integer)
+    lo, hi = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:wl_shard_range, LIB), Cint, (Int64, Cint, Cint, Ptr{Int64}, Ptr{Int64}), nunits, rank, world, lo, hi))
+    return (lo[] + 1):hi[]
+end
+
+"""`dwtc_sharded(X, wt, L; devices=AMDGPU.devices())`: batched column-wise dwt of the HOST matrix `X` (len x nsignals) on
+several GPUs of one node: one task per device, each uploads its column block, runs `dwtc` there (its own context and
+stream) and downloads the coefficients into the matching block of the result.  A resident pipeline keeps the blocks on the
+devices instead (call `dwtc` on each device's `ROCMatrix` from that device's task); this function is the documented recipe."""
+function dwtc_sharded(X::AbstractMatrix{T}, wt, L::Integer=Util.maxtransformlevels(size(X, 1));
+                      devices=AMDGPU.devices()) where {T<:Union{Float32,Float64}}
+    Y = similar(X)
+    world = length(devices)
+    @sync for (r, dev) in enumerate(devices)
+        Threads.@spawn begin
+            AMDGPU.device!(dev)                              # this task's device (and with it this task's stream and context)
+            cols = shard_range(size(X, 2), r - 1, world)
+            if !isempty(cols)
+                y = dwtc(ROCArray(X[:, cols]), wt, L)
+                copyto!(view(Y, :, cols), Array(y))
+            end
+        end
+    end
+    return Y
+end
+
 # ---- MODWT: replaces modwt / imodwt, transforms_maximal_overlap.jl:47-63, 99-107 ----------------------
 function Transforms.modwt(x::ROCVector{T}, wt::OrthoFilter, L::Integer=Util.maxmodwttransformlevels(x)) where {T<:Union{Float32,Float64}}
     L <= Util.maxmodwttransformlevels(x) || throw(ArgumentError("Too many transform levels (length(x) < 2^L)"))
@@ -237,14 +271,18 @@ function Threshold.denoise(x::ROCArray{T,N}, wt::OrthoFilter=Threshold.DEFAULT_W
                            L::Int=min(Util.maxtransformlevels(x), 6), dnt::S=VisuShrink(size(x, 1)),
                            estnoise::Function=noisest, TI::Bool=false,
                            nspin::Union{Int,Tuple}=tuple([8 for i = 1:ndims(x)]...)) where {T<:Union{Float32,Float64},N,S<:DNFT}
-    if !(TI && N <= 2 && haskey(THCODE, typeof(dnt.th)))
+    # only the reference's own TI branch: threshold!(xt, th, t) exists for Hard / Soft / Semisoft / Stein (Pos / Neg take no t:
+    # the generic method raises its MethodError); matrices need one nspin entry per dimension
+    nspt = nspin isa Int ? (nspin,) : nspin
+    if !(TI && (N == 1 || (N == 2 && length(nspt) == 2)) && get(THCODE, typeof(dnt.th), Cint(9)) <= 3)
         return invoke(Threshold.denoise, Tuple{AbstractArray,Union{Wavelets.WT.DiscreteWavelet,Nothing}}, x, wt;
                       L=L, dnt=dnt, estnoise=estnoise, TI=TI, nspin=nspin)
     end
     Util.iscube(x) || throw(ArgumentError("array must be square/cube"))
     sigma = estnoise === noisest ? -1.0 : Float64(estnoise(x, wt))
+    estnoise === noisest || (sigma >= 0 && isfinite(sigma)) || throw(AssertionError("t >= 0"))   # threshold_main.jl:24
     y = similar(x)
-    nsp = Int64[(nspin isa Int ? (nspin,) : nspin)..., 1, 1, 1][1:3]
+    nsp = N == 1 ? Int64[prod(nspt), 1, 1] : Int64[nspt..., 1]      # vectors: prod(nspin) spins shifted by 0 .. pns-1 (denoising.jl:38-42)
     check(ccall((:wl_denoise_ti_filter, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Cdouble, Ptr{Int64},
                  Cdouble, Ptr{Cvoid}),

@@ -219,18 +219,23 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
     if not Util.iscube(x):
         raise ArgumentError("array must be square/cube")
     nsp = (int(nspin),) if not hasattr(nspin, "__len__") else tuple(int(s) for s in nspin)
-    if (TI and isinstance(wt, OrthoFilter) and x.dim() <= 2 and len(nsp) >= x.dim() and isinstance(dnt.th, THType)
-            and dnt.th.code is not None and dnt.th.code >= 0):
+    # fast path only where it is the reference's own branch: threshold!(xt, th, t) exists for Hard / Soft / Semisoft / Stein
+    # (codes 0..3; Pos / Neg take no t and raise in the loop below exactly as the reference's MethodError does); matrices need
+    # one nspin entry per dimension (anything else goes through nspin2circ / circshift in the loop below, as in the reference)
+    if (TI and isinstance(wt, OrthoFilter) and (x.dim() == 1 or (x.dim() == 2 and len(nsp) == 2)) and isinstance(dnt.th, THType)
+            and dnt.th.code is not None and 0 <= dnt.th.code <= 3):
         # the translation-invariant branch for orthogonal filters, vectors and square matrices: one device-resident batch
         # (wl_denoise_ti_filter) -- all spins transformed / thresholded / inverted together, the noise estimate consumed on
         # the device, nothing allocated per spin, no host synchronisation.  Same arithmetic in the same order as the loop below.
         sig = -1.0 if estnoise is noisest else float(estnoise(x, wt))
-        if sig < 0 and estnoise is not noisest:
-            raise AssertionError("t >= 0")
+        if estnoise is not noisest and not (sig >= 0 and np.isfinite(sig)):
+            raise AssertionError("t >= 0")               # (@assert t >= 0 in threshold!, threshold_main.jl:24; NaN fails it too)
         y = similar(x)
         h, st = _context(x.device)
         q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
-        nsv = (C.c_int64 * 3)(*(list(nsp[:x.dim()]) + [1] * (3 - x.dim())))
+        # vectors: prod(nspin) spins shifted by 0 .. pns-1 whatever nspin's length (denoising.jl:38-42)
+        nsl = [int(np.prod(nsp))] if x.dim() == 1 else list(nsp)
+        nsv = (C.c_int64 * 3)(*(nsl + [1] * (3 - len(nsl))))
         _check(_lib.load().wl_denoise_ti_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
                                                 q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), dnt.th.code, float(dnt.t), nsv,
                                                 sig, st), h)
@@ -245,7 +250,7 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
         y.zero_()
         xt = similar(x)
         for i in range(1, pns + 1):
-            shift = nspin2circ(nsp, i)
+            shift = [i - 1] if x.dim() == 1 else nspin2circ(nsp, i)      # (denoising.jl:40-42 / :52-53)
             z = circshift(x, shift)
             dwt_oop_(xt, z, wt, L)
             threshold_(xt, dnt.th, t)

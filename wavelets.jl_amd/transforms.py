@@ -143,13 +143,16 @@ def workspace_held(device=None) -> int:
     return int(_lib.load().wl_ctx_workspace_held(h))
 
 
-def reserve_workspace(x: torch.Tensor, L: int = 0):
-    """Pre-grow the context's device workspace for transforms of x's shape (so that timed
-    regions never allocate)."""
+def reserve_workspace(x: torch.Tensor, L: int = 0, full: bool = False):
+    """Pre-grow the context's device workspace for transforms of x's shape.  Default: what the fast filter-bank paths of
+    dwt / idwt / dwtc hold (two approximation buffers of N / 2^ndims elements) -- after this, those calls never allocate.
+    full=True reserves the upper bound of EVERY entry point (lifting, long / odd filters, 3-D, generic kernels, wpt: about
+    4.5 N elements), so that no transform of this shape allocates or synchronises whatever path it takes."""
     lib = _lib.load()
     h, _ = _context(x.device)
     dims = (C.c_int64 * 3)(*([int(s) for s in x.shape] + [1] * (3 - x.dim())))
-    nbytes = lib.wl_workspace_bytes(_dtype_code(x), x.dim(), dims, int(L))
+    fn = lib.wl_workspace_bytes_full if full else lib.wl_workspace_bytes
+    nbytes = fn(_dtype_code(x), x.dim(), dims, int(L))
     _check(lib.wl_ctx_reserve(h, nbytes), h)
 
 

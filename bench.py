@@ -89,18 +89,29 @@ def respawn_command(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 # timing helpers (device side: HIP events on the launch stream = torch's current stream, which is the stream the library
 # launches on)
-def _event_train_ms(fns, reps):
-    """average ms per call of a back-to-back train of `reps` calls (fns are used round-robin), one event pair around it"""
+def _event_train_ms(fns, reps, chunk=10):
+    """ms per call inside a back-to-back train of `reps` calls (fns are used round-robin).  The train is enqueued without a
+    gap but timed in chunks of `chunk` calls (events between the chunks); the figure is the MEDIAN chunk.  Once or twice per
+    process the ROCm runtime stalls the queue for 30-40 ms (seen at any depth, tools' stall probe); inside a 100-call train
+    that would triple a plain average, the median chunk does not see it."""
     for i in range(min(5, reps)):
         fns[i % len(fns)]()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(reps):
-        fns[i % len(fns)]()
-    e1.record()
+    nchunks = max(1, reps // chunk)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nchunks + 1)]
+    evs[0].record()
+    k = 0
+    for c in range(nchunks):
+        for _ in range(chunk if c < nchunks - 1 else reps - chunk * (nchunks - 1)):
+            fns[k % len(fns)]()
+            k += 1
+        evs[c + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    per = []
+    for c in range(nchunks):
+        ncall = chunk if c < nchunks - 1 else reps - chunk * (nchunks - 1)
+        per.append(evs[c].elapsed_time(evs[c + 1]) / ncall)
+    return statistics.median(per)
 
 
 def _event_each_ms(fns, reps, warm=5):
@@ -435,7 +446,7 @@ def finish(out, rank, dist):
 
 def by_depth_leg(W, xs, yout, wt, esize):
     """the C3 transform at L = 1, 4 and 13 -- ms per transform (back-to-back train of 100 calls rotating
-    over the inputs, HIP events) and the fraction of the 8 TB/s roofline for the algorithmic 2*N*sizeof(T) bytes, which do not
+    over the inputs, HIP events every 10 calls, median chunk) and the fraction of the 8 TB/s roofline for the algorithmic 2*N*sizeof(T) bytes, which do not
     depend on L."""
     res = {}
     alg = 2 * xs[0].numel() * esize
@@ -617,7 +628,7 @@ def roofline_leg(W, xs, wt, batched, esize, args, main_kernel):
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(train_ms, 5),
-           "timing": f"HIP events around a train of {reps} launches on the launch stream, {len(xs)} inputs in rotation",
+           "timing": f"HIP events on the launch stream inside a back-to-back train of {reps} launches (median of chunks of 10), {len(xs)} inputs in rotation",
            "isolated_launch_ms": {"avg": round(avg_ms, 5), "median": round(med_ms, 5), "min": round(min_ms, 5),
                                   "note": "one event pair per launch"},
            "launches_timed": reps, "traffic_note": note,

@@ -295,6 +295,44 @@ def test_fused_pair_2d_kernel(gpu, W, oracle, wmain, tj):
         assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2)), shape
 
 
+@pytest.mark.parametrize("tj", [32, 128])
+@pytest.mark.parametrize("wmain", [2, 4])
+def test_float64_lds_exchange_and_pair_kernels(gpu, W, oracle, wmain, tj):
+    """Float64 instances of the LDS-exchange level kernel (wl_fwd2d64.hip: two rows per lane, exact tiling) and of the fused
+    pair (wl_pair2d64.hip): strips of 128 W rows, every supported filter length, odd / even depths, non-square blocks, a
+    single strip (halo rows wrap onto the strip itself), short last chunks -- bit for bit against the oracle; shapes the
+    kernels decline (rows not a multiple of 128) keep the round-1 kernels."""
+    W.set_option("WL_PAIR_W64", wmain)
+    W.set_option("WL_LDS_W", wmain)
+    W.set_option("WL_TJ2", tj)
+    W.set_option("WL_TJ", tj)
+    W.set_option("WL_PAIR_WG_PER_CU", 0)
+    W.set_option("WL_WAVES_PER_CU", 0)
+    W.set_option("WL_WAVES_MIN", 0)
+    W.set_option("WL_M2D_MAX", 128)
+    W.set_option("WL_TILE", 0)
+    shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4)), ((256, 160), (1, 2)), ((768, 96), (2, 3)),
+              ((1280, 1056), (1, 2)))
+    for pairmin in (0, 1 << 62):
+        W.set_option("WL_LDS_PAIR_MIN64", pairmin)
+        for shape, Ls in shapes:
+            x = rng_array(shape, np.float64, sum(shape) + wmain + tj)
+            for fname in ("db4", "haar", "db2", "db3", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                for L in Ls:
+                    y = host(W, W.dwt(dev(W, x), wt, L))
+                    want = "k_fwd2d_pair64" if (pairmin == 0 and L >= 2 and shape[0] % 256 == 0) else "k_fwd2d_lds64"
+                    assert W.last_kernel() == want, (shape, L, pairmin, W.last_kernel())
+                    ye = oracle.dwt_filter(x, wt.qmf, L)
+                    if not np.array_equal(y, ye):
+                        bad = np.argwhere(y != ye)
+                        raise AssertionError((shape, fname, L, wmain, tj, pairmin, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist()))
+    x = rng_array((320, 64), np.float64, 9)          # 320 rows: no strip of 128 divides it
+    wt = W.wavelet(W.WT.db4)
+    y = host(W, W.dwt(dev(W, x), wt, 2))
+    assert W.last_kernel() not in ("k_fwd2d_lds64", "k_fwd2d_pair64") and np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("nl3max", [0, 4096])
 def test_tile_kernel(gpu, W, oracle, nl3max, dtype):

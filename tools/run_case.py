@@ -58,6 +58,23 @@ elif case == "dwt3d":
 elif case == "modwt":
     x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
     fn = lambda: W.modwt(x, db4, 8)
+elif case == "c2":
+    x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    fn = lambda: W.dwt_oop_(y, x, db4, 24)
+elif case == "c4":
+    x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.dwt_oop_(y, x, sch, 24)
+elif case == "c5":
+    x = torch.randn(8192, 1 << 16, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    fn = lambda: W.dwtc_(y, x, db4, 16)
+elif case == "c1":
+    x = torch.rand(1 << 20, generator=g, dtype=torch.float64).cuda()
+    y = W.similar(x)
+    fn = lambda: W.dwt_oop_(y, x, W.wavelet(W.WT.db2), 20)
 elif case == "denoise":
     x = torch.randn(2048, 2048, generator=g, dtype=torch.float32).cuda().t()
     fn = lambda: W.denoise(x, TI=True)

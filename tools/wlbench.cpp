@@ -11,6 +11,7 @@
 //     mode=seq|each          seq: one event pair around all reps;  each: one pair per call (avg/med/min)
 //     check=1                print a checksum of y
 //     opt=KEY:VAL,...        wl_ctx_set_option pairs
+//     dwtc=1                 batched column-wise transform of n1 signals of length n0 (wl_dwtc_filter)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -111,7 +112,12 @@ int main(int argc, char **argv)
     rc = wl_ctx_reserve(ctx, wl_workspace_bytes(dtype, nd, dims, L));
     if (rc) { fprintf(stderr, "reserve: %s\n", wl_strerror(rc)); return 2; }
     CK(hipDeviceSynchronize());
-    auto call = [&]() { return wl_dwt_filter(ctx, dtype, y, x, nd, dims, qmf.data(), (int)qmf.size(), L, fw, nullptr); };
+    const bool batched = kv.count("dwtc") && atoi(kv["dwtc"].c_str()) != 0;      // dwtc=1: n1 signals of length n0 (columns)
+    if (batched && atoi(kv["L"].c_str()) == 0) L = wl_maxtransformlevels(dims[0]);
+    auto call = [&]() {
+        if (batched) return wl_dwtc_filter(ctx, dtype, y, x, dims[0], dims[1], dims[0], qmf.data(), (int)qmf.size(), L, fw, nullptr);
+        return wl_dwt_filter(ctx, dtype, y, x, nd, dims, qmf.data(), (int)qmf.size(), L, fw, nullptr);
+    };
     for (int i = 0; i < warm; ++i) {
         rc = call();
         if (rc) { fprintf(stderr, "wl_dwt_filter: %s (hip %d)\n", wl_strerror(rc), wl_last_hip_error(ctx)); return 2; }

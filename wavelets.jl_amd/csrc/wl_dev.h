@@ -152,15 +152,19 @@ __device__ __forceinline__ void wg_lds_sync(bool multi)
 // iteration -- the four-step prefetch distance never exists.  Here the load is opaque to the compiler and the wait names the
 // two ring slots it guards, so every consumer depends on the wait through its data.
 typedef float F4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gload16(F4 &dst, const float *p)
+typedef double D2 __attribute__((ext_vector_type(2)));
+// V = any 16-byte vector type (F4: four Float32 rows, D2: two Float64 rows)
+template <typename V, typename T>
+__device__ __forceinline__ void gload16(V &dst, const T *p)
 {
+    static_assert(sizeof(V) == 16, "one global_load_dwordx4");
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 // "at most N vector-memory operations outstanding".  Loads return in issue order among themselves, so this covers every load
 // that has at least N younger LOADS behind it.  Do not count younger stores towards N: round 3 measured (one transform in
 // about a thousand, some boxes only) that a store can be acknowledged while an older load is still in flight.
-template <int N>
-__device__ __forceinline__ void wait_vm(F4 &a, F4 &b)
+template <int N, typename V>
+__device__ __forceinline__ void wait_vm(V &a, V &b)
 {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }

@@ -49,6 +49,17 @@ hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, b
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
                             int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
 
+// The Float64 instance of the LDS-exchange kernel (wl_fwd2d64.hip): two rows per lane, exact tiling only.
+bool fwd2d_lds64_ok(int F, int64_t ms, int64_t ns);
+hipError_t fwd2d_lds64_launch(hipStream_t st, const Taps<double> &taps, bool lvl1, const double *src, int64_t lds,
+                              double *y, int64_t ldy, double *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
+                              int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
+
+// ... and of the fused pair (wl_pair2d64.hip)
+bool fwd2d_pair64_ok(int F, int64_t ms, int64_t ns);
+hipError_t fwd2d_pair64_launch(hipStream_t st, const Taps<double> &taps, bool lvl1, const double *src, int64_t lds, double *y,
+                               int64_t ldy, double *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count);
+
 // Two fused forward 2-D levels per launch with a dedicated level-2 wave per workgroup (wl_pair2d.hip), Float32, even F <= 10,
 // blocks whose rows tile into strips of 1024 / 512.
 bool fwd2d_pair_ok(int F, int64_t ms, int64_t ns);

@@ -1368,6 +1368,34 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 }
             }
         }
+        // ---- Float64: the LDS-exchange level kernel with two rows per lane (wl_fwd2d64.hip) ----
+        if constexpr (sizeof(T) == 8) {
+            if (fastF && two_d && env_int("WL_LDS2D", 1) && n[0] >= env_int("WL_LDS2D_MIN_ROWS", 256) && cur_st.s[0] == 1 &&
+                (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 && aligned16(y) && aligned16(llbuf) &&
+                fwd2d_lds64_ok(F, n[0], n[1])) {
+                // two levels per launch from 2^22 elements upwards (the Float64 pair kernel, wl_pair2d64.hip)
+                if ((L - l + 1) >= 2 && env_int("WL_FUSE2", 1) && fwd2d_pair64_ok(F, n[0], n[1]) &&
+                    n[0] * n[1] >= (int64_t)opt("WL_LDS_PAIR_MIN64", (long long)1 << 23)) {
+                    const bool lastp = (l + 1 == L);
+                    T *lld2 = lastp ? y : llbuf;
+                    const int64_t ldd2 = lastp ? b.full.s[1] : (n[0] >> 2);
+                    WL_TRY(fwd2d_pair64_launch(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld2, ldd2, n[0], n[1], cu_count));
+                    if (!dominant) dominant = "k_fwd2d_pair64";
+                    lstep = 2;
+                    int64_t hn4[3] = {n[0] >> 2, n[1] >> 2, n[2]};
+                    cur = llbuf; cur_st = dense_strides(hn4); pp ^= 1;
+                    continue;
+                }
+                T *lld = last ? y : llbuf;
+                const int64_t ldd = last ? b.full.s[1] : (n[0] >> 1);
+                WL_TRY(fwd2d_lds64_launch(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, n[0], n[1], cu_count));
+                if (!dominant) dominant = "k_fwd2d_lds64";
+                lstep = 1;
+                int64_t hn2[3] = {n[0] >> 1, n[1] >> 1, n[2]};
+                cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                continue;
+            }
+        }
         // ---- streaming 2-D, two levels fused (f32) ----
         if constexpr (sizeof(T) == 4) {
             if (fastF && F <= 8 && two_d && env_int("WL_FUSE2", 1) && (L - l + 1) >= 2 && n[0] >= 512 && (n[0] % 16) == 0 &&

@@ -201,7 +201,9 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 y = host(W, W.dwt(dev(W, x), wt, L))
                 big = int(np.prod(shape)) > 16384          # smaller blocks are finished by the LDS tail kernels alone
                 kexp = "k_vl_lines" if flen == 24 else "k_long_lines"      # (24 taps: the register-window kernels at every size)
-                assert W.last_kernel() == kexp or not big, (fname, shape, L, W.last_kernel())
+                # forward, Float32, 12..20 taps, rows a multiple of 256: one pass per level (wl_fwd2d_long.hip, its own test below)
+                kfw = "k_fwd2d_lds_long" if (dtype == np.float32 and flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0) else kexp
+                assert W.last_kernel() == kfw or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
                 assert W.last_kernel() == kexp or not big, (fname, shape, L, W.last_kernel())
@@ -293,6 +295,37 @@ def test_fused_pair_2d_kernel(gpu, W, oracle, wmain, tj):
         y = host(W, W.dwt(dev(W, x), wt, 2))
         assert W.last_kernel() == "k_fwd2d_lds", (shape, W.last_kernel())
         assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2)), shape
+
+
+@pytest.mark.parametrize("tj", [16, 50, 128])
+@pytest.mark.parametrize("wmain", [1, 2, 4])
+def test_long_filter_single_pass_2d_kernel(gpu, W, oracle, wmain, tj):
+    """k_fwd2d_lds_long (wl_fwd2d_long.hip): 12..20 taps in ONE pass per 2-D level (24-slot column ring, 16 / 20 / 24-row
+    windows, guarded steps: chunk lengths that are not a multiple of the unrolled body), strips of 256 W rows, every filter
+    length of the family, odd / even depths, non-square blocks, one strip only (halo rows wrap onto the strip itself), short
+    last chunks -- bit for bit against the oracle; levels the kernel declines (rows not a multiple of 256) keep the two-pass kernels."""
+    W.set_option("WL_LONG_W", wmain)
+    W.set_option("WL_LONG_TJ", tj)
+    W.set_option("WL_LONG_WG_PER_CU", 0)
+    W.set_option("WL_LONG2D_MIN_ROWS", 256)
+    shapes = (((512, 512), (1, 2, 3)), ((1024, 2048), (1, 2)), ((2048, 256), (1, 3)), ((256, 96), (1,)), ((768, 130), (1,)), ((1280, 1056), (1, 2)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape) + wmain + tj)
+        for fname in ("db6", "db7", "db8", "db9", "db10", "sym6", "sym8", "coif4", "coif6", "beyl"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            assert len(wt.qmf) in (12, 14, 16, 18, 20), (fname, len(wt.qmf))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_lds_long", (shape, fname, L, W.last_kernel())
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                if not np.array_equal(y, ye):
+                    bad = np.argwhere(y != ye)
+                    raise AssertionError((shape, fname, L, wmain, tj, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist()))
+    W.set_option("WL_LONG2D", 0)                     # the two-pass family on the same input gives the same bits
+    x = rng_array((512, 512), np.float32, 4)
+    wt = W.wavelet(W.WT.db8)
+    y = host(W, W.dwt(dev(W, x), wt, 2))
+    assert W.last_kernel() != "k_fwd2d_lds_long" and np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2))
 
 
 @pytest.mark.parametrize("tj", [32, 128])

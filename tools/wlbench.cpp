@@ -32,6 +32,13 @@ static const std::map<std::string, std::vector<double>> kTaps = {
     {"db4", {0.23037781330889648, 0.7148465705529157, 0.6308807679298589, -0.027983769416860003, -0.18703481171909309, 0.030841381835560722, 0.03288301166688518, -0.010597401785069035}},
     {"sym5", {0.019538882735386898, -0.02110183402492983, -0.17532808990810747, 0.016602105764424325, 0.633978963456949, 0.7234076904038076, 0.1993975339769955, -0.03913424930258344, 0.0295194909260734, 0.02733306834516448}},
     {"db6", {0.11154074335010944, 0.4946238903984531, 0.7511339080210953, 0.31525035170919813, -0.22626469396543938, -0.12976686756726197, 0.09750160558732307, 0.027522865530305647, -0.031582039317485995, 0.0005538422011614999, 0.004777257510945508, -0.0010773010853084798}},
+    {"db7", {0.07785205408500918, 0.3965393194819173, 0.7291320908462351, 0.46978228740519296, -0.14390600392856484, -0.2240361849938754, 0.07130921926683056, 0.08061260915108302, -0.0380299369350144, -0.016574541630666913, 0.012550998556099856, 0.00042957797292136554, -0.001801640704047492, 0.00035371379997452024}},
+    {"db9", {0.038077947363878366, 0.24383467461259042, 0.6048231236901115, 0.6572880780513005, 0.13319738582500773, -0.2932737832791742, -0.09684078322297636, 0.14854074933810593, 0.030725681479334035, -0.06763282906133081, 0.00025094711483188403, 0.02236166212367899, -0.0047232047577513816, -0.004281503682463445, 0.0018476468830562337, 0.00023038576352319562, -0.0002519631889427106, 3.934732031627169e-05}},
+    {"db10", {0.026670057900555565, 0.1881768000776916, 0.5272011889317259, 0.6884590394536039, 0.2811723436605773, -0.24984642432731435, -0.195946274377378, 0.12736934033579372, 0.09305736460357084, -0.07139414716639567, -0.029457536821876806, 0.03321267405934165, 0.0036065535669558176, -0.010733175483330465, 0.001395351747052877, 0.0019924052951850644, -0.0006858566949597138, -0.00011646685512928556, 9.358867032006975e-05, -1.3264202894521261e-05}},
+    {"sym8", {-0.0033824159513594415, -0.0005421323316355467, 0.031695087810345246, 0.0076074873252847675, -0.14329423835105426, -0.06127335906790878, 0.48135965125920116, 0.7771857516997479, 0.3644418948359564, -0.0519458381078751, -0.02721902991681368, 0.049137179673476784, 0.003808752014060054, -0.014952258336792626, -0.00030292051455164, 0.0018899503329007496}},
+    {"coif4", {0.0163873364635998, -0.0414649367819558, -0.0673725547222826, 0.3861100668229939, 0.8127236354493977, 0.4170051844236707, -0.0764885990786692, -0.0594344186467388, 0.0236801719464464, 0.0056114348194211, -0.0018232088707116, -0.0007205494453679}},
+    {"coif6", {-0.003793512864491, 0.0077825964273254, 0.0234526961418362, -0.0657719112818552, -0.0611233900026726, 0.405176902409615, 0.7937772226256169, 0.4284834763776168, -0.0717998216193117, -0.0823019271068856, 0.0345550275730615, 0.0158805448636158, -0.0090079761366615, -0.0025745176887502, 0.0011175187708906, 0.0004662169601129, -7.09833031381e-05, -3.45997728362e-05}},
+    {"beyl", {0.09930576537400788, 0.4242153608130337, 0.6998252140570556, 0.4497182511490357, -0.11092759834800882, -0.264497231446021, 0.026900308804002133, 0.15553873187701237, -0.01752074626700139, -0.08854363062300702, 0.01967986604400156, 0.042916387274003404, -0.017460408696001385, -0.01436580796900114, 0.010040411845000796, 0.0014842347820001177, -0.0027360316260002173, 0.0006404853290000508}},
     {"db8", {0.05441584224310398, 0.3128715909142999, 0.6756307362972896, 0.5853546836542072, -0.015829105256348633, -0.2840155429615473, 0.00047248457391376, 0.1287474266204779, -0.017369301001807197, -0.04408825393079476, 0.013981027917398216, 0.008746094047405775, -0.004870352993451561, -0.0003917403733769489, 0.0006754494064505684, -0.00011747678412476926}},
 };
 

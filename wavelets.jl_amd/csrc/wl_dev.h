@@ -160,6 +160,15 @@ __device__ __forceinline__ void gload16(V &dst, const T *p)
     static_assert(sizeof(V) == 16, "one global_load_dwordx4");
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// The same load, skipped when the wave-uniform flag is 0.  The destination is read-write for the compiler (the old contents
+// survive a skipped load), so there is no control flow -- and no phi / register copy -- around the asynchronous load.
+template <typename V, typename T>
+__device__ __forceinline__ void gload16_if(V &dst, const T *p, int flag)
+{
+    static_assert(sizeof(V) == 16, "one global_load_dwordx4");
+    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwl_skip%=\n\tglobal_load_dwordx4 %0, %1, off\n.Lwl_skip%=:"
+                 : "+v"(dst) : "v"(p), "s"(flag) : "memory", "scc");
+}
 // "at most N vector-memory operations outstanding".  Loads return in issue order among themselves, so this covers every load
 // that has at least N younger LOADS behind it.  Do not count younger stores towards N: round 3 measured (one transform in
 // about a thousand, some boxes only) that a store can be acknowledged while an older load is still in flight.

@@ -49,6 +49,11 @@ hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, b
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
                             int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
 
+// 12..20 taps in one pass per level (wl_fwd2d_long.hip): the LDS-exchange kernel with a 24-slot ring and a wider window.
+bool fwd2d_long_ok(int F, int64_t ms, int64_t ns);
+hipError_t fwd2d_long_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count);
+
 // The Float64 instance of the LDS-exchange kernel (wl_fwd2d64.hip): two rows per lane, exact tiling only.
 bool fwd2d_lds64_ok(int F, int64_t ms, int64_t ns);
 hipError_t fwd2d_lds64_launch(hipStream_t st, const Taps<double> &taps, bool lvl1, const double *src, int64_t lds,
@@ -105,7 +110,7 @@ template <typename T>
 hipError_t launch_tail2_inv(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, int64_t x_item, T *out, int64_t ldo,
                             int64_t out_item, int nitems, int n0, int n1, int nt, int nlev);
 template <typename T>
-bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev);
+bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev, int fmax = 10);
 template <typename T>
 hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64_t s1, T *y, int64_t ldy,
                         int64_t src_item, int64_t y_item, int nitems, int m0, int m1, int nt, int nlev);

@@ -1292,10 +1292,13 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             const int64_t blk = two_d ? n[0] * n[1] : n[0];
             // filters beyond 24 taps: one workgroup is slow at 2 F multiply-adds per sample -- the chip-wide line / axis
             // kernels of wl_vlong.hip take every level down to 16 samples per dimension first
-            const int64_t vl_cap = (vlong_filter_ok(F) && env_int("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40);
+            // ... except 12..20 taps on power-of-two blocks of <= 4096 elements: the LDS-resident tail is instantiated for them
+            const bool long_tail = F >= 12 && env_int("WL_LONG_TAIL", 1) && tail2_ok<T>(F, two_d ? 2 : 1, n[0], two_d ? n[1] : 1, L - l + 1, 20);
+            const int64_t vl_cap = long_tail ? (int64_t)4096
+                                   : ((vlong_filter_ok(F) && env_int("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40));
             if (blk <= (two_d ? (int64_t)tail_cap<T>() : line_cap) && blk <= vl_cap && n[0] < (1 << 20) && (!two_d || n[1] <= 256)) {
                 // power-of-two blocks / lines of <= 16 KiB: the latency-optimised tail (wl_tail.hip)
-                const bool t2 = env_int("WL_TAIL2", 1) && tail2_ok<T>(F, two_d ? 2 : 1, n[0], two_d ? n[1] : 1, L - l + 1);
+                const bool t2 = env_int("WL_TAIL2", 1) && tail2_ok<T>(F, two_d ? 2 : 1, n[0], two_d ? n[1] : 1, L - l + 1, 20);
                 if (two_d) {
                     if (t2) WL_TRY(launch_tail2<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
                     else WL_TRY(launch_tail<T>(st, taps, cur, cur_st.s[1], y, b.full.s[1], 0, 0, 1, (int)n[0], (int)n[1], 2, L - l + 1));
@@ -1437,6 +1440,21 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                                                          b.full.s[1], n[0], nlines, cu_count)));
                           done = true);
             if (done && !dominant) dominant = "k_fwd1d_stream";
+        }
+        // ---- 12..20 taps, Float32, blocks whose rows tile into strips of 256: one pass per level (wl_fwd2d_long.hip) ----
+        if constexpr (sizeof(T) == 4) {
+            if (!done && path == 0 && two_d && env_int("WL_LONG2D", 1) && n[0] >= env_int("WL_LONG2D_MIN_ROWS", 256) && b.full.s[0] == 1 &&
+                cur_st.s[0] == 1 && fwd2d_long_ok(F, n[0], n[1]) && (cur_st.s[1] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&
+                aligned16(y) && aligned16(llbuf)) {
+                T *lld = last ? y : llbuf;
+                const int64_t ldd = last ? b.full.s[1] : (n[0] >> 1);
+                WL_TRY(fwd2d_long_launch(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, n[0], n[1], cu_count));
+                if (!dominant) dominant = "k_fwd2d_lds_long";
+                lstep = 1;
+                int64_t hn2[3] = {n[0] >> 1, n[1] >> 1, n[2]};
+                cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                continue;
+            }
         }
         // ---- long filters (12..24 taps): line kernel with multi-lane halo, 2-D as axis pass + line pass (wl_axis.hip) ----
         if (!done && path == 0 && long_filter_ok(F) && env_int("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1 && cur_st.s[0] == 1) {

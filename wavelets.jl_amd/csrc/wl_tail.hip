@@ -142,9 +142,11 @@ __global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
 }
 
 template <typename T>
-bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev)
+bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev, int fmax)
 {
-    if (F < 2 || F > 10 || (F & 1)) return false;
+    // fmax = 10: the inverse tail and the default; 20: the forward tail is also instantiated for 12..20 taps (wl_fwd2d_long.hip's
+    // filters: one workgroup finishes a 64 x 64 block instead of two chip-wide launches per level down to 16 x 16)
+    if (F < 2 || F > fmax || F > 20 || (F & 1)) return false;
     auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
     if (!pow2(m0) || (nt == 2 && !pow2(m1))) return false;
     if (nt == 1 && m1 != 1) return false;
@@ -206,6 +208,11 @@ hipError_t launch_tail2(hipStream_t st, const Taps<T> &taps, const T *src, int64
     case 6: return launch_tail2_f<T, 6>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
     case 8: return launch_tail2_f<T, 8>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
     case 10: return launch_tail2_f<T, 10>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 12: return launch_tail2_f<T, 12>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 14: return launch_tail2_f<T, 14>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 16: return launch_tail2_f<T, 16>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 18: return launch_tail2_f<T, 18>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
+    case 20: return launch_tail2_f<T, 20>(st, taps, src, s1, y, ldy, src_item, y_item, nitems, m0, m1, nt, nlev);
     default: return hipErrorInvalidValue;
     }
 }
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(512) k_tail2_inv(Tail2InvArgs<T, F> a)
 template <typename T>
 bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item)
 {
-    if (!tail2_ok<T>(F, nt, n0, n1, nlev)) return false;
+    if (!tail2_ok<T>(F, nt, n0, n1, nlev, 10)) return false;
     // the last level of a line is stored as 8-byte pairs
     if (nt == 1 && ((reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) != 0 || (out_item % 2) != 0)) return false;
     return true;
@@ -571,8 +578,8 @@ template hipError_t launch_tail3<float>(hipStream_t, const Taps<float> &, int, c
 template hipError_t launch_tail3<double>(hipStream_t, const Taps<double> &, int, const double *, int64_t, int64_t, double *, int64_t, int64_t, int,
                                          int, int, int);
 
-template bool tail2_ok<float>(int, int, int64_t, int64_t, int);
-template bool tail2_ok<double>(int, int, int64_t, int64_t, int);
+template bool tail2_ok<float>(int, int, int64_t, int64_t, int, int);
+template bool tail2_ok<double>(int, int, int64_t, int64_t, int, int);
 template hipError_t launch_tail2<float>(hipStream_t, const Taps<float> &, const float *, int64_t, float *, int64_t, int64_t, int64_t, int, int, int,
                                         int, int);
 template hipError_t launch_tail2<double>(hipStream_t, const Taps<double> &, const double *, int64_t, double *, int64_t, int64_t, int64_t, int, int,

@@ -3,7 +3,7 @@
 #   bench lines for every BASELINE config, rocprofv3 kernel stats of the same commands, the PMC traffic passes of the
 #   headline kernel (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only) and the perf matrix.
 #   tools/rp.sh returns as soon as rocprofv3's CSVs are on disk (rocprofv3 does not exit on its own on this image).
-R=${1:-r02}
+R=${1:-r03}
 REPO=$PWD
 O=$REPO/gpurun_out/prof_$R
 mkdir -p $O
@@ -17,15 +17,15 @@ done
 for c in c3 c2 c4 c5; do
   $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --no-pipelined --steps 50 --warmup 3
 done
-for k in idwt2d lift2d lift2d_inv dwt3d modwt denoise; do
+for k in idwt2d lift2d lift2d_inv dwt3d modwt denoise dwt2d_f64 dwt2d_db8; do
   $REPO/tools/rp.sh $O/stats_$k $R "--kernel-trace --stats" python $REPO/tools/run_case.py $k 20
 done
-# PMC: the first launch of the headline transform (L = 1 call = exactly that kernel), torch-free harness
+# PMC: the first launch of the headline transform (an L = 2 call = exactly that kernel: levels 1-2 fused), torch-free harness
 for pmc in FETCH_SIZE WRITE_SIZE; do
-  $REPO/tools/rp.sh $O/pmc_$pmc $R "--kernel-trace --pmc $pmc" $B L=1 reps=30 warm=5 check=0
+  $REPO/tools/rp.sh $O/pmc_$pmc $R "--kernel-trace --pmc $pmc" $B L=2 reps=30 warm=5 check=0
 done
-$REPO/tools/rp.sh $O/pmc_sq $R "--kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $B L=1 reps=30 warm=5 check=0
-$REPO/tools/rp.sh $O/pmc_tcc $R "--kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $B L=1 reps=30 warm=5 check=0
+$REPO/tools/rp.sh $O/pmc_sq $R "--kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $B L=2 reps=30 warm=5 check=0
+$REPO/tools/rp.sh $O/pmc_tcc $R "--kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $B L=2 reps=30 warm=5 check=0
 timeout 600 python $REPO/tools/perf_matrix.py > $O/perf_matrix.md 2> $O/perf_matrix.err
 find $O -name "*.csv" -size +4M -delete
 find $O -name "*.csv" | head -60

@@ -29,6 +29,11 @@ elif case == "dwt2d_f64":
     x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
     y = W.similar(x)
     fn = lambda: W.dwt_oop_(y, x, db4, 13)
+elif case == "dwt2d_db8":
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    db8 = W.wavelet(W.WT.db8)
+    fn = lambda: W.dwt_oop_(y, x, db8, 13)
 elif case == "idwt2d_f64":
     x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
     y = W.similar(x)

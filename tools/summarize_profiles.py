@@ -3,11 +3,11 @@ under profiles/: per-config bench lines, rocprofv3 kernel-stats CSVs, the PMC co
 profiles/pmc_latest.json (bytes per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 note) and the perf matrix."""
 import csv, glob, json, os, shutil, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
-HEAD = "k_fwd2d_lds<8, 1, 1>"          # first launch of the 8192 x 8192 f32 db4 transform (its own template instance)
+HEAD = "k_fwd2d_pair<8, 2, 1>"         # first launch of the 8192 x 8192 f32 db4 transform: levels 1-2 fused (its own template instance)
 
 
 def find(sub, pat):
@@ -21,7 +21,7 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
-for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise"):
+for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise", "dwt2d_f64", "dwt2d_db8"):
     p = find(f"stats_{k}", "*kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(DST, f"{R}_{k}_kernel_stats.csv"))
@@ -65,8 +65,8 @@ if len(pm) == 2:
     write = pm["WRITE_SIZE"][0] * 1024
     alg = 2 * 8192 * 8192 * 4
     out = {
-        "kernel": f"wl::{HEAD} (first launch of the 8192x8192 f32 db4 dwt: level 1)",
-        "kernel_short": "k_fwd2d_lds",
+        "kernel": f"wl::{HEAD} (first launch of the 8192x8192 f32 db4 dwt: levels 1-2 fused)",
+        "kernel_short": "k_fwd2d_pair",
         "FETCH_SIZE_KB_raw": round(pm["FETCH_SIZE"][0], 1), "WRITE_SIZE_KB_raw": round(pm["WRITE_SIZE"][0], 1),
         "launches": [pm["FETCH_SIZE"][1], pm["WRITE_SIZE"][1]],
         "fetch_bytes_corrected": int(fetch), "write_bytes": int(write), "hbm_bytes_per_launch": int(fetch + write),
@@ -74,8 +74,9 @@ if len(pm) == 2:
         "other_counters_avg_per_launch": extra,
         "note": ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only "
                  f"(profiles/{R}_c3_first_launch_pmc_*.csv); per-launch averages in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-                 "(gfx950 reports 1/2 of 16-B/lane coalesced reads). traffic/algorithmic = %.3f (exact row tiling: the only "
-                 "redundant reads are the 6 halo columns per 128-column chunk and the helper waves' 8 halo rows per 1024)"
+                 "(gfx950 reports 1/2 of 16-B/lane coalesced reads). traffic/algorithmic = %.3f (exact row tiling; redundant reads: "
+                 "18 halo columns per 128-column chunk and the helper waves' 24 halo rows per 512; the level-1 approximation "
+                 "never reaches HBM)"
                  % ((fetch + write) / alg)),
     }
     json.dump(out, open(os.path.join(DST, "pmc_latest.json"), "w"), indent=1)

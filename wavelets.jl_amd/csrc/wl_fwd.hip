@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
     const int own_len = (int)((own0 + a.TS <= n) ? a.TS : (n - own0));
     const int lenA = own_len + 2 * H[0];
     T *bufA = reinterpret_cast<T *>(smem_raw);
-    T *bufB = bufA + ((a.TS + 2 * H[0] + 7) & ~7);
+    T *bufB = bufA + ((a.TS + 2 * H[0] + 7) & ~7) + 16;
     const T *src = a.src + (int64_t)blockIdx.y * a.src_ls;
     T *y = a.y + (int64_t)blockIdx.y * a.y_ls;
 
@@ -575,10 +575,18 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
             for (int u = 0; u < UL; ++u) {
                 const int c = c0 + u * 256;
                 if (c < nch) {
+                    const int j0 = c * VEC - r;
+                    if (r == 0 && j0 + VEC <= lenA) {
+                        vstore16<T, VEC>(bufA + j0, v[u]);                                   // one 16-byte LDS write
+                    } else if (VEC == 4 && r == 2 && j0 >= 0 && j0 + VEC <= lenA) {
+                        vstore<T, 2>(bufA + j0, reinterpret_cast<const T(&)[2]>(v[u][0]));   // two 8-byte halves
+                        vstore<T, 2>(bufA + j0 + 2, reinterpret_cast<const T(&)[2]>(v[u][2]));
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int j = c * VEC + e - r;
-                        if (j >= 0 && j < lenA) bufA[j] = v[u][e];
+                        for (int e = 0; e < VEC; ++e) {
+                            const int j = j0 + e;
+                            if (j >= 0 && j < lenA) bufA[j] = v[u][e];
+                        }
                     }
                 }
             }
@@ -586,6 +594,14 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
     }
     lds_barrier_vm();
     T *Ain = bufA, *Aout = bufB;
+    // (Tried in round 3 and dropped: ONE buffer, each level writing its approximation over the input it has consumed after an
+    //  extra barrier -- 17 KiB of LDS, eight resident workgroups instead of six: 8192 x 2^16 1107 us against 997.)
+    // A thread owns PPT = 16 / sizeof(T) consecutive pairs: one 16-byte window row per ds_read_b128, one 16-byte store per
+    // output stream.  (Round 2 gave a thread two pairs: Float32 details left in 8-byte stores, half the width, and the 2 F
+    // window values read for two pairs are enough for four.)
+    constexpr int PPT = VEC;
+    constexpr int NWIN = ((2 * PPT + 2 * F - 4) + VEC - 1) / VEC * VEC;
+    const int lane = tid & 63;
     for (int t = 1; t <= NL; ++t) {
         const int ownt = own_len >> t;
         const int Lout = ownt + 2 * H[t];
@@ -593,12 +609,18 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
         T *dd = y + (n >> t);
         const bool lastlev = (t == NL);
         T *sg = a.sdst + (int64_t)blockIdx.y * a.s_ls;
-        for (int i = 2 * tid; i < Lout; i += 2 * 256) {
-            T xv[2 * F];
-            vload16<T, 2 * F>(Ain + 2 * i, xv);       // window of pairs i and i+1 (2i is a multiple of 4)
-            T so[2], dO[2];
+        // global position of local pair i is k0 + i - H[t]; k0 is a multiple of PPT (tiles of >= 4096 bytes), so a thread's
+        // group starts PPT - mis pairs before an aligned 16-byte group, mis = H[t] mod PPT (0, or 2 for Float32)
+        const int mis = H[t] & (PPT - 1);
+        const bool quads = (ownt % PPT) == 0 && (k0 % PPT) == 0;
+        // wave-uniform trip count: the lane exchange below needs the neighbour lane inside the loop
+        for (int i0 = PPT * (tid - lane); i0 < Lout; i0 += PPT * 256) {
+            const int i = i0 + PPT * lane;
+            T xv[NWIN];
+            vload16<T, NWIN>(Ain + 2 * i, xv);        // window of pairs i .. i+PPT-1 (2i is a multiple of 2 PPT)
+            T so[PPT], dO[PPT];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < PPT; ++q) {
                 T sv = a.tp.h[0] * xv[2 * q + F - 2];
 #pragma unroll
                 for (int m = 1; m < F; ++m) sv = sv + a.tp.h[m] * xv[2 * q + F - 2 + m];
@@ -608,23 +630,40 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
                 so[q] = sv;
                 dO[q] = dv;
             }
-            const bool two = (i + 1) < Lout;
-            const int io = i - H[t];                  // owned iff 0 <= io < ownt
-            if (!lastlev) {
-                Aout[i] = so[0];
-                if (two) Aout[i + 1] = so[1];
-            }
-            if (io >= 0 && io < ownt) {
-                if (two && io + 1 < ownt) {
-                    vstore<T, 2>(dd + k0 + io, dO);
-                    if (lastlev) vstore<T, 2>(sg + k0 + io, so);
-                } else {
-                    dd[k0 + io] = dO[0];
-                    if (lastlev) sg[k0 + io] = so[0];
+            if (!lastlev && i < Lout) vstore16<T, PPT>(Aout + i, so);      // (the tail of the last group lands in the padding)
+            const int io = i - H[t];                  // pair i + q is owned iff 0 <= io + q < ownt
+            if (quads && mis == 0) {
+                if (io >= 0 && io + PPT <= ownt) {
+                    vstore16<T, PPT>(dd + k0 + io, dO);
+                    if (lastlev) vstore16<T, PPT>(sg + k0 + io, so);
                 }
-            } else if (two && io + 1 >= 0 && io + 1 < ownt) {
-                dd[k0 + io + 1] = dO[1];
-                if (lastlev) sg[k0 + io + 1] = so[1];
+            } else if (quads && PPT == 4 && mis == 2) {
+                // pairs io+2, io+3 open an aligned group that the next lane's first two pairs complete
+                constexpr int Q2 = (PPT == 4) ? 2 : 0, Q3 = (PPT == 4) ? 3 : 1;      // (Float32 only; keeps the Float64 instance well-formed)
+                T q4[4] = {dO[Q2], dO[Q3], from_next(dO[0]), from_next(dO[1])};
+                T s4[4] = {so[Q2], so[Q3], from_next(so[0]), from_next(so[1])};
+                const int ia = io + 2;
+                if (lane != 63) {
+                    if (ia >= 0 && ia + 4 <= ownt) {
+                        vstore16<T, 4>(dd + k0 + ia, q4);
+                        if (lastlev) vstore16<T, 4>(sg + k0 + ia, s4);
+                    }
+                } else if (ia >= 0 && ia + 2 <= ownt) {   // (the completing lane belongs to another wave: two 8-byte halves)
+                    vstore<T, 2>(dd + k0 + ia, reinterpret_cast<const T(&)[2]>(q4[0]));
+                    if (lastlev) vstore<T, 2>(sg + k0 + ia, reinterpret_cast<const T(&)[2]>(s4[0]));
+                }
+                if (lane == 0 && io >= 0 && io + 2 <= ownt) {
+                    vstore<T, 2>(dd + k0 + io, reinterpret_cast<const T(&)[2]>(dO[0]));
+                    if (lastlev) vstore<T, 2>(sg + k0 + io, reinterpret_cast<const T(&)[2]>(so[0]));
+                }
+            } else {
+                // short / oddly placed tiles: element by element
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+                    if (io + q >= 0 && io + q < ownt && i + q < Lout) {
+                        dd[k0 + io + q] = dO[q];
+                        if (lastlev) sg[k0 + io + q] = so[q];
+                    }
             }
         }
         lds_barrier();
@@ -1128,7 +1167,7 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     while (a.TS > (int)(4096 / sizeof(T)) && ((n + a.TS - 1) / a.TS) * nlines < 512) a.TS >>= 1;
     a.tp = shrink<T, F>(taps);
     const int H0 = (F - 2) * ((1 << NL) - 1), H1 = (F - 2) * ((1 << (NL - 1)) - 1);
-    const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + (size_t)(a.TS / 2 + 2 * H1 + 8);
+    const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + 16 + (size_t)(a.TS / 2 + 2 * H1 + 8) + 32;   // (+ room for the last groups' windows)
     const size_t shmem = elems * sizeof(T);
     const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
     const int64_t slab = env_int_raw("WL_SLAB_LINES", 32768);

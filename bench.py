@@ -31,6 +31,7 @@ Objects on the JSON line:
 Other workloads (parity-test configs, not the headline): --workload c1|c2|c4|c5.
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -91,9 +92,8 @@ def respawn_command(args, argv):
 # launches on)
 def _event_train_ms(fns, reps, chunk=10):
     """ms per call inside a back-to-back train of `reps` calls (fns are used round-robin).  The train is enqueued without a
-    gap but timed in chunks of `chunk` calls (events between the chunks); the figure is the MEDIAN chunk.  Once or twice per
-    process the ROCm runtime stalls the queue for 30-40 ms (seen at any depth, tools' stall probe); inside a 100-call train
-    that would triple a plain average, the median chunk does not see it."""
+    gap but timed in chunks of `chunk` calls (events between the chunks); the figure is the MEDIAN chunk, so that a single
+    host hiccup (a garbage collection, an interrupt) inside a 100-call train cannot triple the figure."""
     for i in range(min(5, reps)):
         fns[i % len(fns)]()
     torch.cuda.synchronize()
@@ -215,7 +215,22 @@ class HipBackend:
 
 def timed_steps(step, backend, dist, sharding, device, steps, warmup, precondition=0):
     """The driver's protocol: [untimed conditioning] barrier + synchronize, W warm-up steps, synchronize, K timed steps,
-    synchronize, barrier; returns the MAX over ranks of this rank's wall time for the K steps (seconds)."""
+    synchronize, barrier; returns the MAX over ranks of this rank's wall time for the K steps (seconds).
+    Python's cyclic garbage collector is off inside (as in `timeit`): with torch imported, the first full collection of a
+    process takes 35-45 ms of host time -- it arrives around the 1240th library call (70 000 container allocations) and, landing
+    in a timed region whose calls are shorter than the host's lead, shows up as a stall of the whole queue (round 2 blamed the
+    ROCm runtime for it; tools/exp measured the same stall at the same call index for 3- and 6-launch calls, and none after
+    gc.freeze())."""
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    try:
+        return _timed_steps(step, backend, dist, sharding, device, steps, warmup, precondition)
+    finally:
+        gc.enable()
+
+
+def _timed_steps(step, backend, dist, sharding, device, steps, warmup, precondition=0):
     for i in range(precondition):
         step(i)
     backend.sync()
@@ -347,6 +362,11 @@ def main():
     from wavelets_jl_amd import sharding
     W._lib.load()
     W.set_kernel_path(args.path)
+    # no cyclic garbage collection during the measurements (see timed_steps): reference counting still frees everything the
+    # bench allocates; the legs below time calls of 20-200 us, a full collection with torch loaded costs 40 ms
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     if world > 1 and args.workload is None:
         out = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device))
@@ -380,8 +400,7 @@ def main():
         def sync():
             torch.cuda.synchronize()
     # device conditioning before the W warm-up steps (untimed, reported in the JSON line): clocks need about a millisecond of
-    # load to ramp, and the ROCm runtime has a one-off enqueue stall the first time the host runs a few hundred launches
-    # ahead -- neither belongs to the steady-state throughput this line reports
+    # load to ramp before the steady-state throughput this line reports
     precondition = max(0, 300 - args.warmup)
     dt = timed_steps(lambda i: fn(xs[i % len(xs)]), _B, dist, sharding, device, args.steps, args.warmup, precondition)
     kernel = W.last_kernel()
@@ -486,7 +505,7 @@ def pipelined_leg(W, xs, wt, L, args, nstreams=4):
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
     outs = [W.similar(xs[0]) for _ in range(nstreams)]
     steps = max(args.steps, 100)
-    for i in range(max(steps, 400)):                  # untimed: creates the contexts, absorbs the runtime's one-off enqueue stall
+    for i in range(max(steps, 400)):                  # untimed: creates the per-stream contexts, ramps the clocks
         with torch.cuda.stream(streams[i % nstreams]):
             W.dwt_oop_(outs[i % nstreams], xs[i % len(xs)], wt, L)
     torch.cuda.synchronize()
@@ -507,8 +526,8 @@ def pipelined_leg(W, xs, wt, L, args, nstreams=4):
 def secondary_leg(W, device, reps=20):
     """Device-timed runs of the other BASELINE.json configs and of the section-8(f) rows (parity-test configs, not the
     headline).  Protocol: 5 untimed calls, then `reps` calls enqueued back to back with ONE HIP EVENT PAIR PER CALL; the
-    figure is the MEDIAN (the minimum is printed beside it), so a single runtime hiccup -- the one-off enqueue stall, a
-    first-use code-object load -- cannot poison it."""
+    figure is the MEDIAN (the minimum is printed beside it), so a single hiccup -- a host garbage collection, a first-use
+    code-object load -- cannot poison it."""
     res = []
 
     def run(label, L, dtag, x, fn, alg_bytes):

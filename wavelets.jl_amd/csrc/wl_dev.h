@@ -137,6 +137,32 @@ __device__ __forceinline__ void window_inv(const T (&sw)[(F - 2) / 2 + 1], const
 }
 
 
+// ---- threshold! (threshold_main.jl:21-80) ----
+// T: element type, C: the type Julia's promotion computes `x[i] op t` in
+template <typename T, typename C>
+__device__ __forceinline__ T threshold_one(T xr, int th, C t)
+{
+    const C xi = (C)xr;
+    const C ax = xi < 0 ? -xi : xi;
+    const C sg = (C)((xi > 0) - (xi < 0));
+    T out = xr;
+    switch (th) {
+    case WL_TH_HARD: if (ax <= t) out = (T)0; break;
+    case WL_TH_SOFT: { const C sh = ax - t; out = (sh < 0) ? (T)0 : (T)(sg * sh); } break;
+    case WL_TH_SEMISOFT:
+        if (xi <= 2 * t) {
+            const C sh = ax - t;
+            if (sh < 0) out = (T)0;
+            else if (sh - t < 0) out = (T)(sg * sh * 2);
+        }
+        break;
+    case WL_TH_STEIN: { const C sh = 1 - t * t / (xi * xi); out = (sh < 0) ? (T)0 : (T)(xi * sh); } break;
+    case WL_TH_POS: if (xi > 0) out = (T)0; break;
+    case WL_TH_NEG: if (xi < 0) out = (T)0; break;
+    }
+    return out;
+}
+
 // ---- hand-placed vector-memory loads / waits of the 2-D marching kernels (wl_fwd2d.hip, wl_pair2d.hip) ----
 __device__ __forceinline__ void wg_lds_sync(bool multi)
 {

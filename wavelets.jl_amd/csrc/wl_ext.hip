@@ -8,6 +8,7 @@
 // results are bit-identical to the reference loops.
 #include "wl_ctx.h"
 #include "wl_fast.h"
+#include "wl_dev.h"
 
 #include <cmath>
 #include <cstring>
@@ -317,30 +318,7 @@ int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int
 }
 
 // ---- threshold! ------------------------------------------------------------------------------------
-// T: element type, C: the type Julia's promotion computes `x[i] op t` in
-template <typename T, typename C>
-__device__ __forceinline__ T threshold_one(T xr, int th, C t)
-{
-    const C xi = (C)xr;
-    const C ax = xi < 0 ? -xi : xi;
-    const C sg = (C)((xi > 0) - (xi < 0));
-    T out = xr;
-    switch (th) {
-    case WL_TH_HARD: if (ax <= t) out = (T)0; break;
-    case WL_TH_SOFT: { const C sh = ax - t; out = (sh < 0) ? (T)0 : (T)(sg * sh); } break;
-    case WL_TH_SEMISOFT:
-        if (xi <= 2 * t) {
-            const C sh = ax - t;
-            if (sh < 0) out = (T)0;
-            else if (sh - t < 0) out = (T)(sg * sh * 2);
-        }
-        break;
-    case WL_TH_STEIN: { const C sh = 1 - t * t / (xi * xi); out = (sh < 0) ? (T)0 : (T)(xi * sh); } break;
-    case WL_TH_POS: if (xi > 0) out = (T)0; break;
-    case WL_TH_NEG: if (xi < 0) out = (T)0; break;
-    }
-    return out;
-}
+// (threshold_one: wl_dev.h -- the level-1 kernel of the translation-invariant batch applies it at its stores)
 template <typename T, typename C>
 __global__ void __launch_bounds__(EXT_THREADS) k_threshold(T *__restrict__ x, int64_t n, int th, C t, int vec_ok)
 {
@@ -843,6 +821,18 @@ __global__ void __launch_bounds__(EXT_THREADS) k_threshold_dev(T *__restrict__ x
     const double t = sigma * t_unit;
     ew_inplace<T>(x, n, vec_ok, [=](T v, int64_t) { return threshold_one<T, double>(v, th, t); });
 }
+// the same on the approximation quadrant [0, h0) x [0, h1) of every plane of a batch (leading dimension n0, plane stride N): the
+// details of level 1 were thresholded by the kernel that produced them (SrcView::th)
+template <typename T>
+__global__ void __launch_bounds__(256) k_threshold_dev_quadrant(T *__restrict__ x, int64_t n0, int64_t N, int64_t h0, int th,
+                                                                const double *__restrict__ mad_dev, double t_unit, double sigma_host)
+{
+    const double sigma = (sigma_host >= 0) ? sigma_host : (*mad_dev / 0.6745);
+    const double t = sigma * t_unit;
+    T *col = x + (int64_t)blockIdx.z * N + (int64_t)blockIdx.y * n0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < h0; i += (int64_t)gridDim.x * blockDim.x)
+        col[i] = threshold_one<T, double>(col[i], th, t);
+}
 template <typename T>
 __global__ void __launch_bounds__(EXT_THREADS) k_copy_range(T *__restrict__ dst, const T *__restrict__ src, int64_t n)
 {
@@ -863,17 +853,31 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     SelState *sel = (SelState *)ctx->aux;
     // spins per batch: the whole set unless the buffers (2 N B for the shifted copies and their coefficients, plus the
     // transform workspace of the batch box) would pass the cap
-    const size_t cap = (size_t)opt("WL_TI_WS_CAP_MB", 16384) << 20;
-    auto need = [&](int64_t B) { return (ws_elems(N * B, ndims) + (size_t)2 * N * B + (size_t)n0 + 64) * sizeof(T); };
+    // Virtual shifts (Float32 square images on the LDS-exchange level kernel): a circular shift along dim 2 is an offset of the
+    // column index inside the level-1 kernel, so only the nsp0 row-shifted copies of x are materialised (ZR) instead of
+    // nsp0 * nsp1 shifted planes -- for 8 x 8 spins of a 2048^2 image 128 MiB written instead of 1 GiB (265 us of 2.4 ms).
+    bool virt = false;
+    if constexpr (sizeof(T) == 4) {
+        virt = ndims == 2 && L >= 1 && ctx->path == 0 && (flen % 2) == 0 && flen <= 10 && opt("WL_TI_VIRTSHIFT", 1) != 0 &&
+               fwd2d_lds_ok(flen, 1, n0, n1) && (n0 % 4) == 0 && nsp1 <= n1 && nsp0 <= n0 && nsp0 < (1 << 20);
+    }
+    const size_t zr_elems = virt ? (size_t)N * (size_t)nsp0 : 0;
+    const size_t cap = (size_t)opt("WL_TI_WS_CAP_MB", 8192) << 20;
+    auto need = [&](int64_t B) { return (ws_elems(N * B, ndims) + (size_t)2 * N * B + zr_elems + (size_t)n0 + 64) * sizeof(T); };
     int64_t B = pns;
     while (B > 1 && need(B) > cap) B = (B + 1) / 2;
     if (B > 65535) B = 65535;
     rc = wl_ensure_ws(ctx, need(B));
+    while (rc == WL_ENOMEM && B > 1) {                      // (another allocator may own most of the HBM: smaller groups of spins)
+        B = (B + 1) / 2;
+        rc = wl_ensure_ws(ctx, need(B));
+    }
     if (rc != WL_OK) return rc;
     T *tw = (T *)ctx->ws;                                   // transform workspace of the batch box (with the generic buffers)
     T *Z = tw + ws_elems(N * B, ndims);
     T *XT = Z + N * B;
-    T *dr = XT + N * B;                                     // detail range of the noise estimate (n0/2 samples)
+    T *ZR = XT + N * B;                                     // row-shifted copies (virtual shifts only)
+    T *dr = ZR + zr_elems;                                  // detail range of the noise estimate (n0/2 samples)
     const unsigned nbk = ext_blocks(N * B, 4, ctx->cu_count);
 
     // ---- sigma = noisest(x, wt): level-1 transform, MAD of y1[detailrange(y1, 1)] (linear indexing: first column) ----
@@ -906,33 +910,54 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     bb.dims[0] = n0; bb.dims[1] = (ndims == 2) ? n1 : 0; bb.dims[2] = 1;
     TiGeom g;
     g.n0 = n0; g.n1 = n1; g.N = N; g.nsp0 = nsp0; g.nsp1 = nsp1;
+    const unsigned gxs = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
+    if (virt) {
+        TiGeom gr = g;                                      // spins 0 .. nsp0-1 shift dim 1 only
+        gr.nsp1 = 1; gr.b0 = 0;
+        hipLaunchKernelGGL((k_ti_shift<T>), dim3(gxs, (unsigned)((n1 + 7) / 8), (unsigned)nsp0), dim3(256), 0, st, ZR, x, gr);
+    }
     for (int64_t b0 = 0; b0 < pns; b0 += B) {
         const int64_t nb = (pns - b0 < B) ? (pns - b0) : B;
         g.b0 = b0;
         if (ndims == 2) { bb.dims[2] = nb; }
         else { bb.dims[1] = nb; bb.dims[2] = 1; }
         bb.full = dense_strides(bb.dims);
-        {
-            const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
-            hipLaunchKernelGGL((k_ti_shift<T>), dim3(gx, (unsigned)((n1 + 7) / 8), (unsigned)nb), dim3(256), 0, st, Z, x, g);
+        bool shifted = false, thresholded_l1 = false;
+        if (virt) {
+            // plane p of this group = copy (b0 + p) % nsp0 of ZR with its columns rotated by (b0 + p) / nsp0
+            tl_srcview.mod = (int)nsp0; tl_srcview.spin0 = b0; tl_srcview.used = 0;
+            // ... and that launch thresholds the level-1 details as it stores them (3/4 of all coefficients)
+            const bool fuse_th = opt("WL_TI_FUSE_TH", 1) != 0 && th == WL_TH_HARD;      // (one Float32 compare; the other kinds compute in Float64)
+            tl_srcview.th = fuse_th ? th : -1; tl_srcview.t_unit = t_unit; tl_srcview.sigma_host = sigma_host; tl_srcview.mad_dev = &sel->result;
+            rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, ZR, taps, L, &ctx->last_kernel, &ctx->last_hip);
+            shifted = tl_srcview.used != 0;
+            tl_srcview.mod = 0; tl_srcview.th = -1;
+            if (rc != WL_OK) return rc;
+            thresholded_l1 = shifted && fuse_th;
+        }
+        if (!shifted) {                                     // (materialised shifted planes: every other case)
+            hipLaunchKernelGGL((k_ti_shift<T>), dim3(gxs, (unsigned)((n1 + 7) / 8), (unsigned)nb), dim3(256), 0, st, Z, x, g);
+            if (L > 0) {
+                rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
+                if (rc != WL_OK) return rc;
+            }
         }
         // L == 0: dwt / idwt are copies (transforms_filter.jl:36-38), so the shifted signal itself is thresholded
         T *const coef = (L == 0) ? Z : XT;
-        if (L > 0) {
-            rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, Z, taps, L, &ctx->last_kernel, &ctx->last_hip);
-            if (rc != WL_OK) return rc;
+        if (thresholded_l1) {
+            const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
+            hipLaunchKernelGGL((k_threshold_dev_quadrant<T>), dim3((unsigned)((h0 + 255) / 256 > 8 ? 8 : (h0 + 255) / 256), (unsigned)h1, (unsigned)nb),
+                               dim3(256), 0, st, coef, n0, N, h0, th, &sel->result, t_unit, sigma_host);
+        } else {
+            hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, coef, N * nb, th, &sel->result, t_unit, sigma_host,
+                               vec_ok16(coef));
         }
-        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, coef, N * nb, th, &sel->result, t_unit, sigma_host,
-                           vec_ok16(coef));
         if (L > 0) {
             const char *kn = nullptr;
             rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, Z, XT, taps, L, &kn, &ctx->last_hip);
             if (rc != WL_OK) return rc;
         }
-        {
-            const unsigned gx = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
-            hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(gx, (unsigned)n1), dim3(256), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
-        }
+        hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(gxs, (unsigned)n1), dim3(256), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
     }
     hipLaunchKernelGGL((k_rmul<T>), dim3(ext_blocks(N, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, N, 1.0 / (double)pns, vec_ok16(y));
     WL_HIP(ctx, hipGetLastError());

@@ -42,12 +42,23 @@ template <typename T>
 int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t ldy, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
+// Level-1 source view of a batch of planes (translation-invariant denoise): plane p of the batch is NOT materialised; it is
+// read from row-shifted copy (spin0 + p) % mod of the image with its columns rotated by (spin0 + p) / mod -- a circular shift
+// along dim 2 is an offset of the column index, only the shift along the contiguous dim 1 needs a copy (mod copies instead of
+// mod * nsp1 planes).  Set by the caller around filter_fwd_levels; consumed (and `used` set) by the plane-batched level-1 launch.
+// th >= 0 additionally makes that launch threshold the level-1 DETAIL coefficients as it stores them (threshold!(xt, th, sigma * t),
+// denoising.jl:58; sigma = sigma_host, or *mad_dev / 0.6745 when sigma_host < 0): the caller then thresholds only the
+// approximation quadrant, which the deeper levels fill.
+struct SrcView { int mod; int64_t spin0; int used; int th; double t_unit, sigma_host; const double *mad_dev; };
+extern thread_local SrcView tl_srcview;
+
 // LDS-exchange streaming kernel (wl_fwd2d.hip): one (nlev = 1) or two (nlev = 2) fused forward 2-D levels, Float32,
 // even F <= 10 (F <= 8 for nlev = 2).  fwd2d_lds_ok = shape eligibility.
 bool fwd2d_lds_ok(int F, int nlev, int64_t ms, int64_t ns);
 hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, bool lvl1, const float *src, int64_t lds,
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
-                            int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1);
+                            int64_t nbatch = 1, int64_t bs_src = 0, int64_t bs_y = 0, int64_t bs_ll = 0, int nll = 1, int src_mod = 0,
+                            int64_t spin0 = 0, const SrcView *thresh = nullptr);
 
 // 12..20 taps in one pass per level (wl_fwd2d_long.hip): the LDS-exchange kernel with a 24-slot ring and a wider window.
 bool fwd2d_long_ok(int F, int64_t ms, int64_t ns);

@@ -1219,6 +1219,8 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+thread_local SrcView tl_srcview = {0, 0, 0, -1, 0.0, 0.0, nullptr};
+
 template <typename T>
 int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
                       T *y, const T *x, const Taps<T> &taps, int L, const char **kernel_name, int *hip_err)
@@ -1260,8 +1262,12 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             if (fastF && b.nd == 3 && b.nt == 2 && fwd2d_lds_ok(F, 1, n[0], n[1]) && n[2] <= 65535 && cur_st.s[0] == 1 &&
                 (cur_st.s[1] % VEC) == 0 && (cur_st.s[2] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&
                 (b.full.s[2] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+                const bool view = (l == 1 && tl_srcview.mod > 0);      // level 1 of a translation-invariant batch: virtual shifted planes
                 WL_TRY(fwd2d_lds_launch(st, taps, 1, l == 1, cur, cur_st.s[1], y, b.full.s[1], last ? (T *)nullptr : llbuf, hn[0],
-                                        n[0], n[1], cu_count, n[2], cur_st.s[2], b.full.s[2], ll_st.s[2], (int)n[2]));
+                                        n[0], n[1], cu_count, n[2], cur_st.s[2], b.full.s[2], ll_st.s[2], (int)n[2],
+                                        view ? tl_srcview.mod : 0, view ? tl_srcview.spin0 : 0,
+                                        (view && tl_srcview.th >= 0) ? &tl_srcview : nullptr));
+                if (view) tl_srcview.used = 1;
                 if (!dominant) dominant = "k_fwd2d_lds";
                 cur = llbuf; cur_st = ll_st; pp ^= 1;
                 continue;

@@ -41,10 +41,12 @@ struct Lds2DArgs {
     int rev;
     int helper;                       // 1: the workgroup's last wave only supplies halo rows (exact tiling)
     int64_t bs_src, bs_y, bs_ll; int nll;    // batch of independent blocks over blockIdx.y (planes of a 3-D level)
+    int src_mod; int64_t spin0;       // > 0: plane p reads copy (spin0 + p) % src_mod with its columns rotated by (spin0 + p) / src_mod (SrcView)
+    int th; double t_unit, sigma_host; const double *mad_dev;     // TH instances: threshold the details at the store (SrcView)
     TapsF<float, F> tp;
 };
 
-template <int F, int LVL1>
+template <int F, int LVL1, int TH = 0>
 __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
 {
     typedef float T;
@@ -87,7 +89,14 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     const int64_t j0 = (int64_t)chunk * a.TJ;
     const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
     const int S = (int)((jend - j0) >> 1);                       // steps = output columns of this chunk (multiple of 8)
-    const T *base = a.src + (int64_t)blockIdx.y * a.bs_src + row;
+    // virtual circular shift along dim 2 (translation-invariant denoise): column j of the plane is column j - crot of its source
+    int64_t splane = blockIdx.y, crot = 0;
+    if (a.src_mod > 0) {
+        const int64_t spin = a.spin0 + (int64_t)blockIdx.y;
+        splane = spin % a.src_mod;
+        crot = spin / a.src_mod;
+    }
+    const T *base = a.src + splane * a.bs_src + row;
 
     T4 ring[R];
 #pragma unroll
@@ -97,6 +106,8 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         for (int c = 0; c < R - 2; ++c) {
             int64_t jc = j0 + c;
             if (jc >= ns) jc -= ns;
+            jc -= crot;
+            if (jc < 0) jc += ns;
             gload16(ring[c], base + jc * a.lds);
         }
     }
@@ -110,6 +121,15 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     T *const llb = to_ll ? (a.ll + (int64_t)blockIdx.y * a.bs_ll) : yb;
     const int64_t ldl = to_ll ? a.ldll : a.ldy;
     const int64_t kbase = j0 >> 1;                     // multiple of 8
+    // TH (hard threshold only): |x| <= t with t = sigma * dnt.t in Float64 (the reference compares the promoted values) is
+    // |x| <= tf for the largest Float32 tf <= t -- one compare and one select per coefficient.  (The general threshold_one in
+    // Float64 made this kernel, which is VALU-bound with 10 taps, slower than the separate pass it was meant to save.)
+    float tf = 0.f;
+    if constexpr (TH != 0) {
+        const double tthr = ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit;
+        tf = (float)tthr;
+        if ((double)tf > tthr) tf = __uint_as_float(__float_as_uint(tf) - 1u);        // (tthr >= 0: the next float towards zero)
+    }
 
     auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
         if (prefetch && loader) {
@@ -118,6 +138,8 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
+                jc -= crot;
+                if (jc < 0) jc += ns;
                 gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
             }
         }
@@ -167,6 +189,15 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
             for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
             P[q] = s;
             Q[q] = d;
+        }
+        if constexpr (TH != 0) {
+            // the three detail components of every row (sd, ds, dd) are final coefficients: threshold!(xt, th, sigma * t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                P[q].y = (__builtin_fabsf(P[q].y) <= tf) ? 0.f : P[q].y;
+                Q[q].x = (__builtin_fabsf(Q[q].x) <= tf) ? 0.f : Q[q].x;
+                Q[q].y = (__builtin_fabsf(Q[q].y) <= tf) ? 0.f : Q[q].y;
+            }
         }
         const int64_t k = kbase + t;
         int64_t kd = k + SH;
@@ -233,11 +264,14 @@ static Shape2D pick_shape(int64_t ms, int mode, int wmain)
 template <int F>
 static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds,
                                float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
-                               int64_t nbatch, int64_t bs_src, int64_t bs_y, int64_t bs_ll, int nll)
+                               int64_t nbatch, int64_t bs_src, int64_t bs_y, int64_t bs_ll, int nll, int src_mod, int64_t spin0,
+                               const SrcView *thresh)
 {
     Lds2DArgs<F> a;
+    a.th = thresh ? thresh->th : -1; a.t_unit = thresh ? thresh->t_unit : 0.0; a.sigma_host = thresh ? thresh->sigma_host : 0.0;
+    a.mad_dev = thresh ? thresh->mad_dev : nullptr;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
-    a.bs_src = bs_src; a.bs_y = bs_y; a.bs_ll = bs_ll; a.nll = nll;
+    a.bs_src = bs_src; a.bs_y = bs_y; a.bs_ll = bs_ll; a.nll = nll; a.src_mod = src_mod; a.spin0 = spin0;
     const Shape2D sh = pick_shape(ms, (int)opt("WL_LDS_MODE", 0), (int)opt("WL_LDS_W", 4));
     a.npl = sh.npl; a.nload = sh.nload; a.nstrips = sh.nstrips; a.helper = sh.helper;
     int TJ = (int)opt("WL_TJ", 128);
@@ -252,7 +286,8 @@ static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, bool lvl
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     const int nthreads = 64 * sh.nw;
     const size_t shmem = (size_t)2 * (4 * nthreads + 16) * 8;
-    if (lvl1) hipLaunchKernelGGL((k_fwd2d_lds<F, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
+    if (thresh) hipLaunchKernelGGL((k_fwd2d_lds<F, 1, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
+    else if (lvl1) hipLaunchKernelGGL((k_fwd2d_lds<F, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
     else hipLaunchKernelGGL((k_fwd2d_lds<F, 0>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
     return hipGetLastError();
 }
@@ -268,18 +303,19 @@ bool fwd2d_lds_ok(int F, int nlev, int64_t ms, int64_t ns)
 
 hipError_t fwd2d_lds_launch(hipStream_t st, const Taps<float> &taps, int nlev, bool lvl1, const float *src, int64_t lds,
                             float *y, int64_t ldy, float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count,
-                            int64_t nbatch, int64_t bs_src, int64_t bs_y, int64_t bs_ll, int nll)
+                            int64_t nbatch, int64_t bs_src, int64_t bs_y, int64_t bs_ll, int nll, int src_mod, int64_t spin0,
+                            const SrcView *thresh)
 {
     if (nlev == 2) {
         if (nbatch != 1) return hipErrorInvalidValue;
         return fwd2d_pair_launch(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
     }
     switch (taps.F) {
-    case 2: return launch_lds_f<2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll);
-    case 4: return launch_lds_f<4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll);
-    case 6: return launch_lds_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll);
-    case 8: return launch_lds_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll);
-    case 10: return launch_lds_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll);
+    case 2: return launch_lds_f<2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll, src_mod, spin0, thresh);
+    case 4: return launch_lds_f<4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll, src_mod, spin0, thresh);
+    case 6: return launch_lds_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll, src_mod, spin0, thresh);
+    case 8: return launch_lds_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll, src_mod, spin0, thresh);
+    case 10: return launch_lds_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nbatch, bs_src, bs_y, bs_ll, nll, src_mod, spin0, thresh);
     default: return hipErrorInvalidValue;
     }
 }

@@ -222,7 +222,13 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
     # fast path only where it is the reference's own branch: threshold!(xt, th, t) exists for Hard / Soft / Semisoft / Stein
     # (codes 0..3; Pos / Neg take no t and raise in the loop below exactly as the reference's MethodError does); matrices need
     # one nspin entry per dimension (anything else goes through nspin2circ / circshift in the loop below, as in the reference)
-    if (TI and isinstance(wt, OrthoFilter) and (x.dim() == 1 or (x.dim() == 2 and len(nsp) == 2)) and isinstance(dnt.th, THType)
+    # The plain (not translation-invariant) denoise of an orthogonal filter takes the same device-resident call with ONE spin
+    # of shift zero: y = (0 + idwt(threshold!(dwt(x)))) * 1 -- the same bits (a -0.0 may come back as +0.0), and the noise
+    # estimate never leaves the device (the reference's order needs sigma on the host between noisest and threshold!).
+    one_spin = (not TI) and estnoise is noisest and wt is not None
+    if one_spin:
+        nsp = tuple(1 for _ in range(x.dim()))
+    if ((TI or one_spin) and isinstance(wt, OrthoFilter) and (x.dim() == 1 or (x.dim() == 2 and len(nsp) == 2)) and isinstance(dnt.th, THType)
             and dnt.th.code is not None and 0 <= dnt.th.code <= 3):
         # the translation-invariant branch for orthogonal filters, vectors and square matrices: one device-resident batch
         # (wl_denoise_ti_filter) -- all spins transformed / thresholded / inverted together, the noise estimate consumed on

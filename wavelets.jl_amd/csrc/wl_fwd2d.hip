@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     constexpr int R = 16, U = 8, PFD = (R - F) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
+    // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
     const int nthreads = blockDim.x;
     const bool multi = nthreads > 64;
     const int lp = threadIdx.x;                       // L': lane index within the workgroup's strip
@@ -153,16 +155,16 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         }
         // ---- level l, dim-2 pass on row pairs: {A, B}[r] = scaling / detail (column k / kd) of row r ----
         T2 sa01 = a.tp.h[0] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
-        T2 da01 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
+        T2 da01 = gq(F - 1) * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
         T2 sa23 = a.tp.h[0] * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
-        T2 da23 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
+        T2 da23 = gq(F - 1) * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
 #pragma unroll
         for (int m = 1; m < F; ++m) {
             const T4 xm = ring[(2 * u + m) % R];
             sa01 = sa01 + a.tp.h[m] * T2{xm.x, xm.y};
-            da01 = da01 + a.tp.g[F - 1 - m] * T2{xm.x, xm.y};
+            da01 = da01 + gq(F - 1 - m) * T2{xm.x, xm.y};
             sa23 = sa23 + a.tp.h[m] * T2{xm.z, xm.w};
-            da23 = da23 + a.tp.g[F - 1 - m] * T2{xm.z, xm.w};
+            da23 = da23 + gq(F - 1 - m) * T2{xm.z, xm.w};
         }
         T2 *const w1 = x1 + (t & 1) * rows1;
         *reinterpret_cast<T4 *>(w1 + 4 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
@@ -184,9 +186,9 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
             T2 s = a.tp.h[0] * E[2 * q];
 #pragma unroll
             for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
-            T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+            T2 d = gq(F - 1) * E[2 * q + 10 - F];
 #pragma unroll
-            for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+            for (int m = F - 2; m >= 0; --m) d = d + gq(m) * E[2 * q + 9 - m];
             P[q] = s;
             Q[q] = d;
         }

@@ -40,6 +40,8 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds64(Lds2DArgs64<F> a)
     constexpr int HL = 4;                             // halo lanes: 8 rows above the strip
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
+    // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
     const int nthreads = blockDim.x;
     const int lp = threadIdx.x;                       // L': lane index within the workgroup's strip
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
@@ -104,12 +106,12 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds64(Lds2DArgs64<F> a)
         else wait_vm<0>(ring[(2 * u + F - 2) % R], ring[(2 * u + F - 1) % R]);
         // ---- dim-2 pass on the lane's two rows: {A, B}[r] = scaling / detail (column k / kd) of row r ----
         T2 sa = a.tp.h[0] * ring[(2 * u) % R];
-        T2 da = a.tp.g[F - 1] * ring[(2 * u) % R];
+        T2 da = gq(F - 1) * ring[(2 * u) % R];
 #pragma unroll
         for (int m = 1; m < F; ++m) {
             const T2 xm = ring[(2 * u + m) % R];
             sa = sa + a.tp.h[m] * xm;
-            da = da + a.tp.g[F - 1 - m] * xm;
+            da = da + gq(F - 1 - m) * xm;
         }
         T2 *const w1 = x1 + (t & 1) * rows1;
         w1[2 * lp] = T2{sa.x, da.x};
@@ -124,9 +126,9 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds64(Lds2DArgs64<F> a)
         T2 P = a.tp.h[0] * E[0];                       // {ss, sd} of row ko
 #pragma unroll
         for (int m = 1; m < F; ++m) P = P + a.tp.h[m] * E[m];
-        T2 Q = a.tp.g[F - 1] * E[10 - F];              // {ds, dd} of row kod
+        T2 Q = gq(F - 1) * E[10 - F];              // {ds, dd} of row kod
 #pragma unroll
-        for (int m = F - 2; m >= 0; --m) Q = Q + a.tp.g[m] * E[9 - m];
+        for (int m = F - 2; m >= 0; --m) Q = Q + gq(m) * E[9 - m];
         const int64_t k = kbase + t;
         int64_t kd = k + SH;
         if (kd >= nxj) kd -= nxj;

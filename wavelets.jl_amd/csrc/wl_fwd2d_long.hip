@@ -202,7 +202,9 @@ template <int F>
 static hipError_t launch_long_f(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
 {
-    constexpr int R = 24;
+    // ring slots: 20 for 12 / 14 taps, 24 above -- fewer VGPRs for the shorter filters (20 slots keep them under
+    // 170 VGPRs = 3 waves per SIMD); the unrolled body covers R / 2 steps, any chunk length (guarded steps)
+    constexpr int R = (F <= 14) ? 20 : 24;
     typedef LongGeom<F> G;
     LdsLongArgs<F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;

@@ -63,6 +63,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     __shared__ __attribute__((aligned(16))) T ll1[NSLOT * RL];
     __shared__ __attribute__((aligned(16))) T2 x2[RL];
 
+    // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
@@ -107,8 +109,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     }
 #pragma unroll
                     for (int r = 0; r < RW; ++r) {
-                        if (m == 0) { sa[r] = a.tp.h[0] * xm[r]; da[r] = a.tp.g[F - 1] * xm[r]; }
-                        else { sa[r] = sa[r] + a.tp.h[m] * xm[r]; da[r] = da[r] + a.tp.g[F - 1 - m] * xm[r]; }
+                        if (m == 0) { sa[r] = a.tp.h[0] * xm[r]; da[r] = gq(F - 1) * xm[r]; }
+                        else { sa[r] = sa[r] + a.tp.h[m] * xm[r]; da[r] = da[r] + gq(F - 1 - m) * xm[r]; }
                     }
                 }
 #pragma unroll
@@ -131,9 +133,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     T2 s = a.tp.h[0] * E[2 * q];
 #pragma unroll
                     for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
-                    T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+                    T2 d = gq(F - 1) * E[2 * q + 10 - F];
 #pragma unroll
-                    for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+                    for (int m = F - 2; m >= 0; --m) d = d + gq(m) * E[2 * q + 9 - m];
                     P[q] = s;
                     Q[q] = d;
                 }
@@ -226,13 +228,13 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             }
             T2 da01 = T2{0.f, 0.f}, da23 = T2{0.f, 0.f};
             if (!sonly) {
-                da01 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
-                da23 = a.tp.g[F - 1] * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
+                da01 = gq(F - 1) * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
+                da23 = gq(F - 1) * T2{ring[(2 * u) % R].z, ring[(2 * u) % R].w};
 #pragma unroll
                 for (int m = 1; m < F; ++m) {
                     const T4 xm = ring[(2 * u + m) % R];
-                    da01 = da01 + a.tp.g[F - 1 - m] * T2{xm.x, xm.y};
-                    da23 = da23 + a.tp.g[F - 1 - m] * T2{xm.z, xm.w};
+                    da01 = da01 + gq(F - 1 - m) * T2{xm.x, xm.y};
+                    da23 = da23 + gq(F - 1 - m) * T2{xm.z, xm.w};
                 }
             }
             *reinterpret_cast<T4 *>(w1 + 4 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
@@ -247,8 +249,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
 #pragma unroll
                 for (int m = 0; m < F; ++m) {
                     const T2 xm = *reinterpret_cast<const T2 *>(ll1 + ((t - F + m) & (NSLOT - 1)) * RL + 2 * lp);
-                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = a.tp.g[F - 1] * xm; }
-                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + a.tp.g[F - 1 - m] * xm; }
+                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = gq(F - 1) * xm; }
+                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + gq(F - 1 - m) * xm; }
                 }
                 *reinterpret_cast<T4 *>(x2 + 2 * lp) = T4{s2.x, d2.x, s2.y, d2.y};
             }
@@ -284,9 +286,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             T2 s = a.tp.h[0] * E[2 * q];
 #pragma unroll
             for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
-            T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+            T2 d = gq(F - 1) * E[2 * q + 10 - F];
 #pragma unroll
-            for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+            for (int m = F - 2; m >= 0; --m) d = d + gq(m) * E[2 * q + 9 - m];
             P[q] = s;
             Q[q] = d;
         }

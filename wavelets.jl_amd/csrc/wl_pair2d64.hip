@@ -39,6 +39,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
     __shared__ __attribute__((aligned(16))) T ll1[NSLOT * RL];
     __shared__ __attribute__((aligned(16))) T2 x2[RL];
 
+    // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
@@ -83,8 +85,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
                     }
 #pragma unroll
                     for (int r = 0; r < RW; ++r) {
-                        if (m == 0) { sa[r] = a.tp.h[0] * xm[r]; da[r] = a.tp.g[F - 1] * xm[r]; }
-                        else { sa[r] = sa[r] + a.tp.h[m] * xm[r]; da[r] = da[r] + a.tp.g[F - 1 - m] * xm[r]; }
+                        if (m == 0) { sa[r] = a.tp.h[0] * xm[r]; da[r] = gq(F - 1) * xm[r]; }
+                        else { sa[r] = sa[r] + a.tp.h[m] * xm[r]; da[r] = da[r] + gq(F - 1 - m) * xm[r]; }
                     }
                 }
 #pragma unroll
@@ -102,9 +104,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
                     T2 s = a.tp.h[0] * E[2 * q];
 #pragma unroll
                     for (int m = 1; m < F; ++m) s = s + a.tp.h[m] * E[2 * q + m];
-                    T2 d = a.tp.g[F - 1] * E[2 * q + 10 - F];
+                    T2 d = gq(F - 1) * E[2 * q + 10 - F];
 #pragma unroll
-                    for (int m = F - 2; m >= 0; --m) d = d + a.tp.g[m] * E[2 * q + 9 - m];
+                    for (int m = F - 2; m >= 0; --m) d = d + gq(m) * E[2 * q + 9 - m];
                     P[q] = s;
                     Q[q] = d;
                 }
@@ -179,9 +181,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
             for (int m = 1; m < F; ++m) sa = sa + a.tp.h[m] * ring[(2 * u + m) % R];
             T2 da = T2{0.0, 0.0};
             if (!sonly) {
-                da = a.tp.g[F - 1] * ring[(2 * u) % R];
+                da = gq(F - 1) * ring[(2 * u) % R];
 #pragma unroll
-                for (int m = 1; m < F; ++m) da = da + a.tp.g[F - 1 - m] * ring[(2 * u + m) % R];
+                for (int m = 1; m < F; ++m) da = da + gq(F - 1 - m) * ring[(2 * u + m) % R];
             }
             w1[2 * lp] = T2{sa.x, da.x};
             w1[2 * lp + 1] = T2{sa.y, da.y};
@@ -195,8 +197,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
 #pragma unroll
                 for (int m = 0; m < F; ++m) {
                     const T xm = ll1[((t - F + m) & (NSLOT - 1)) * RL + lp];
-                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = a.tp.g[F - 1] * xm; }
-                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + a.tp.g[F - 1 - m] * xm; }
+                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = gq(F - 1) * xm; }
+                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + gq(F - 1 - m) * xm; }
                 }
                 x2[lp] = T2{s2, d2};
             }
@@ -218,9 +220,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
         T2 P = a.tp.h[0] * E[0];                       // {ss, sd} of row ko
 #pragma unroll
         for (int m = 1; m < F; ++m) P = P + a.tp.h[m] * E[m];
-        T2 Q = a.tp.g[F - 1] * E[10 - F];              // {ds, dd} of row kod
+        T2 Q = gq(F - 1) * E[10 - F];              // {ds, dd} of row kod
 #pragma unroll
-        for (int m = F - 2; m >= 0; --m) Q = Q + a.tp.g[m] * E[9 - m];
+        for (int m = F - 2; m >= 0; --m) Q = Q + gq(m) * E[9 - m];
         *slot = P.x;                                   // approximation column kbase + t -> ring
         const int64_t k = kbase + t;
         int64_t kd = k + SH;

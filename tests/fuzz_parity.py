@@ -69,9 +69,22 @@ def one_case(r, verbose=False):
         wt = W.wavelet(getattr(W.WT, name))
         ye = oracle.dwt_filter(x, wt.qmf, L)
         xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
-    y = W.to_host(W.dwt(xd, wt, L)); kf = W.last_kernel()
-    xr = W.to_host(W.idwt(W.to_device(ye), wt, L)); ki = W.last_kernel()
-    tag = f"{'lifting' if lifting else 'filter'} {name} {dtype.__name__} shape={shape} L={L} [{kf} | {ki}]"
+    # a third of the cases pull the size thresholds of the fused-pair / single-pass kernels down to the fuzzed sizes and vary
+    # their strip / chunk shapes (the default dispatch only uses them from 4096^2 upwards)
+    knobs = {}
+    if not lifting and nd == 2 and r.random() < 0.35:
+        knobs = {"WL_LDS_PAIR_MIN": 0, "WL_LDS_PAIR_MIN64": 0, "WL_LONG2D_MIN_ROWS": 256, "WL_TILE": int(r.integers(0, 2)),
+                 "WL_PAIR_W": int(r.choice([2, 4])), "WL_PAIR_W64": int(r.choice([2, 4])), "WL_TJ2": int(r.choice([32, 64, 128])),
+                 "WL_LONG_W": int(r.choice([0, 1, 2, 4])), "WL_LONG_TJ": int(r.choice([16, 22, 64, 128]))}
+    for k, v in knobs.items():
+        W.set_option(k, v)
+    try:
+        y = W.to_host(W.dwt(xd, wt, L)); kf = W.last_kernel()
+        xr = W.to_host(W.idwt(W.to_device(ye), wt, L)); ki = W.last_kernel()
+    finally:
+        if knobs:
+            W.clear_options()
+    tag = f"{'lifting' if lifting else 'filter'} {name} {dtype.__name__} shape={shape} L={L} {knobs if knobs else ''} [{kf} | {ki}]"
     if verbose:
         print(tag)
     assert np.array_equal(y, ye), "FORWARD " + tag

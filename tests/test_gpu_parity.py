@@ -374,6 +374,7 @@ def test_tile_kernel(gpu, W, oracle, nl3max, dtype):
     non-square blocks, periodic wrap of the last tiles -- bit for bit against the oracle."""
     W.set_option("WL_TILE_NL3_MAX", nl3max)
     W.set_option("WL_TILE_MAX", 2048)
+    W.set_option("WL_TILEB", 0)                     # (the variant without the staging buffer has its own test below)
     W.set_option("WL_LDS2D_MIN_ROWS", 1 << 20)      # keep the streaming kernel out: every level >= 128 goes to the tile kernel
     shapes = (((128, 128), (1, 2, 3, 7)), ((256, 256), (1, 2, 3, 4, 8)), ((512, 512), (2, 3, 5, 9)), ((1024, 1024), (3, 6)),
               ((256, 128), (1, 2, 3, 7)), ((128, 512), (2, 3)), ((2048, 2048), (2, 3)), ((192, 320), (1, 2, 3)))
@@ -573,6 +574,34 @@ def test_tail2_inverse_kernel(gpu, W, oracle, dtype):
             assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname)
             with W.options(WL_TAIL2=0):
                 assert np.array_equal(host(W, W.idwt(dev(W, y), wt, L)), xe), (shape, fname, "general tail")
+
+
+def test_tile_kernel_without_staging(gpu, W, oracle):
+    """k_fwd2d_tileB (two fused levels, the first dim-2 pass straight from global memory: 33 KB of LDS, four workgroups per CU;
+    default for blocks of 2^21 .. 2^22 elements, i.e. the 2048^2 level of C3): every filter length, even and odd depths (a pair
+    followed by single levels / the tail), non-square blocks, the periodic wrap of the last tile row and column -- bit for bit."""
+    W.set_option("WL_TILEB_MIN", 0)
+    W.set_option("WL_LDS2D_MIN_ROWS", 1 << 20)
+    W.set_option("WL_LDS_PAIR_MIN", 1 << 62)
+    shapes = (((128, 128), (2, 3, 7)), ((256, 256), (2, 4, 8)), ((512, 512), (2, 3, 9)), ((1024, 1024), (2, 6)), ((256, 128), (2, 3)),
+              ((128, 512), (2, 3)), ((2048, 2048), (2, 3, 11)), ((192, 320), (2, 3)), ((2048, 1024), (2,)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape))
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            if shape[0] >= 1024 and fname in ("db2", "db3"):
+                continue
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                y = host(W, W.dwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_fwd2d_tileB", (shape, L, W.last_kernel())
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                assert np.array_equal(y, ye), (shape, fname, L, int((y != ye).sum()))
+    W.clear_options()
+    # default dispatch: the 2048^2 block of an 8192^2 transform (after the fused pair) takes it
+    x = rng_array((2048, 2048), np.float32, 3)
+    wt = W.wavelet(W.WT.db4)
+    y = host(W, W.dwt(dev(W, x), wt, 11))
+    assert W.last_kernel() == "k_fwd2d_tileB" and np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 11))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

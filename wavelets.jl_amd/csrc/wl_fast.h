@@ -88,6 +88,10 @@ template <typename T>
 hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
                              int64_t ldll, int M, int N);
 
+// ... and its variant without the staging buffer (two levels, Float32): four workgroups per CU for blocks of 2048 rows
+hipError_t fwd2d_tileB_launch(hipStream_t st, const Taps<float> &taps, const float *src, int64_t lds, float *y, int64_t ldy, float *ll,
+                              int64_t ldll, int M, int N);
+
 // Deep tail of a forward transform (wl_tail.hip): every remaining level of a small power-of-two block / line in one launch.
 // one lifting pass along any axis of a box of any even extent, known scheme shapes (wl_lift.hip)
 template <typename T>

@@ -1273,6 +1273,23 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 continue;
             }
         }
+        // ---- two levels of a block too big for one resident round of the staging tile kernel (2048 rows): tiles without staging ----
+        if constexpr (sizeof(T) == 4) {
+            if (fastF && two_d && env_int("WL_TILEB", 1) && (L - l + 1) >= 2 && n[0] <= env_int("WL_TILEB_MAX", 2048) &&
+                n[1] <= env_int("WL_TILEB_MAX", 2048) && n[0] * n[1] >= (int64_t)env_int_raw("WL_TILEB_MIN", 1 << 21) && cur_st.s[0] == 1 &&
+                (cur_st.s[1] % 4) == 0 && aligned16(cur) && (b.full.s[1] % 4) == 0 && aligned16(y) && aligned16(llbuf) &&
+                fwd2d_tile_ok(F, 2, n[0], n[1])) {
+                const bool lastt = (l + 1 == L);
+                T *lld = lastt ? y : llbuf;
+                const int64_t ldd = lastt ? b.full.s[1] : (n[0] >> 2);
+                WL_TRY(fwd2d_tileB_launch(st, taps, cur, cur_st.s[1], y, b.full.s[1], lld, ldd, (int)n[0], (int)n[1]));
+                if (!dominant) dominant = "k_fwd2d_tileB";
+                lstep = 2;
+                int64_t hn2[3] = {n[0] >> 2, n[1] >> 2, n[2]};
+                cur = llbuf; cur_st = dense_strides(hn2); pp ^= 1;
+                continue;
+            }
+        }
         // ---- tile kernel: 1..3 fused levels of a cache-resident block (wl_tile.hip; Float64: up to 2 levels) ----
         {
             auto al4 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0; };     // 4-element vectors

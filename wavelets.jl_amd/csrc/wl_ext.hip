@@ -527,15 +527,32 @@ __device__ typename KeyOf<T>::U lds_select(const typename KeyOf<T>::U *keys, int
             if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(unsigned)((key >> shift) & 0xff)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned long long kk = sh[1], cum = 0;
-            int b = 0;
-            for (; b < 255; ++b) {
-                if (kk < cum + hist[b]) break;
-                cum += hist[b];
+        // the bin that holds rank kk: first b with kk < hist[0] + ... + hist[b] (255 when none).  One wave scans the 256 bins, four
+        // per lane (thread 0 walking them one dependent LDS read at a time cost ~8 us per pass: 16 passes per mad!)
+        if (tid < 64) {
+            const unsigned int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned int mine = h0 + h1 + h2 + h3;
+            unsigned int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int o = __shfl_up(incl, d, 64);
+                if (tid >= d) incl += o;
             }
-            sh[1] = kk - cum;
-            sh[0] = sh[0] | (((unsigned long long)b) << shift);
+            const unsigned long long kk = sh[1];
+            const unsigned long long excl = incl - mine;
+            const bool hit = kk < (unsigned long long)incl;
+            const unsigned long long m = __ballot(hit);
+            const int first = m ? (__ffsll((long long)m) - 1) : 64;
+            if (tid == first) {
+                int b = 4 * tid;
+                unsigned long long cum = excl;
+                if (kk >= cum + h0) { cum += h0; ++b; if (kk >= cum + h1) { cum += h1; ++b; if (kk >= cum + h2) { cum += h2; ++b; } } }
+                sh[1] = kk - cum;
+                sh[0] = sh[0] | (((unsigned long long)b) << shift);
+            } else if (first == 64 && tid == 63) {       // (cannot happen for kk < n; mirrors the serial walk: bin 255, all lower bins skipped)
+                sh[1] = kk - (excl + h0 + h1 + h2);
+                sh[0] = sh[0] | (255ull << shift);
+            }
         }
         __syncthreads();
     }
@@ -761,10 +778,8 @@ __global__ void __launch_bounds__(256) k_ti_shift(T *__restrict__ Z, const T *__
 template <typename T>
 __global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const T *__restrict__ Z, TiGeom g, int64_t nb, int first)
 {
-    typedef T V4 __attribute__((ext_vector_type(4)));
     __shared__ int sh0[256], sh1[256];
     const int n0 = (int)g.n0, n1 = (int)g.n1, i1 = (int)blockIdx.y;
-    const bool vec = (n0 & 3) == 0 && (reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T))) == 0;
     for (int64_t bb0 = 0; bb0 < nb; bb0 += 256) {
         const int nbb = (int)((nb - bb0 < 256) ? (nb - bb0) : 256);
         __syncthreads();
@@ -775,10 +790,13 @@ __global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const 
             sh1[threadIdx.x] = (int)s1;
         }
         __syncthreads();
-        for (int i0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x); i0 < n0; i0 += 4 * (int)(gridDim.x * blockDim.x)) {
+        // a thread owns rows ib + tid + 256 e (e < 4): consecutive lanes read consecutive addresses of every shifted plane (the
+        // shifts are arbitrary, so 16-byte loads are out; four rows per lane side by side cost four partial lines per load)
+        for (int ib = 4 * (int)(blockIdx.x * blockDim.x); ib < n0; ib += 4 * (int)(gridDim.x * blockDim.x)) {
+            const int ibt = ib + (int)threadIdx.x;
             T acc[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = ((first && bb0 == 0) || i0 + e >= n0) ? (T)0 : y[i0 + e + (int64_t)n0 * i1];
+            for (int e = 0; e < 4; ++e) acc[e] = ((first && bb0 == 0) || ibt + 256 * e >= n0) ? (T)0 : y[ibt + 256 * e + (int64_t)n0 * i1];
             for (int b8 = 0; b8 < nbb; b8 += 8) {
                 T v[8][4];
 #pragma unroll
@@ -790,9 +808,9 @@ __global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const 
                         const int s = sh0[b8 + u];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            int j0 = i0 + e + s;
+                            int j0 = ibt + 256 * e + s;
                             if (j0 >= n0) j0 -= n0;
-                            v[u][e] = (i0 + e < n0) ? zp[j0] : (T)0;
+                            v[u][e] = (ibt + 256 * e < n0) ? zp[j0] : (T)0;
                         }
                     }
                 }
@@ -803,11 +821,9 @@ __global__ void __launch_bounds__(256) k_ti_accumulate(T *__restrict__ y, const 
                         for (int e = 0; e < 4; ++e) acc[e] = acc[e] + v[u][e];
                     }
             }
-            if (vec) {
-                *reinterpret_cast<V4 *>(y + i0 + (int64_t)n0 * i1) = V4{acc[0], acc[1], acc[2], acc[3]};
-            } else {
-                for (int e = 0; e < 4 && i0 + e < n0; ++e) y[i0 + e + (int64_t)n0 * i1] = acc[e];
-            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ibt + 256 * e < n0) y[ibt + 256 * e + (int64_t)n0 * i1] = acc[e];
         }
     }
 }
@@ -923,14 +939,16 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
         else { bb.dims[1] = nb; bb.dims[2] = 1; }
         bb.full = dense_strides(bb.dims);
         bool shifted = false, thresholded_l1 = false;
+        int64_t th_c0 = n0, th_c1 = n1;                      // what the level kernels left unthresholded: the low corner of every plane
         if (virt) {
             // plane p of this group = copy (b0 + p) % nsp0 of ZR with its columns rotated by (b0 + p) / nsp0
-            tl_srcview.mod = (int)nsp0; tl_srcview.spin0 = b0; tl_srcview.used = 0;
+            tl_srcview.mod = (int)nsp0; tl_srcview.spin0 = b0; tl_srcview.used = 0; tl_srcview.corner0 = n0; tl_srcview.corner1 = n1;
             // ... and that launch thresholds the level-1 details as it stores them (3/4 of all coefficients)
             const bool fuse_th = opt("WL_TI_FUSE_TH", 1) != 0 && th == WL_TH_HARD;      // (one Float32 compare; the other kinds compute in Float64)
             tl_srcview.th = fuse_th ? th : -1; tl_srcview.t_unit = t_unit; tl_srcview.sigma_host = sigma_host; tl_srcview.mad_dev = &sel->result;
             rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, ZR, taps, L, &ctx->last_kernel, &ctx->last_hip);
             shifted = tl_srcview.used != 0;
+            th_c0 = tl_srcview.corner0; th_c1 = tl_srcview.corner1;
             tl_srcview.mod = 0; tl_srcview.th = -1;
             if (rc != WL_OK) return rc;
             thresholded_l1 = shifted && fuse_th;
@@ -945,9 +963,10 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
         // L == 0: dwt / idwt are copies (transforms_filter.jl:36-38), so the shifted signal itself is thresholded
         T *const coef = (L == 0) ? Z : XT;
         if (thresholded_l1) {
-            const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
-            hipLaunchKernelGGL((k_threshold_dev_quadrant<T>), dim3((unsigned)((h0 + 255) / 256 > 8 ? 8 : (h0 + 255) / 256), (unsigned)h1, (unsigned)nb),
-                               dim3(256), 0, st, coef, n0, N, h0, th, &sel->result, t_unit, sigma_host);
+            const int64_t h0 = th_c0, h1 = th_c1;
+            if (h0 > 0 && h1 > 0)
+                hipLaunchKernelGGL((k_threshold_dev_quadrant<T>), dim3((unsigned)((h0 + 255) / 256 > 8 ? 8 : (h0 + 255) / 256), (unsigned)h1, (unsigned)nb),
+                                   dim3(256), 0, st, coef, n0, N, h0, th, &sel->result, t_unit, sigma_host);
         } else {
             hipLaunchKernelGGL((k_threshold_dev<T>), dim3(nbk), dim3(EXT_THREADS), 0, st, coef, N * nb, th, &sel->result, t_unit, sigma_host,
                                vec_ok16(coef));

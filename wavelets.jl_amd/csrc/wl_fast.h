@@ -49,7 +49,8 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
 // th >= 0 additionally makes that launch threshold the level-1 DETAIL coefficients as it stores them (threshold!(xt, th, sigma * t),
 // denoising.jl:58; sigma = sigma_host, or *mad_dev / 0.6745 when sigma_host < 0): the caller then thresholds only the
 // approximation quadrant, which the deeper levels fill.
-struct SrcView { int mod; int64_t spin0; int used; int th; double t_unit, sigma_host; const double *mad_dev; };
+struct SrcView { int mod; int64_t spin0; int used; int th; double t_unit, sigma_host; const double *mad_dev;
+                 int64_t corner0, corner1; };      // th >= 0: the low corner [0, corner0) x [0, corner1) of every plane is what the fused thresholds left
 extern thread_local SrcView tl_srcview;
 
 // LDS-exchange streaming kernel (wl_fwd2d.hip): one (nlev = 1) or two (nlev = 2) fused forward 2-D levels, Float32,

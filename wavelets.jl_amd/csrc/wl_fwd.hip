@@ -1219,7 +1219,7 @@ static hipError_t launch_fwd2d_multi(hipStream_t st, const Taps<T> &taps, const 
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-thread_local SrcView tl_srcview = {0, 0, 0, -1, 0.0, 0.0, nullptr};
+thread_local SrcView tl_srcview = {0, 0, 0, -1, 0.0, 0.0, nullptr, 0, 0};
 
 template <typename T>
 int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t st, const BoxSpec &b,
@@ -1263,10 +1263,12 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 (cur_st.s[1] % VEC) == 0 && (cur_st.s[2] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&
                 (b.full.s[2] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
                 const bool view = (l == 1 && tl_srcview.mod > 0);      // level 1 of a translation-invariant batch: virtual shifted planes
+                // ... whose launches also threshold the coefficients they store (every level that runs here, once level 1 did)
+                const bool thr = tl_srcview.th >= 0 && (view || (l > 1 && tl_srcview.used != 0 && tl_srcview.corner0 == n[0] && tl_srcview.corner1 == n[1]));
                 WL_TRY(fwd2d_lds_launch(st, taps, 1, l == 1, cur, cur_st.s[1], y, b.full.s[1], last ? (T *)nullptr : llbuf, hn[0],
                                         n[0], n[1], cu_count, n[2], cur_st.s[2], b.full.s[2], ll_st.s[2], (int)n[2],
-                                        view ? tl_srcview.mod : 0, view ? tl_srcview.spin0 : 0,
-                                        (view && tl_srcview.th >= 0) ? &tl_srcview : nullptr));
+                                        view ? tl_srcview.mod : 0, view ? tl_srcview.spin0 : 0, thr ? &tl_srcview : nullptr));
+                if (thr) { tl_srcview.corner0 = last ? 0 : hn[0]; tl_srcview.corner1 = last ? 0 : hn[1]; }
                 if (view) tl_srcview.used = 1;
                 if (!dominant) dominant = "k_fwd2d_lds";
                 cur = llbuf; cur_st = ll_st; pp ^= 1;

@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
                 P[q].y = (__builtin_fabsf(P[q].y) <= tf) ? 0.f : P[q].y;
                 Q[q].x = (__builtin_fabsf(Q[q].x) <= tf) ? 0.f : Q[q].x;
                 Q[q].y = (__builtin_fabsf(Q[q].y) <= tf) ? 0.f : Q[q].y;
+                if (!to_ll) P[q].x = (__builtin_fabsf(P[q].x) <= tf) ? 0.f : P[q].x;     // (last level: the approximation is final too)
             }
         }
         const int64_t k = kbase + t;
@@ -289,7 +290,8 @@ static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, bool lvl
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     const int nthreads = 64 * sh.nw;
     const size_t shmem = (size_t)2 * (4 * nthreads + 16) * 8;
-    if (thresh) hipLaunchKernelGGL((k_fwd2d_lds<F, 1, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
+    if (thresh && lvl1) hipLaunchKernelGGL((k_fwd2d_lds<F, 1, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
+    else if (thresh) hipLaunchKernelGGL((k_fwd2d_lds<F, 0, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
     else if (lvl1) hipLaunchKernelGGL((k_fwd2d_lds<F, 1>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
     else hipLaunchKernelGGL((k_fwd2d_lds<F, 0>), dim3(nwg, (unsigned)nbatch), dim3(nthreads), shmem, st, a);
     return hipGetLastError();

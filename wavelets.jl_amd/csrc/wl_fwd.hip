@@ -532,6 +532,95 @@ struct Multi1DArgs {
     TapsF<T, F> tp;
 };
 
+// the NL levels of one staged tile, LDS -> LDS (bufA holds the tile + halo); ends with a barrier after the last level
+template <typename T, int F>
+__device__ __forceinline__ void multi1d_levels(const Multi1DArgs<T, F> &a, const int (&H)[8], const int64_t own0, const int own_len,
+                                               T *bufA, T *bufB, T *y)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const int tid = threadIdx.x;
+    const int64_t n = a.n;
+    const int NL = a.NL;
+    T *Ain = bufA, *Aout = bufB;
+    // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs (a detail term multiplies by the negated tap)
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
+    // (Tried in round 3 and dropped: ONE buffer, each level writing its approximation over the input it has consumed after an
+    //  extra barrier -- 17 KiB of LDS, eight resident workgroups instead of six: 8192 x 2^16 1107 us against 997.)
+    // A thread owns PPT = 16 / sizeof(T) consecutive pairs: one 16-byte window row per ds_read_b128, one 16-byte store per
+    // output stream.  (Round 2 gave a thread two pairs: Float32 details left in 8-byte stores, half the width, and the 2 F
+    // window values read for two pairs are enough for four.)
+    constexpr int PPT = VEC;
+    constexpr int NWIN = ((2 * PPT + 2 * F - 4) + VEC - 1) / VEC * VEC;
+    const int lane = tid & 63;
+    for (int t = 1; t <= NL; ++t) {
+        const int ownt = own_len >> t;
+        const int Lout = ownt + 2 * H[t];
+        const int64_t k0 = own0 >> t;                 // global index of the first owned pair
+        T *dd = y + (n >> t);
+        const bool lastlev = (t == NL);
+        T *sg = a.sdst + (int64_t)blockIdx.y * a.s_ls;
+        // global position of local pair i is k0 + i - H[t]; k0 is a multiple of PPT (tiles of >= 4096 bytes), so a thread's
+        // group starts PPT - mis pairs before an aligned 16-byte group, mis = H[t] mod PPT (0, or 2 for Float32)
+        const int mis = H[t] & (PPT - 1);
+        const bool quads = (ownt % PPT) == 0 && (k0 % PPT) == 0;
+        // wave-uniform trip count: the lane exchange below needs the neighbour lane inside the loop
+        for (int i0 = PPT * (tid - lane); i0 < Lout; i0 += PPT * 256) {
+            const int i = i0 + PPT * lane;
+            T xv[NWIN];
+            vload16<T, NWIN>(Ain + 2 * i, xv);        // window of pairs i .. i+PPT-1 (2i is a multiple of 2 PPT)
+            T so[PPT], dO[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                T sv = a.tp.h[0] * xv[2 * q + F - 2];
+#pragma unroll
+                for (int m = 1; m < F; ++m) sv = sv + a.tp.h[m] * xv[2 * q + F - 2 + m];
+                T dv = gq(F - 1) * xv[2 * q];
+#pragma unroll
+                for (int m = F - 2; m >= 0; --m) dv = dv + gq(m) * xv[2 * q + F - 1 - m];
+                so[q] = sv;
+                dO[q] = dv;
+            }
+            if (!lastlev && i < Lout) vstore16<T, PPT>(Aout + i, so);      // (the tail of the last group lands in the padding)
+            const int io = i - H[t];                  // pair i + q is owned iff 0 <= io + q < ownt
+            if (quads && mis == 0) {
+                if (io >= 0 && io + PPT <= ownt) {
+                    vstore16<T, PPT>(dd + k0 + io, dO);
+                    if (lastlev) vstore16<T, PPT>(sg + k0 + io, so);
+                }
+            } else if (quads && PPT == 4 && mis == 2) {
+                // pairs io+2, io+3 open an aligned group that the next lane's first two pairs complete
+                constexpr int Q2 = (PPT == 4) ? 2 : 0, Q3 = (PPT == 4) ? 3 : 1;      // (Float32 only; keeps the Float64 instance well-formed)
+                T q4[4] = {dO[Q2], dO[Q3], from_next(dO[0]), from_next(dO[1])};
+                T s4[4] = {so[Q2], so[Q3], from_next(so[0]), from_next(so[1])};
+                const int ia = io + 2;
+                if (lane != 63) {
+                    if (ia >= 0 && ia + 4 <= ownt) {
+                        vstore16<T, 4>(dd + k0 + ia, q4);
+                        if (lastlev) vstore16<T, 4>(sg + k0 + ia, s4);
+                    }
+                } else if (ia >= 0 && ia + 2 <= ownt) {   // (the completing lane belongs to another wave: two 8-byte halves)
+                    vstore<T, 2>(dd + k0 + ia, reinterpret_cast<const T(&)[2]>(q4[0]));
+                    if (lastlev) vstore<T, 2>(sg + k0 + ia, reinterpret_cast<const T(&)[2]>(s4[0]));
+                }
+                if (lane == 0 && io >= 0 && io + 2 <= ownt) {
+                    vstore<T, 2>(dd + k0 + io, reinterpret_cast<const T(&)[2]>(dO[0]));
+                    if (lastlev) vstore<T, 2>(sg + k0 + io, reinterpret_cast<const T(&)[2]>(so[0]));
+                }
+            } else {
+                // short / oddly placed tiles: element by element
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+                    if (io + q >= 0 && io + q < ownt && i + q < Lout) {
+                        dd[k0 + io + q] = dO[q];
+                        if (lastlev) sg[k0 + io + q] = so[q];
+                    }
+            }
+        }
+        lds_barrier();
+        T *tmp = Ain; Ain = Aout; Aout = tmp;
+    }
+}
+
 template <typename T, int F, int LVL1>
 __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
 {
@@ -593,84 +682,13 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
         }
     }
     lds_barrier_vm();
-    T *Ain = bufA, *Aout = bufB;
-    // (Tried in round 3 and dropped: ONE buffer, each level writing its approximation over the input it has consumed after an
-    //  extra barrier -- 17 KiB of LDS, eight resident workgroups instead of six: 8192 x 2^16 1107 us against 997.)
-    // A thread owns PPT = 16 / sizeof(T) consecutive pairs: one 16-byte window row per ds_read_b128, one 16-byte store per
-    // output stream.  (Round 2 gave a thread two pairs: Float32 details left in 8-byte stores, half the width, and the 2 F
-    // window values read for two pairs are enough for four.)
-    constexpr int PPT = VEC;
-    constexpr int NWIN = ((2 * PPT + 2 * F - 4) + VEC - 1) / VEC * VEC;
-    const int lane = tid & 63;
-    for (int t = 1; t <= NL; ++t) {
-        const int ownt = own_len >> t;
-        const int Lout = ownt + 2 * H[t];
-        const int64_t k0 = own0 >> t;                 // global index of the first owned pair
-        T *dd = y + (n >> t);
-        const bool lastlev = (t == NL);
-        T *sg = a.sdst + (int64_t)blockIdx.y * a.s_ls;
-        // global position of local pair i is k0 + i - H[t]; k0 is a multiple of PPT (tiles of >= 4096 bytes), so a thread's
-        // group starts PPT - mis pairs before an aligned 16-byte group, mis = H[t] mod PPT (0, or 2 for Float32)
-        const int mis = H[t] & (PPT - 1);
-        const bool quads = (ownt % PPT) == 0 && (k0 % PPT) == 0;
-        // wave-uniform trip count: the lane exchange below needs the neighbour lane inside the loop
-        for (int i0 = PPT * (tid - lane); i0 < Lout; i0 += PPT * 256) {
-            const int i = i0 + PPT * lane;
-            T xv[NWIN];
-            vload16<T, NWIN>(Ain + 2 * i, xv);        // window of pairs i .. i+PPT-1 (2i is a multiple of 2 PPT)
-            T so[PPT], dO[PPT];
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                T sv = a.tp.h[0] * xv[2 * q + F - 2];
-#pragma unroll
-                for (int m = 1; m < F; ++m) sv = sv + a.tp.h[m] * xv[2 * q + F - 2 + m];
-                T dv = a.tp.g[F - 1] * xv[2 * q];
-#pragma unroll
-                for (int m = F - 2; m >= 0; --m) dv = dv + a.tp.g[m] * xv[2 * q + F - 1 - m];
-                so[q] = sv;
-                dO[q] = dv;
-            }
-            if (!lastlev && i < Lout) vstore16<T, PPT>(Aout + i, so);      // (the tail of the last group lands in the padding)
-            const int io = i - H[t];                  // pair i + q is owned iff 0 <= io + q < ownt
-            if (quads && mis == 0) {
-                if (io >= 0 && io + PPT <= ownt) {
-                    vstore16<T, PPT>(dd + k0 + io, dO);
-                    if (lastlev) vstore16<T, PPT>(sg + k0 + io, so);
-                }
-            } else if (quads && PPT == 4 && mis == 2) {
-                // pairs io+2, io+3 open an aligned group that the next lane's first two pairs complete
-                constexpr int Q2 = (PPT == 4) ? 2 : 0, Q3 = (PPT == 4) ? 3 : 1;      // (Float32 only; keeps the Float64 instance well-formed)
-                T q4[4] = {dO[Q2], dO[Q3], from_next(dO[0]), from_next(dO[1])};
-                T s4[4] = {so[Q2], so[Q3], from_next(so[0]), from_next(so[1])};
-                const int ia = io + 2;
-                if (lane != 63) {
-                    if (ia >= 0 && ia + 4 <= ownt) {
-                        vstore16<T, 4>(dd + k0 + ia, q4);
-                        if (lastlev) vstore16<T, 4>(sg + k0 + ia, s4);
-                    }
-                } else if (ia >= 0 && ia + 2 <= ownt) {   // (the completing lane belongs to another wave: two 8-byte halves)
-                    vstore<T, 2>(dd + k0 + ia, reinterpret_cast<const T(&)[2]>(q4[0]));
-                    if (lastlev) vstore<T, 2>(sg + k0 + ia, reinterpret_cast<const T(&)[2]>(s4[0]));
-                }
-                if (lane == 0 && io >= 0 && io + 2 <= ownt) {
-                    vstore<T, 2>(dd + k0 + io, reinterpret_cast<const T(&)[2]>(dO[0]));
-                    if (lastlev) vstore<T, 2>(sg + k0 + io, reinterpret_cast<const T(&)[2]>(so[0]));
-                }
-            } else {
-                // short / oddly placed tiles: element by element
-#pragma unroll
-                for (int q = 0; q < PPT; ++q)
-                    if (io + q >= 0 && io + q < ownt && i + q < Lout) {
-                        dd[k0 + io + q] = dO[q];
-                        if (lastlev) sg[k0 + io + q] = so[q];
-                    }
-            }
-        }
-        lds_barrier();
-        T *tmp = Ain; Ain = Aout; Aout = tmp;
-    }
+    multi1d_levels<T, F>(a, H, own0, own_len, bufA, bufB, y);
 }
 
+// (Tried in round 3 and dropped: a persistent variant that walks 2-8 consecutive tiles of a line and requests tile k+1 -- five
+//  16-byte loads per thread, held in registers -- right after tile k has reached LDS.  Bit-identical, but 8192 x 2^16 db4 went
+//  from 1000 us to 1137-1175 us, db2 859 -> 917-959, Float64 937 -> 1005-1025: the 20 extra VGPRs cost one to three resident
+//  workgroups per CU, and six to eight independent workgroups already overlap each other's staging latency.)
 
 // ==========================================================================================
 // 2-D multi-level tile kernel for the small, cache-resident levels: NL (1 or 2) consecutive 2-D

@@ -222,6 +222,7 @@ def test_fused_level_pair_kernel(gpu, W, oracle):
     W.set_option("WL_LDS2D", 0)          # (the LDS-exchange kernel, tested below, takes these shapes by default)
     W.set_option("WL_M2D_MAX", 128)      # (... and the tile kernels everything up to 2048 x 2048)
     W.set_option("WL_TILE", 0)
+    W.set_option("WL_TILEB", 0)
     for shape, Ls in (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (4, 9)), ((528, 96), (2, 4)),
                       ((4096, 64), (2,))):
         x = rng_array(shape, np.float32, sum(shape))
@@ -247,6 +248,7 @@ def test_lds_exchange_2d_kernel(gpu, W, oracle, mode):
     W.set_option("WL_FUSE2", 0)
     W.set_option("WL_M2D_MAX", 128)      # (the tile kernels would otherwise take everything up to 2048 x 2048)
     W.set_option("WL_TILE", 0)
+    W.set_option("WL_TILEB", 0)
     shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4, 9)), ((528, 96), (1, 2, 4)), ((4096, 64), (1, 2)),
               ((256, 256), (1, 2)), ((1000, 64), (1, 2, 3)), ((272, 64), (1,)), ((768, 1024), (2, 3)), ((1280, 128), (1, 2)))
     for shape, Ls in shapes:
@@ -274,6 +276,7 @@ def test_fused_pair_2d_kernel(gpu, W, oracle, wmain, tj):
     W.set_option("WL_PAIR_WG_PER_CU", 0)  # (keep the requested chunk length)
     W.set_option("WL_M2D_MAX", 128)
     W.set_option("WL_TILE", 0)
+    W.set_option("WL_TILEB", 0)
     shapes = (((512, 512), (2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (2, 4, 9)), ((4096, 64), (2,)), ((1536, 160), (2, 3)),
               ((1024, 96), (2,)), ((512, 1056), (2, 4)))
     for shape, Ls in shapes:
@@ -344,6 +347,7 @@ def test_float64_lds_exchange_and_pair_kernels(gpu, W, oracle, wmain, tj):
     W.set_option("WL_WAVES_MIN", 0)
     W.set_option("WL_M2D_MAX", 128)
     W.set_option("WL_TILE", 0)
+    W.set_option("WL_TILEB", 0)
     shapes = (((512, 512), (1, 2, 3, 9)), ((1024, 2048), (2, 5)), ((2048, 512), (1, 4)), ((256, 160), (1, 2)), ((768, 96), (2, 3)),
               ((1280, 1056), (1, 2)))
     for pairmin in (0, 1 << 62):
@@ -752,6 +756,44 @@ def test_lifting_cubes_fast_vs_generic(gpu, W, oracle):
             assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (n, sname, L, "inv")
 
 
+def test_lifting_2d_tile_kernel(gpu, W, oracle):
+    """k_lift2d_tile_fwd / k_lift2d_tile_inv (wl_lift_tile.hip): one 2-D lifting level of a block of 128 ... 2048 rows (a multiple of
+    64) as 64 x 64 tiles with the scheme's dependency cone recomputed per segment -- every scheme shape, both element types, sizes
+    with 2 ... 64 tiles per side (and 4096 with the size limit raised), forward and inverse, bit for bit against the oracle; the
+    level-1 call in place must not take it (it reads what it overwrites)."""
+    for n, Ls, tmax in ((128, (1, 2), 0), (192, (1,), 0), (256, (2, 8), 0), (320, (2,), 0), (1024, (3,), 0), (2048, (1, 11), 0), (4096, (2,), 4096)):
+        for dtype in (np.float32, np.float64):
+            if n >= 2048 and dtype == np.float64:
+                continue
+            x = rng_array((n, n), dtype, n + 5)
+            for sname in ("cdf97", "db2", "haar"):
+                if n == 4096 and sname != "cdf97":
+                    continue
+                sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+                for L in Ls:
+                    if tmax:
+                        W.set_option("WL_LIFT_TILE_MAX", tmax)
+                    ye = oracle.dwt_lifting(x, sch, L)
+                    y = host(W, W.dwt(dev(W, x), sch, L))
+                    if n <= 2048 and n != 320:        # (320 -> 160: the second level is not a multiple of 64 and marches)
+                        assert W.last_kernel() == "k_lift2d_tile", W.last_kernel()
+                    assert np.array_equal(y, ye), (n, sname, L, dtype, np.abs(y - ye).max())
+                    xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                    xr = host(W, W.idwt(dev(W, ye), sch, L))
+                    if n <= 2048 and n != 320:
+                        assert W.last_kernel() == "k_lift2d_tile", W.last_kernel()
+                    assert np.array_equal(xr, xe), (n, sname, L, dtype, "inv")
+                    if n == 256:
+                        t = dev(W, x)
+                        W.dwt_(t, sch, L)
+                        assert np.array_equal(host(W, t), ye), (n, sname, L, dtype, "fwd in place")
+                        t = dev(W, ye)
+                        W.idwt_(t, sch, L)
+                        assert np.array_equal(host(W, t), xe), (n, sname, L, dtype, "inv in place")
+                    if tmax:
+                        W.set_option("WL_LIFT_TILE_MAX", 2048)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tp", ["64", "24", ""])
 def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, tp, fused):
@@ -762,6 +804,7 @@ def test_lifting_2d_axis_stream_kernel(gpu, W, oracle, tp, fused):
         W.set_option("WL_LIFT_TP", int(tp))
     if not fused:
         W.set_option("WL_NO_LIFT2D_FUSED", int(1))
+    W.set_option("WL_LIFT_TILE", 0)          # (blocks of <= 2048 rows take the tile kernel by default: test_lifting_2d_tile_kernel)
     expect = "k_lift2d" if fused else "k_lift_axis_stream"
     for n, Ls in ((512, (1, 3)), (1024, (2,)), (576, (1,)), (2048, (1, 11))):
         for dtype in (np.float32, np.float64):

@@ -17,24 +17,10 @@
 // x += (c1*a + c2*b [+ c3*c]) (lift_inbounds!, transforms_lifting.jl:455-483), a wrapped one as
 // x += c1*a; x += c2*b; ... (lift_perboundary!, :437-451); no FMA contraction.
 #include "wl_fast.h"
+#include "wl_lift_shapes.h"
 
 
 namespace wl {
-
-// ---- scheme shapes known at compile time (coefficients stay run-time data) -----------------------
-// direction-adjusted order (as produced by make_scheme): step i = {is_update, nc, shift}
-struct StepShape { int upd, nc, sh; };
-// the shape-specialised kernels never have more steps than this; their argument blocks carry only these coefficients
-// (keeping kernel arguments small matters: launches with > 256 bytes of arguments were seen to stall the enqueue path)
-constexpr int LIFT_FAST_STEPS = 4;
-template <int ID> struct Shape;
-// cdf9/7 forward and inverse have the same shape sequence read in opposite order
-template <> struct Shape<0> { static constexpr int NS = 4; static constexpr StepShape S[4] = {{1, 2, 0}, {0, 2, 1}, {1, 2, 0}, {0, 2, 1}}; };   // cdf9/7 fw
-template <> struct Shape<1> { static constexpr int NS = 4; static constexpr StepShape S[4] = {{0, 2, 1}, {1, 2, 0}, {0, 2, 1}, {1, 2, 0}}; };   // cdf9/7 inv
-template <> struct Shape<2> { static constexpr int NS = 3; static constexpr StepShape S[3] = {{0, 1, 0}, {1, 2, 1}, {0, 1, -1}}; };             // db2 fw
-template <> struct Shape<3> { static constexpr int NS = 3; static constexpr StepShape S[3] = {{0, 1, -1}, {1, 2, 1}, {0, 1, 0}}; };             // db2 inv
-template <> struct Shape<4> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{0, 1, 0}, {1, 1, 0}}; };                          // haar/db1 fw
-template <> struct Shape<5> { static constexpr int NS = 2; static constexpr StepShape S[2] = {{1, 1, 0}, {0, 1, 0}}; };                          // haar/db1 inv
 
 template <int ID>
 static bool shape_matches(int nsteps, const int *upd, const int *nc, const int *sh)
@@ -252,7 +238,9 @@ __device__ __forceinline__ T lane_operand(const T (&op)[PPL], int off)
     return v;
 }
 
-template <typename T, int ID, int PPL>
+// FAST: the caller has established that no operand of any lane wraps around the ends of the line (every update takes the
+// in-bounds form): the boundary form and the 64-bit position tests disappear
+template <typename T, int ID, int PPL, bool FAST = false>
 __device__ __forceinline__ void lift_steps_lane(T (&s)[PPL], T (&d)[PPL], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF],
                                                 int64_t kfirst, int64_t half)
 {
@@ -276,10 +264,14 @@ __device__ __forceinline__ void lift_steps_lane(T (&s)[PPL], T (&d)[PPL], const 
             if (nc > 1) acc = acc + c[st][1] * o[1];
             if (nc > 2) acc = acc + c[st][2] * o[2];
             const T xin = x + acc;
-            T xb = x + c[st][0] * o[0];
-            if (nc > 1) xb = xb + c[st][1] * o[1];
-            if (nc > 2) xb = xb + c[st][2] * o[2];
-            res[jj] = inb ? xin : xb;
+            if constexpr (FAST) {
+                res[jj] = xin;
+            } else {
+                T xb = x + c[st][0] * o[0];
+                if (nc > 1) xb = xb + c[st][1] * o[1];
+                if (nc > 2) xb = xb + c[st][2] * o[2];
+                res[jj] = inb ? xin : xb;
+            }
         }
 #pragma unroll
         for (int jj = 0; jj < PPL; ++jj) { if (upd) d[jj] = res[jj]; else s[jj] = res[jj]; }
@@ -1145,23 +1137,6 @@ static hipError_t launch_tail_lift2d_reg(int id, hipStream_t st, const LiftSchem
 // tail a lane holds a whole tile row (then a whole tile column) in registers and runs split -> steps -> normalize (or the
 // inverse order) as straight-line code -- only the choice between the reference's in-bounds and boundary summation forms
 // depends on the global position and is a wave-uniform select.  Tile edges inside the halo are garbage and never stored.
-template <int ID>
-struct LiftReach {
-    static constexpr int left()
-    {
-        int v = 0;
-        for (int k = 0; k < Shape<ID>::NS; ++k) { const int a = Shape<ID>::S[k].sh; if (a > 0) v += a; }
-        return v;
-    }
-    static constexpr int right()
-    {
-        int v = 0;
-        for (int k = 0; k < Shape<ID>::NS; ++k) { const int b = Shape<ID>::S[k].nc - 1 - Shape<ID>::S[k].sh; if (b > 0) v += b; }
-        return v;
-    }
-    static constexpr int HP = left() > right() ? left() : right();
-};
-
 template <typename T>
 struct LiftGTileArgs {
     const T *src; int64_t lds;      // fw: block n x n;  inv: coefficient array
@@ -2094,8 +2069,8 @@ struct Lift2DArgs {
 
 // R: ring slots = steps per unrolled iteration; loads run PF = R - DL + AMIN - 1 column pairs ahead (R = 8 everywhere: 16 was
 // measured on the small, latency-bound levels and lost).
-template <typename T, int ID, int R = 8>
-__global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
+template <typename T, int ID, int R, bool FAST>
+__device__ __forceinline__ void lift2d_fwd_body(const Lift2DArgs<T> &a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
@@ -2161,10 +2136,13 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
                 if (nc > 1) acc = acc + a.c[k][1] * o[1];
                 if (nc > 2) acc = acc + a.c[k][2] * o[2];
                 const T xin = x + acc;
-                T xb = x + a.c[k][0] * o[0];
-                if (nc > 1) xb = xb + a.c[k][1] * o[1];
-                if (nc > 2) xb = xb + a.c[k][2] * o[2];
-                const T res = inb ? xin : xb;
+                T res = xin;
+                if constexpr (!FAST) {
+                    T xb = x + a.c[k][0] * o[0];
+                    if (nc > 1) xb = xb + a.c[k][1] * o[1];
+                    if (nc > 2) xb = xb + a.c[k][2] * o[2];
+                    res = inb ? xin : xb;
+                }
                 if (upd) rd[slot][q] = res; else rs[slot][q] = res;
             }
         }
@@ -2178,8 +2156,8 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
                 s1[j] = rs[slot][2 * j] * a.norm1; d1[j] = rs[slot][2 * j + 1] * a.norm1;
                 s2[j] = rd[slot][2 * j] * a.norm2; d2[j] = rd[slot][2 * j + 1] * a.norm2;
             }
-            lift_steps_lane<T, ID, 2>(s1, d1, a.c, kfirst, h0);
-            lift_steps_lane<T, ID, 2>(s2, d2, a.c, kfirst, h0);
+            lift_steps_lane<T, ID, 2, FAST>(s1, d1, a.c, kfirst, h0);
+            lift_steps_lane<T, ID, 2, FAST>(s2, d2, a.c, kfirst, h0);
             // lane pairs (2i, 2i+1) own rows k0..k0+1 and k0+2..k0+3 of the same four sub-band columns: they swap
             // halves so that the even lane stores 4 rows of LL and HL (left column), the odd lane 4 rows of LH and HH
             const bool odd = (lane & 1) != 0;
@@ -2215,11 +2193,28 @@ __global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
     }
 }
 
+// interior workgroups (strip and chunk a few pairs away from the ends of the block in both dimensions: all but the border ones on the
+// big levels) run the body without the boundary summation form -- this kernel is bound by VALU issue, not by HBM
+template <typename T>
+__device__ __forceinline__ bool lift2d_interior(const Lift2DArgs<T> &a)
+{
+    constexpr int VR = (64 - 2 * kLift2dML) * 4;
+    const int strip = (int)(blockIdx.x % (unsigned)a.nstrips), chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int64_t gi0 = (int64_t)strip * VR - kLift2dML * 4, p0 = (int64_t)chunk * a.TP;
+    return gi0 >= 16 && gi0 + 256 + 16 <= a.n0 && p0 >= 32 && p0 + a.TP + 32 <= (a.n1 >> 1);
+}
+template <typename T, int ID, int R = 8>
+__global__ void __launch_bounds__(64) k_lift2d_fwd(Lift2DArgs<T> a)
+{
+    if (lift2d_interior<T>(a)) lift2d_fwd_body<T, ID, R, true>(a);
+    else lift2d_fwd_body<T, ID, R, false>(a);
+}
+
 // The inverse: per step the raw coefficient column pair (left-half column p: approximation rows + detail rows, and
 // right-half column p) is loaded four steps ahead, both columns are reconstructed along dim 1 across the lanes
 // (normalize -> steps -> merge), and the results enter the dim-2 inverse cascade as its (s, d) pair.
-template <typename T, int ID, int R = 8>
-__global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
+template <typename T, int ID, int R, bool FAST>
+__device__ __forceinline__ void lift2d_inv_body(const Lift2DArgs<T> &a)
 {
     typedef Shape<ID> SH;
     typedef Cascade<ID> CS;
@@ -2282,8 +2277,8 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
                 s1[j] = a.norm1 * qLs[u][j]; d1[j] = a.norm2 * qLd[u][j];
                 s2[j] = a.norm1 * qRs[u][j]; d2[j] = a.norm2 * qRd[u][j];
             }
-            lift_steps_lane<T, ID, 2>(s1, d1, a.c, kw, h0);
-            lift_steps_lane<T, ID, 2>(s2, d2, a.c, kw, h0);
+            lift_steps_lane<T, ID, 2, FAST>(s1, d1, a.c, kw, h0);
+            lift_steps_lane<T, ID, 2, FAST>(s2, d2, a.c, kw, h0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 rs[u][2 * j] = a.norm1 * s1[j]; rs[u][2 * j + 1] = a.norm1 * d1[j];          // merge!, then normalize! of dim 2
@@ -2308,10 +2303,13 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
                 if (nc > 1) acc = acc + a.c[k][1] * o[1];
                 if (nc > 2) acc = acc + a.c[k][2] * o[2];
                 const T xin = x + acc;
-                T xb = x + a.c[k][0] * o[0];
-                if (nc > 1) xb = xb + a.c[k][1] * o[1];
-                if (nc > 2) xb = xb + a.c[k][2] * o[2];
-                const T res = inb ? xin : xb;
+                T res = xin;
+                if constexpr (!FAST) {
+                    T xb = x + a.c[k][0] * o[0];
+                    if (nc > 1) xb = xb + a.c[k][1] * o[1];
+                    if (nc > 2) xb = xb + a.c[k][2] * o[2];
+                    res = inb ? xin : xb;
+                }
                 if (upd) rd[slot][q] = res; else rs[slot][q] = res;
             }
         }
@@ -2327,6 +2325,13 @@ __global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
 #pragma unroll
         for (int u = 0; u < R; ++u) step(t0 + u, u);
     }
+}
+
+template <typename T, int ID, int R = 8>
+__global__ void __launch_bounds__(64) k_lift2d_inv(Lift2DArgs<T> a)
+{
+    if (lift2d_interior<T>(a)) lift2d_inv_body<T, ID, R, true>(a);
+    else lift2d_inv_body<T, ID, R, false>(a);
 }
 
 template <typename T, int ID>
@@ -2578,7 +2583,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     Strides3 full = {{1, ldy, ldy * n0}};
     auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
     auto fused_ok = [](int64_t n) { return n >= 128 && (n % 8) == 0; };     // k_lift2d_*: a lane's 4 rows wrap at most once
-    bool any_fast = false, fused = false, gtile = false;
+    bool any_fast = false, fused = false, gtile = false, tiled = false;
 
     if (fw) {
         const T *cur = x;
@@ -2597,6 +2602,14 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                     WL_E((launch_tail_lift2d<T, 1>(st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
                 any_fast = true;
                 break;
+            }
+            // cache-resident levels: 64 x 64 tiles, one launch per level without the marching kernels' latency chain
+            if (aligned && l_env("WL_LIFT_TILE", 1) != 0 && n <= l_env("WL_LIFT_TILE_MAX", 2048) && lift2d_tile_ok(id, n) && (id == 0 || id == 2 || id == 4) &&
+                (cur_ls % VEC) == 0 && al16(cur) && al16(llbuf) && cur != y) {
+                WL_E((lift2d_tile_launch<T>(id, 1, st, sc, cur, cur_ls, y, ldy, last ? (T *)nullptr : llbuf, h, n)));
+                any_fast = true; tiled = true;
+                cur = llbuf; cur_ls = h; pp ^= 1;
+                continue;
             }
             if (aligned && fused_ok(n) && n > l_env("WL_LIFT_GTILE_MAX", 0) && (id == 0 || id == 2 || id == 4) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (cur_ls % VEC) == 0 &&
                 al16(cur) && al16(llbuf) && cur != y) {      // (in place, level 1 reads y while writing it: two passes via T0)
@@ -2676,6 +2689,13 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
+            if (aligned && l_env("WL_LIFT_TILE", 1) != 0 && n <= l_env("WL_LIFT_TILE_MAX", 2048) && lift2d_tile_ok(id, n) && (id == 1 || id == 3 || id == 5) &&
+                (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {
+                WL_E((lift2d_tile_launch<T>(id, 0, st, sc, x, ldy, out, ldo, const_cast<T *>(llsrc), ll_ls, n)));
+                any_fast = true; tiled = true;
+                llsrc = out; ll_ls = ldo; pp ^= 1;
+                continue;
+            }
             if (aligned && fused_ok(n) && n > l_env("WL_LIFT_GTILE_MAX", 0) && (id == 1 || id == 3 || id == 5) && l_env("WL_NO_LIFT2D_FUSED", 0) == 0 && (ldo % VEC) == 0 && al16(out) &&
                 (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {   // (in place, level 1 writes y while reading it)
                 Lift2DArgs<T> q2;
@@ -2728,7 +2748,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     }
     *handled = 1;
     if (kernel_name)
-        *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : (gtile ? "k_lift2d_gtile" : "k_lift_axis_stream+lines"))
+        *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : (tiled ? "k_lift2d_tile" : (gtile ? "k_lift2d_gtile" : "k_lift_axis_stream+lines")))
                                 : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
     return WL_OK;
 }

@@ -1,0 +1,317 @@
+// wl_lift_tile.hip -- one 2-D lifting level of a cache-resident square block (128 ... 2048 rows) per launch, forward and inverse.
+//
+// The marching level kernels of wl_lift.hip (k_lift2d_fwd / k_lift2d_inv) need >= 16 column steps of a load -> cascade -> DPP ->
+// store chain whatever the block size: 12-14 us per level from 1024^2 down to 128^2, four such levels per 8192^2 transform.
+// Here a 256-thread workgroup owns a 64 x 64 piece of the block: the piece and the dependency cone of the scheme around it
+// (HS = 4 samples on every side for cdf9/7 and db2, none for haar) are staged to LDS with every load in flight at once (periodic
+// wrap resolved while staging), then each pass gives a thread a short open line segment -- 16 or 8 owned (s, d) pairs plus the
+// cone -- which it runs through split -> steps -> normalize (or normalize -> steps -> merge) in registers as straight-line code;
+// cone pairs are recomputed by the neighbouring segment instead of exchanged, so a pass costs two barriers and no step does.
+// Rounding follows the reference: a pair whose operands do not wrap around the ends of the WHOLE line takes the in-bounds form
+// x += (c1*a + c2*b), the others x += c1*a; x += c2*b (transforms_lifting.jl:437-483); which one depends on the global pair
+// index only (a per-lane select, both forms share their products).
+#include "wl_fast.h"
+#include "wl_lift_shapes.h"
+#include "wl_dev.h"
+
+namespace wl {
+
+namespace {
+
+template <typename T>
+struct LiftTileArgs {
+    const T *src; int64_t lds;      // fw: block n x n                  inv: coefficient array
+    T *y; int64_t ldy;              // fw: coefficient array            inv: result block n x n
+    T *ll; int64_t ldl;             // fw: approximation destination or nullptr (-> y);  inv: approximation source or nullptr (-> src)
+    int n;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <int ID>
+struct TileGeom {
+    static constexpr int HPE = (LiftReach<ID>::HP + 1) & ~1;      // cone in pairs, rounded to even: 16-byte aligned region rows
+    static constexpr int HS = 2 * HPE;                            // ... in samples
+    static constexpr int OWN = 64, OWNP = 32;                     // owned samples / pairs per dimension
+    static constexpr int REG = OWN + 2 * HS, REGP = OWNP + 2 * HPE;
+    static constexpr int LD = REG + 4;                            // (a multiple of 4, and 16-byte reads at a stride of LD hit distinct banks)
+};
+
+// all steps on an open segment of NP pairs whose first pair has the global (periodic) index kg0 of a line with `half` pairs;
+// pairs closer than the scheme's reach to either end of the segment come out wrong and are never used
+template <typename T, int ID, int NP, bool FAST>
+__device__ __forceinline__ void seg_line_steps_v(T (&s)[NP], T (&d)[NP], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF], const int kg0, const int half)
+{
+    typedef Shape<ID> SH;
+#pragma unroll
+    for (int k = 0; k < SH::NS; ++k) {
+        const int upd = SH::S[k].upd, nc = SH::S[k].nc, sh = SH::S[k].sh;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int j0 = j - sh;
+            if (j0 < 0 || j0 + nc - 1 > NP - 1) continue;
+            int jg = kg0 + j;
+            if (jg >= half) jg -= half;
+            const bool inb = (jg - sh >= 0) && (jg - sh + nc - 1 <= half - 1);
+            const T x = upd ? d[j] : s[j];
+            const T o0 = upd ? s[j0] : d[j0];
+            const T o1 = (nc > 1) ? (upd ? s[(j0 + 1 < NP) ? j0 + 1 : j0] : d[(j0 + 1 < NP) ? j0 + 1 : j0]) : (T)0;
+            const T o2 = (nc > 2) ? (upd ? s[(j0 + 2 < NP) ? j0 + 2 : j0] : d[(j0 + 2 < NP) ? j0 + 2 : j0]) : (T)0;
+            const T m0 = c[k][0] * o0;
+            T acc = m0;
+            T xb = x + m0;
+            if (nc > 1) { const T m1 = c[k][1] * o1; acc = acc + m1; xb = xb + m1; }
+            if (nc > 2) { const T m2 = c[k][2] * o2; acc = acc + m2; xb = xb + m2; }
+            const T xin = x + acc;
+            const T r = FAST ? xin : (inb ? xin : xb);
+            if (upd) d[j] = r; else s[j] = r;
+        }
+    }
+}
+// kg0 is the same for every lane of a wave (the callers map a wave to one segment position): the position tests are scalar work,
+// and a wave whose segment stays clear of the ends of the line skips the boundary form altogether
+template <typename T, int ID, int NP>
+__device__ __forceinline__ void seg_line_steps(T (&s)[NP], T (&d)[NP], const T (&c)[LIFT_FAST_STEPS][WL_MAX_NCOEF], const int kg0_, const int half)
+{
+    const int kg0 = __builtin_amdgcn_readfirstlane(kg0_);
+    if (kg0 >= 4 && kg0 + NP + 4 <= half) seg_line_steps_v<T, ID, NP, true>(s, d, c, kg0, half);
+    else seg_line_steps_v<T, ID, NP, false>(s, d, c, kg0, half);
+}
+
+__device__ __forceinline__ int wrap_into(int v, const int m)
+{
+    while (v < 0) v += m;
+    while (v >= m) v -= m;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward: dim-2 pass (lines along the columns) on every region row, then dim-1 pass on the owned columns, quadrants stored
+// straight from registers
+template <typename T, int ID>
+__global__ void __launch_bounds__(256) k_lift2d_tile_fwd(LiftTileArgs<T> a)
+{
+    typedef TileGeom<ID> G;
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    constexpr int HPE = G::HPE, HS = G::HS, REG = G::REG, LD = G::LD;
+    __shared__ __attribute__((aligned(16))) T P[LD * REG];
+    const int tid = threadIdx.x;
+    const int n = a.n, h = n >> 1;
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    // ---- stage: P[r + c * LD] = x[(64 bx - HS + r) mod n, (64 by - HS + c) mod n], 16-byte chunks along the rows ----
+    {
+        constexpr int CPC = REG / VEC, NCH = CPC * REG, PER = (NCH + 255) / 256;
+        V v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int col = id / CPC, cc = id - col * CPC;
+                const int gi = wrap_into(64 * bx - HS + VEC * cc, n), gj = wrap_into(64 * by - HS + col, n);
+                v[u] = *reinterpret_cast<const V *>(a.src + gi + (int64_t)gj * a.lds);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int col = id / CPC, cc = id - col * CPC;
+                *reinterpret_cast<V *>(P + VEC * cc + col * LD) = v[u];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- dim 2: task = (region row r, half of the owned column pairs); 16 owned pairs + the cone on either side ----
+    {
+        constexpr int SEG = 16, NP = SEG + 2 * HPE;
+        // wave w: segment w & 1 of region rows 64 (w >> 1) ... (one segment position per wave)
+        const int seg = (tid >> 6) & 1, r = ((tid >> 7) << 6) + (tid & 63);
+        const bool active = r < REG;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                s[q] = P[r + (2 * (SEG * seg + q)) * LD];
+                d[q] = P[r + (2 * (SEG * seg + q) + 1) * LD];
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * by - HPE + SEG * seg, h), h);
+        }
+        lds_barrier();                                  // every segment has read its cone before anybody overwrites it
+        if (active) {
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; ++q) {
+                P[r + (2 * (SEG * seg + q)) * LD] = s[q] * a.norm1;
+                P[r + (2 * (SEG * seg + q) + 1) * LD] = d[q] * a.norm2;
+            }
+        }
+        lds_barrier();
+    }
+    // ---- dim 1: task = (owned column, quarter of the owned row pairs); rows are contiguous in LDS ----
+    {
+        constexpr int SEG = 8, NP = SEG + 2 * HPE;
+        const int jc = tid & 63, seg = tid >> 6;
+        const int c = HS + jc;                          // region column: even = scaling column of pair c/2, odd = detail column
+        T v[2 * NP];
+#pragma unroll
+        for (int e = 0; e < 2 * NP / VEC; ++e) {
+            const V t = *reinterpret_cast<const V *>(P + 2 * SEG * seg + VEC * e + c * LD);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[VEC * e + i] = t[i];
+        }
+        T s[NP], d[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { s[q] = v[2 * q]; d[q] = v[2 * q + 1]; }
+        seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * bx - HPE + SEG * seg, h), h);
+        T so[SEG], dO[SEG];
+#pragma unroll
+        for (int q = 0; q < SEG; ++q) { so[q] = s[HPE + q] * a.norm1; dO[q] = d[HPE + q] * a.norm2; }
+        const int gk = 32 * bx + SEG * seg;             // first owned row pair of this task
+        const int gkc = 32 * by + (jc >> 1);            // column pair
+        const bool dcol = (jc & 1) != 0;
+        T *const lo = (!dcol && a.ll) ? (a.ll + gk + (int64_t)gkc * a.ldl) : (a.y + gk + (int64_t)((dcol ? h : 0) + gkc) * a.ldy);
+        T *const hi = a.y + h + gk + (int64_t)((dcol ? h : 0) + gkc) * a.ldy;
+#pragma unroll
+        for (int e = 0; e < SEG / VEC; ++e) {
+            V t, u;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { t[i] = so[VEC * e + i]; u[i] = dO[VEC * e + i]; }
+            *reinterpret_cast<V *>(lo + VEC * e) = t;
+            *reinterpret_cast<V *>(hi + VEC * e) = u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// inverse: the four quadrant pieces staged de-interleaved (scaling rows | detail rows, scaling columns | detail columns), dim-1
+// pass (normalize -> steps -> merge along the rows) on every region column, then dim-2 pass on the owned rows
+template <typename T, int ID>
+__global__ void __launch_bounds__(256) k_lift2d_tile_inv(LiftTileArgs<T> a)
+{
+    typedef TileGeom<ID> G;
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    constexpr int HPE = G::HPE, HS = G::HS, REG = G::REG, REGP = G::REGP, LD = G::LD;
+    __shared__ __attribute__((aligned(16))) T P[LD * REG];
+    const int tid = threadIdx.x;
+    const int n = a.n, h = n >> 1;
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    // ---- stage: column slot cs < REGP: scaling column pair cs, cs >= REGP: detail column pair cs - REGP; rows [0, REGP): scaling
+    //      row pairs, [REGP, REG): detail row pairs.  Chunks of two rows (the cone is an even number of pairs). ----
+    {
+        constexpr int CPH = REGP / 2, NCH = 2 * CPH * REG, PER = (NCH + 255) / 256;
+        V2 v[PER];
+        const T *const lls = a.ll ? a.ll : a.src;
+        const int64_t ldl = a.ll ? a.ldl : a.lds;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int cs = id / (2 * CPH), rem = id - cs * (2 * CPH);
+                const int rdet = (rem >= CPH) ? 1 : 0, cc = rem - rdet * CPH;
+                const int cdet = (cs >= REGP) ? 1 : 0;
+                const int gk = wrap_into(32 * bx - HPE + 2 * cc, h), gc = wrap_into(32 * by - HPE + (cs - cdet * REGP), h);
+                const T *p = (!rdet && !cdet) ? (lls + gk + (int64_t)gc * ldl) : (a.src + (rdet ? h : 0) + gk + (int64_t)((cdet ? h : 0) + gc) * a.lds);
+                v[u] = *reinterpret_cast<const V2 *>(p);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int cs = id / (2 * CPH), rem = id - cs * (2 * CPH);
+                *reinterpret_cast<V2 *>(P + 2 * rem + cs * LD) = v[u];       // (rem counts two-row chunks through scaling then detail rows)
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- dim 1: task = (column slot, half of the owned row pairs) ----
+    {
+        constexpr int SEG = 16, NP = SEG + 2 * HPE;
+        const int seg = (tid >> 6) & 1, cs = ((tid >> 7) << 6) + (tid & 63);      // (one segment position per wave)
+        const bool active = cs < REG;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < NP / VEC; ++e) {
+                const V t = *reinterpret_cast<const V *>(P + SEG * seg + VEC * e + cs * LD);
+                const V u = *reinterpret_cast<const V *>(P + REGP + SEG * seg + VEC * e + cs * LD);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { s[VEC * e + i] = a.norm1 * t[i]; d[VEC * e + i] = a.norm2 * u[i]; }
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * bx - HPE + SEG * seg, h), h);
+        }
+        lds_barrier();
+        if (active) {
+            // merged rows of the owned pairs, interleaved: region row 2 (SEG seg + q), + 1
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; q += VEC / 2) {
+                V t;
+#pragma unroll
+                for (int i = 0; i < VEC / 2; ++i) { t[2 * i] = s[q + i]; t[2 * i + 1] = d[q + i]; }
+                *reinterpret_cast<V *>(P + 2 * (SEG * seg + q) + cs * LD) = t;
+            }
+        }
+        lds_barrier();
+    }
+    // ---- dim 2: task = (owned row, quarter of the owned column pairs) ----
+    {
+        constexpr int SEG = 8, NP = SEG + 2 * HPE;
+        const int ir = tid & 63, seg = tid >> 6;
+        const int r = HS + ir;
+        T s[NP], d[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            s[q] = a.norm1 * P[r + (SEG * seg + q) * LD];
+            d[q] = a.norm2 * P[r + (REGP + SEG * seg + q) * LD];
+        }
+        seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * by - HPE + SEG * seg, h), h);
+        T *const o = a.y + 64 * bx + ir + (int64_t)(2 * (32 * by + SEG * seg)) * a.ldy;
+#pragma unroll
+        for (int q = 0; q < SEG; ++q) {
+            o[(int64_t)(2 * q) * a.ldy] = s[HPE + q];
+            o[(int64_t)(2 * q + 1) * a.ldy] = d[HPE + q];
+        }
+    }
+}
+
+template <typename T, int ID, int FW>
+hipError_t launch_tile_id(hipStream_t st, const LiftTileArgs<T> &a)
+{
+    const unsigned g = (unsigned)(a.n / 64);
+    if (FW) hipLaunchKernelGGL((k_lift2d_tile_fwd<T, ID>), dim3(g, g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_lift2d_tile_inv<T, ID>), dim3(g, g), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool lift2d_tile_ok(int id, int64_t n) { return id >= 0 && id <= 5 && n >= 128 && n <= 16384 && (n % 64) == 0; }
+
+template <typename T>
+hipError_t lift2d_tile_launch(int id, int fw, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
+                              int64_t ldl, int64_t n)
+{
+    LiftTileArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldl = ldl; a.n = (int)n;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    switch (id) {
+    case 0: return fw ? launch_tile_id<T, 0, 1>(st, a) : hipErrorInvalidValue;
+    case 2: return fw ? launch_tile_id<T, 2, 1>(st, a) : hipErrorInvalidValue;
+    case 4: return fw ? launch_tile_id<T, 4, 1>(st, a) : hipErrorInvalidValue;
+    case 1: return fw ? hipErrorInvalidValue : launch_tile_id<T, 1, 0>(st, a);
+    case 3: return fw ? hipErrorInvalidValue : launch_tile_id<T, 3, 0>(st, a);
+    case 5: return fw ? hipErrorInvalidValue : launch_tile_id<T, 5, 0>(st, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template hipError_t lift2d_tile_launch<float>(int, int, hipStream_t, const LiftScheme<float> &, const float *, int64_t, float *, int64_t, float *,
+                                              int64_t, int64_t);
+template hipError_t lift2d_tile_launch<double>(int, int, hipStream_t, const LiftScheme<double> &, const double *, int64_t, double *, int64_t,
+                                               double *, int64_t, int64_t);
+
+}  // namespace wl

@@ -186,6 +186,12 @@ __device__ __forceinline__ void gload16(V &dst, const T *p)
     static_assert(sizeof(V) == 16, "one global_load_dwordx4");
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// one row per lane (the halo wave of the fused pair kernel)
+template <typename T>
+__device__ __forceinline__ void gload4(float &dst, const T *p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
 // The same load, skipped when the wave-uniform flag is 0.  The destination is read-write for the compiler (the old contents
 // survive a skipped load), so there is no control flow -- and no phi / register copy -- around the asynchronous load.
 template <typename V, typename T>

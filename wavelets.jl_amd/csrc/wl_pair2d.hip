@@ -6,7 +6,7 @@
 // A workgroup owns a strip of 256 W rows (W = 4 or 2) and marches along the columns of a chunk exactly like k_fwd2d_lds
 // (wl_fwd2d.hip): W main waves (4 rows per lane, 16-slot column ring in VGPRs filled by hand-placed global_load_dwordx4, dim-2
 // pass in registers, dim-1 pass on 12-row windows read back from a two-slot LDS exchange) and one helper wave that supplies
-// the halo rows above the strip.  Level l+1 is NOT interleaved into those waves (the round-2 attempt: one more dependent LDS
+// the 24 halo rows next to the strip (one row per lane, scalar ring: a quarter of a main wave's dim-2 instructions).  Level l+1 is NOT interleaved into those waves (the round-2 attempt: one more dependent LDS
 // round trip on every step's critical path, 143 VGPRs, 135-140 us against 105 + 34 for two launches).  Instead:
 //
 //   * the main waves and the helper park the level-l approximation column they produce at step t (rows 0 .. 128 W + 7 of the
@@ -54,7 +54,6 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     constexpr int NT1 = 64 * (W + 1);                 // lanes of the level-l exchange (main waves + helper)
     constexpr int ROWS1 = 4 * NT1 + 16;
     constexpr int NPL = 64 * W;                       // owned lanes
-    constexpr int NLOAD = NPL + 6;                    // + halo lanes: 24 rows above the strip
     constexpr int RL = 128 * W + 16;                  // approximation rows per ring slot: 128 W owned + 8 halo (+ 8 pad)
     constexpr int NSLOT = 16;
     constexpr int RW = 2 * W;                         // approximation rows per lane of the level-(l+1) wave
@@ -159,20 +158,105 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         return;
     }
 
-    // =============================== main waves and the helper: level l ===============================
+    if (wv == W) {
+        // =============================== the helper wave: ONE halo row per lane ===============================
+        // The 24 rows below the strip (rows 4 NPL .. 4 NPL + 23 of it, periodic) feed the last main lanes' windows and the 8 halo
+        // approximation rows of the level-(l+1) wave.  With four rows per lane, as in the main waves, six lanes did useful work and
+        // the wave still issued a full wave's dim-2 pass every step (an eighth of the workgroup's VALU work); one row per lane
+        // and a scalar column ring cost a quarter of that.  Lanes >= 24 load row 0 and compute values nobody reads.
+        const int hl = (int)(threadIdx.x & 63);
+        const int lp = NPL + hl;                           // lane index in the level-l exchange (lanes NPL .. NPL+3 own approximation rows)
+        int hrow = strip * (4 * NPL) + 4 * NPL + hl;
+        if (hrow >= msi) hrow -= msi;
+        const T *hbase = a.src + ((hl < 24) ? hrow : 0);
+        T hring[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) hring[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < R - 2; ++c) {
+            int64_t jc = j0 + c;
+            if (jc >= ns) jc -= ns;
+            gload4(hring[c], hbase + jc * a.lds);
+        }
+#pragma unroll
+        for (int c = 0; c < R; c += 2) wait_vm<0>(hring[c], hring[c + 1]);
+        auto hstep = [&](const int t, const int u, const bool prefetch, const bool full, const bool produce) __attribute__((always_inline)) {
+            if (prefetch) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int64_t jc = j0 + 2 * t + (R - 2) + e;
+                    if (jc >= ns) jc -= ns;
+                    if (jc >= ns) jc -= ns;
+                    gload4(hring[(2 * u + R - 2 + e) % R], hbase + jc * a.lds);
+                }
+            }
+            if (produce) {
+                if (prefetch) wait_vm<2 * PFD>(hring[(2 * u + F - 2) % R], hring[(2 * u + F - 1) % R]);      // (loads only: see the main waves)
+                else wait_vm<0>(hring[(2 * u + F - 2) % R], hring[(2 * u + F - 1) % R]);
+            }
+            T2 *const w1 = x1 + (t & 1) * ROWS1;
+            if (produce) {
+                T sa = a.tp.h[0] * hring[(2 * u) % R];
+#pragma unroll
+                for (int m = 1; m < F; ++m) sa = sa + a.tp.h[m] * hring[(2 * u + m) % R];
+                T da = 0.f;
+                if (full) {
+                    da = gq(F - 1) * hring[(2 * u) % R];
+#pragma unroll
+                    for (int m = 1; m < F; ++m) da = da + gq(F - 1 - m) * hring[(2 * u + m) % R];
+                }
+                if (hl < 24) w1[4 * NPL + hl] = T2{sa, da};
+            }
+            wg_lds_sync(true);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- even steps: level-(l+1) dim-2 pass of the halo rows 128 W + 2i, 128 W + 2i + 1 (lanes i = 0..3) ----
+            if (!(u & 1) && t >= F) {
+                if (hl < 4) {
+                    T2 s2, d2;
+#pragma unroll
+                    for (int m = 0; m < F; ++m) {
+                        const T2 xm = *reinterpret_cast<const T2 *>(ll1 + ((t - F + m) & (NSLOT - 1)) * RL + 2 * lp);
+                        if (m == 0) { s2 = a.tp.h[0] * xm; d2 = gq(F - 1) * xm; }
+                        else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + gq(F - 1 - m) * xm; }
+                    }
+                    *reinterpret_cast<T4 *>(x2 + 2 * lp) = T4{s2.x, d2.x, s2.y, d2.y};
+                }
+            }
+            if (!produce) return;
+            // ---- approximation rows ko, ko+1 of lanes i = 0..3 from window rows 4L' .. 4L'+F+1 ----
+            if (hl < 4) {
+                T A[12];
+#pragma unroll
+                for (int c = 0; c < (F + 3) / 2; ++c) {
+                    const T4 v = *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
+                    A[2 * c] = v.x;
+                    A[2 * c + 1] = v.z;
+                }
+                T p0 = a.tp.h[0] * A[0], p1 = a.tp.h[0] * A[2];
+#pragma unroll
+                for (int m = 1; m < F; ++m) { p0 = p0 + a.tp.h[m] * A[m]; p1 = p1 + a.tp.h[m] * A[2 + m]; }
+                *reinterpret_cast<T2 *>(ll1 + (t & (NSLOT - 1)) * RL + 2 * lp) = T2{p0, p1};
+            }
+        };
+        int t0 = 0;
+        for (; t0 < S_own; t0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) hstep(t0 + u, u, true, true, true);
+        }
+#pragma unroll
+        for (int u = 0; u < F; ++u) hstep(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
+        return;
+    }
+
+    // =============================== main waves: level l ===============================
     const int lp = threadIdx.x;                       // L': lane index within the workgroup's strip (0 .. NT1-1)
     const int gi = strip * (4 * NPL) + 4 * lp;        // first row of this lane (halo lanes may exceed ms: wrap)
     int row = gi;
     if (row >= msi) row -= msi;
-    const bool loader = lp < NLOAD;
-    const bool helper = (wv == W);
     const int ko = gi >> 1;
     int kod = ko + 4;  if (kod >= hmi) kod -= hmi;    // first d row of this lane
     const bool odd = (lp & 1) != 0;
-    // lanes that hold no input rows (the helper's upper lanes, lanes past the strip) load the first rows of the same column instead
-    // of being masked: one extra cache line per column, and no `if` -- hence no phi and no register copy -- around the
-    // asynchronous loads (wl_dev.h: gload16_if)
-    const T *base = a.src + (loader ? row : 0);
+    const T *base = a.src + row;
     const int64_t kbase = j0 >> 1;
 
     T4 ring[R];
@@ -214,9 +298,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             }
         }
         T2 *const w1 = x1 + (t & 1) * ROWS1;
-        // the helper's halo rows feed the main lanes' windows with both components inside the chunk; its own outputs are
-        // approximation rows only (helper: wave-uniform run-time flag; !full: compile-time)
-        const bool sonly = !full;
+        const bool sonly = !full;                          // (compile-time)
         if (produce) {
             // ---- level l, dim-2 pass on row pairs: {A, B}[r] = scaling / detail (column k / kd) of row r ----
             T2 sa01 = a.tp.h[0] * T2{ring[(2 * u) % R].x, ring[(2 * u) % R].y};
@@ -243,22 +325,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         }
         wg_lds_sync(true);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- helper, even steps: level-(l+1) dim-2 pass of the halo rows 128 W + 2i, 128 W + 2i + 1 (lanes i = 0..3) ----
-        if (helper && !(u & 1) && t >= F) {
-            if (lp < NPL + 4) {
-                T2 s2, d2;
-#pragma unroll
-                for (int m = 0; m < F; ++m) {
-                    const T2 xm = *reinterpret_cast<const T2 *>(ll1 + ((t - F + m) & (NSLOT - 1)) * RL + 2 * lp);
-                    if (m == 0) { s2 = a.tp.h[0] * xm; d2 = gq(F - 1) * xm; }
-                    else { s2 = s2 + a.tp.h[m] * xm; d2 = d2 + gq(F - 1 - m) * xm; }
-                }
-                *reinterpret_cast<T4 *>(x2 + 2 * lp) = T4{s2.x, d2.x, s2.y, d2.y};
-            }
-        }
         if (!produce) return;
         T *const slot = ll1 + (t & (NSLOT - 1)) * RL + 2 * lp;
-        if (sonly || helper) {
+        if (sonly) {
             // ---- approximation only: ss rows ko, ko+1 from window rows 4L' .. 4L'+F+1 ----
             T A[12];
 #pragma unroll
@@ -270,7 +339,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             T p0 = a.tp.h[0] * A[0], p1 = a.tp.h[0] * A[2];
 #pragma unroll
             for (int m = 1; m < F; ++m) { p0 = p0 + a.tp.h[m] * A[m]; p1 = p1 + a.tp.h[m] * A[2 + m]; }
-            if (lp < NPL + 4) *reinterpret_cast<T2 *>(slot) = T2{p0, p1};
+            *reinterpret_cast<T2 *>(slot) = T2{p0, p1};
             return;
         }
         // ---- level l, dim-1 pass: window rows 4L' .. 4L'+11 as {A, B} pairs ----

@@ -103,6 +103,62 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     // asynchronous loads (wl_dev.h: gload16_if)
     const T *base = a.src + splane * a.bs_src + (loader ? row : 0);
 
+    if (helper) {
+        // ---- the halo wave of an exactly tiled strip: the 8 rows below it, ONE row per lane in a scalar column ring (with four rows
+        //      per lane two lanes did useful work while the wave issued a full wave's dim-2 pass every step; see wl_pair2d.hip).
+        //      Same loads / waits / one barrier per step as the main waves; lanes >= 8 load row 0 and write nothing. ----
+        const int hl = (int)(threadIdx.x & 63);
+        int hrow = strip * (4 * a.npl) + 4 * a.npl + hl;
+        if (hrow >= msi) hrow -= msi;
+        if (hrow >= msi) hrow = 0;
+        const T *hbase = a.src + splane * a.bs_src + ((hl < 8) ? hrow : 0);
+        T hring[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) hring[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < R - 2; ++c) {
+            int64_t jc = j0 + c;
+            if (jc >= ns) jc -= ns;
+            jc -= crot;
+            if (jc < 0) jc += ns;
+            gload4(hring[c], hbase + jc * a.lds);
+        }
+#pragma unroll
+        for (int c = 0; c < R; c += 2) wait_vm<0>(hring[c], hring[c + 1]);
+        auto hstep = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
+            if (prefetch) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int64_t jc = j0 + 2 * t + (R - 2) + e;
+                    if (jc >= ns) jc -= ns;
+                    if (jc >= ns) jc -= ns;
+                    jc -= crot;
+                    if (jc < 0) jc += ns;
+                    gload4(hring[(2 * u + R - 2 + e) % R], hbase + jc * a.lds);
+                }
+                wait_vm<2 * PFD>(hring[(2 * u + F - 2) % R], hring[(2 * u + F - 1) % R]);
+            } else {
+                wait_vm<0>(hring[(2 * u + F - 2) % R], hring[(2 * u + F - 1) % R]);
+            }
+            T sa = a.tp.h[0] * hring[(2 * u) % R], da = gq(F - 1) * hring[(2 * u) % R];
+#pragma unroll
+            for (int m = 1; m < F; ++m) {
+                sa = sa + a.tp.h[m] * hring[(2 * u + m) % R];
+                da = da + gq(F - 1 - m) * hring[(2 * u + m) % R];
+            }
+            if (hl < 8) (x1 + (t & 1) * rows1)[4 * a.npl + hl] = T2{sa, da};
+            wg_lds_sync(multi);
+        };
+        int t0 = 0;
+        for (; t0 < S - U; t0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) hstep(t0 + u, u, true);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) hstep(t0 + u, u, u < U - PFD);
+        return;
+    }
+
     T4 ring[R];
 #pragma unroll
     for (int c = 0; c < R; ++c) ring[c] = T4{0.f, 0.f, 0.f, 0.f};
@@ -172,7 +228,6 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         *reinterpret_cast<T4 *>(w1 + 4 * lp + 2) = T4{sa23.x, da23.x, sa23.y, da23.y};
         wg_lds_sync(multi);
         __builtin_amdgcn_sched_barrier(0);
-        if (helper) return;                                // the helper wave owns no output
         // ---- level l, dim-1 pass: window rows 4L' .. 4L'+11 as {A, B} pairs ----
         T2 E[12];
 #pragma unroll

@@ -25,7 +25,13 @@ names = list(rows)
 dem = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.splitlines() if names else []
 for n, d in zip(names, dem):
     r = rows[n]
-    d = re.sub(r'\(.*\)$', '', d).replace('void ', '').replace('wl::', '')
+    depth = 0; cut = len(d)                      # strip the trailing parameter list only (names may contain '(anonymous namespace)')
+    for i in range(len(d) - 1, -1, -1):
+        if d[i] == ')': depth += 1
+        elif d[i] == '(':
+            depth -= 1
+            if depth == 0: cut = i; break
+    d = (d[:cut] if d.endswith(')') else d).replace('void ', '').replace('wl::', '').replace('(anonymous namespace)::', '')
     print('| \`%s\` | %s | %s | %s | %s | %s | %s | %s | %s |' % (d, r.get('VGPRs'), r.get('AGPRs'), r.get('TotalSGPRs'), r.get('ScratchSize [bytes/lane]'),
           r.get('LDS Size [bytes/block]'), r.get('Occupancy [waves/SIMD]'), r.get('VGPRs Spill'), r.get('SGPRs Spill')))
 "

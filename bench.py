@@ -114,9 +114,22 @@ def _event_train_ms(fns, reps, chunk=10):
     return statistics.median(per)
 
 
-def _event_each_ms(fns, reps, warm=5):
-    """one event pair per call, calls enqueued back to back: (median, min, mean) ms"""
+def _event_each_ms(fns, reps, warm=5, warm_ms=40.0):
+    """one event pair per call, calls enqueued back to back: (median, min, mean) ms.  Untimed conditioning first: `warm` calls, then
+    as many more as fill `warm_ms` of device time (at most 400) -- after the host-side set-up of a leg the device has been idle
+    for seconds, and a handful of sub-millisecond calls does not bring its clocks back (8192^2 Float64: 0.32-0.36 ms after five
+    calls, 0.28 ms in steady state)."""
     for i in range(warm):
+        fns[i % len(fns)]()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(3):
+        fns[i % len(fns)]()
+    b.record()
+    torch.cuda.synchronize()
+    est = max(a.elapsed_time(b) / 3.0, 1e-3)
+    for i in range(min(400, max(0, int(warm_ms / est) - 3))):
         fns[i % len(fns)]()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -525,7 +538,8 @@ def pipelined_leg(W, xs, wt, L, args, nstreams=4):
 
 def secondary_leg(W, device, reps=20):
     """Device-timed runs of the other BASELINE.json configs and of the section-8(f) rows (parity-test configs, not the
-    headline).  Protocol: 5 untimed calls, then `reps` calls enqueued back to back with ONE HIP EVENT PAIR PER CALL; the
+    headline).  Protocol: untimed conditioning calls (5, then enough to fill 40 ms of device time), then `reps` calls enqueued
+    back to back with ONE HIP EVENT PAIR PER CALL; the
     figure is the MEDIAN (the minimum is printed beside it), so a single hiccup -- a host garbage collection, a first-use
     code-object load -- cannot poison it."""
     res = []

@@ -202,6 +202,38 @@ def test_guard_bands_batched_and_callers(gpu, W, oracle):
     g.check([1], "threshold")
 
 
+def test_nonsense_option_values_are_harmless(gpu, W, oracle):
+    """The per-context options are tuning / test knobs, but a zero or an odd value must not be able to crash the process (chunk and
+    tile lengths are divisors in the launchers): every knob that sizes a chunk, a tile or a slab set to 0, 1 and 7 -- the
+    transforms still run and still give the oracle's bits."""
+    knobs = ("WL_TJ", "WL_TJ2", "WL_TS", "WL_INV2D_TP", "WL_SLAB_LINES", "WL_LONG_TJ", "WL_LIFT_TP", "WL_TAIL2_THREADS", "WL_PAIR_W",
+             "WL_PAIR_W64", "WL_LONG_W", "WL_TILEB_MAX", "WL_LIFT_TILE_MAX")
+    db4, db8, cdf = W.wavelet(W.WT.db4), W.wavelet(W.WT.db8), W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    cases = [((512, 512), np.float32, db4, 3, False), ((512, 256), np.float64, db4, 2, False), ((1 << 16,), np.float32, db4, 16, False),
+             ((512, 512), np.float32, db8, 2, False), ((512, 512), np.float32, cdf, 3, True), ((1 << 15,), np.float64, cdf, 15, True)]
+    data = []
+    for shape, dtype, wt, L, lifting in cases:
+        x = rng_array(shape, dtype, 3 + len(shape))
+        ye = oracle.dwt_lifting(x, wt, L) if lifting else oracle.dwt_filter(x, wt.qmf, L)
+        data.append((x, ye))
+    xc = rng_array((4096, 6), np.float32, 9)
+    yc = oracle.dwtc_filter(xc, db4.qmf, 5)
+    for bad in (0, 1, 7):
+        for k in knobs:
+            W.set_option(k, bad)
+        W.set_option("WL_LDS_PAIR_MIN", 0)
+        try:
+            for (shape, dtype, wt, L, lifting), (x, ye) in zip(cases, data):
+                y = W.to_host(W.dwt(W.to_device(x), wt, L))
+                assert np.array_equal(y, ye), (bad, shape, dtype, L)
+                xr = W.to_host(W.idwt(W.to_device(ye), wt, L))
+                xe = oracle.dwt_lifting(ye, wt, L, fw=False) if lifting else oracle.dwt_filter(ye, wt.qmf, L, fw=False)
+                assert np.array_equal(xr, xe), (bad, shape, dtype, L, "inv")
+            assert np.array_equal(W.to_host(W.dwtc(W.to_device(xc), db4, 5)), yc), bad
+        finally:
+            W.clear_options()
+
+
 def test_hipgraph_capture_and_replay(gpu, W, oracle):
     """A transform call allocates nothing and synchronises nothing once its context exists and the workspace is reserved, so it can
     be captured into a hipGraph; replays on new input data give the bits of a direct call."""

@@ -1161,7 +1161,7 @@ static hipError_t launch_fwd1d(hipStream_t st, const Taps<T> &taps, bool lvl1, c
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
     // gridDim.y is limited to 65535: launch in slabs of lines
-    const int64_t slab = env_int_raw("WL_SLAB_LINES", 32768);
+    const int64_t slab = (env_int_raw("WL_SLAB_LINES", 32768) > 0) ? env_int_raw("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Fwd1DArgs<T, F> b = a;
@@ -1182,13 +1182,14 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     // tile = 32 KiB of input for long lines; shorter tiles (down to 4 KiB) when there would otherwise be
     // fewer workgroups than CUs -- a workgroup's latency chain (stage, NL levels, barriers) is ~constant
     a.TS = env_int("WL_TS", (int)(16384 / sizeof(T)));
+    if (a.TS < 256 || (a.TS % 64) != 0) a.TS = (int)(16384 / sizeof(T));
     while (a.TS > (int)(4096 / sizeof(T)) && ((n + a.TS - 1) / a.TS) * nlines < 512) a.TS >>= 1;
     a.tp = shrink<T, F>(taps);
     const int H0 = (F - 2) * ((1 << NL) - 1), H1 = (F - 2) * ((1 << (NL - 1)) - 1);
     const size_t elems = (size_t)((a.TS + 2 * H0 + 7) & ~7) + 16 + (size_t)(a.TS / 2 + 2 * H1 + 8) + 32;   // (+ room for the last groups' windows)
     const size_t shmem = elems * sizeof(T);
     const unsigned ntiles = (unsigned)((n + a.TS - 1) / a.TS);
-    const int64_t slab = env_int_raw("WL_SLAB_LINES", 32768);
+    const int64_t slab = (env_int_raw("WL_SLAB_LINES", 32768) > 0) ? env_int_raw("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Multi1DArgs<T, F> b = a;

@@ -334,6 +334,7 @@ static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, bool lvl
     const Shape2D sh = pick_shape(ms, (int)opt("WL_LDS_MODE", 0), (int)opt("WL_LDS_W", 4));
     a.npl = sh.npl; a.nload = sh.nload; a.nstrips = sh.nstrips; a.helper = sh.helper;
     int TJ = (int)opt("WL_TJ", 128);
+    if (TJ < 16 || (TJ % 16) != 0) TJ = 128;              // (a test knob must not be able to divide by zero)
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * sh.nw * ((ns + tj - 1) / tj) * nbatch; };
     const int wpc = (int)opt("WL_WAVES_PER_CU", 8);
     while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * wpc) TJ >>= 1;

@@ -178,6 +178,7 @@ static hipError_t launch_lds64_f(hipStream_t st, const Taps<double> &taps, bool 
     a.npl = 64 * W;
     a.nstrips = (int)(ms / (128 * W));
     int TJ = (int)opt("WL_TJ", 128);
+    if (TJ < 16 || (TJ % 16) != 0) TJ = 128;
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * (W + 1) * ((ns + tj - 1) / tj) * nbatch; };
     while (TJ > 32 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * opt("WL_WAVES_PER_CU", 8)) TJ >>= 1;
     while (TJ > 16 && (TJ % 32) == 0 && nwaves(TJ) < (int64_t)cu_count * opt("WL_WAVES_MIN", 8)) TJ >>= 1;

@@ -539,7 +539,7 @@ static hipError_t launch_inv1d(hipStream_t st, const Taps<T> &taps, const T *ssr
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    const int64_t slab = i_env("WL_SLAB_LINES", 32768);
+    const int64_t slab = (i_env("WL_SLAB_LINES", 32768) > 0) ? i_env("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Inv1DArgs<T, F> b = a;
@@ -628,7 +628,7 @@ static hipError_t launch_inv1d2(hipStream_t st, const Taps<T> &taps, const T *s2
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    const int64_t slab = i_env("WL_SLAB_LINES", 32768);
+    const int64_t slab = (i_env("WL_SLAB_LINES", 32768) > 0) ? i_env("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Inv1D2Args<T, F> b = a;
@@ -798,6 +798,7 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
     const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
     a.nstrips = (int)((h0 + VP - 1) / VP);
     int TP = i_env("WL_INV2D_TP", 64);
+    if (TP < 8 || (TP % 8) != 0) TP = 64;                 // (a test knob must not be able to divide by zero)
     while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 16) TP >>= 1;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);

@@ -1347,7 +1347,7 @@ static void launch_stream_id(hipStream_t st, const Lift1DArgs<T> &a, int64_t nli
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    const int64_t slab = l_env("WL_SLAB_LINES", 32768);
+    const int64_t slab = (l_env("WL_SLAB_LINES", 32768) > 0) ? l_env("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {      // gridDim.y <= 65535
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Lift1DArgs<T> b = a;
@@ -1363,7 +1363,7 @@ static void launch_fwd3_id(hipStream_t st, const Lift3Args<T> &a, int64_t nlines
     int64_t gx = (a.ntiles + 3) / 4;
     const int64_t cap = (int64_t)cu_count * 8;
     if (gx > cap) gx = cap;
-    const int64_t slab = l_env("WL_SLAB_LINES", 32768);
+    const int64_t slab = (l_env("WL_SLAB_LINES", 32768) > 0) ? l_env("WL_SLAB_LINES", 32768) : 32768;
     for (int64_t l0 = 0; l0 < nlines; l0 += slab) {
         const int64_t nl = (nlines - l0 < slab) ? (nlines - l0) : slab;
         Lift3Args<T> b = a;
@@ -2340,8 +2340,14 @@ static hipError_t launch_lift2d_inv(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     constexpr int VR = (64 - 2 * kLift2dML) * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
-    int TP = 64;
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
+    // chunk length: these kernels are latency-bound per wave (8-slot ring: loads run three or four steps ahead), so what counts is
+    // how many waves are resident -- 40 pairs per chunk puts 3.7 waves on every SIMD for 8192^2 (64: 2.3 waves, 136 -> 125 us;
+    // 32: the same time with more cone columns; 24 and below: a second round of workgroups)
+    int TP = 40;
+    if ((int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 3) {
+        TP = 64;
+        while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
+    }
     const int tpo = (int)opt("WL_LIFT_TP", 0);
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;
@@ -2357,8 +2363,14 @@ static hipError_t launch_lift2d_fwd(hipStream_t st, Lift2DArgs<T> a, int cu_coun
     constexpr int VR = (64 - 2 * kLift2dML) * 4;
     a.nstrips = (int)((a.n0 + VR - 1) / VR);
     const int64_t h1 = a.n1 >> 1;
-    int TP = 64;
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
+    // chunk length: these kernels are latency-bound per wave (8-slot ring: loads run three or four steps ahead), so what counts is
+    // how many waves are resident -- 40 pairs per chunk puts 3.7 waves on every SIMD for 8192^2 (64: 2.3 waves, 136 -> 125 us;
+    // 32: the same time with more cone columns; 24 and below: a second round of workgroups)
+    int TP = 40;
+    if ((int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 3) {
+        TP = 64;
+        while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 8) TP >>= 1;
+    }
     const int tpo = (int)opt("WL_LIFT_TP", 0);
     if (tpo >= 8 && (tpo % 8) == 0) TP = tpo;
     a.TP = TP;

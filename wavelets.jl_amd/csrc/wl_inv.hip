@@ -70,17 +70,17 @@ __device__ __forceinline__ void inv_pair(const T *sw, const T *dw, const TapsI<T
     T Se = tp.h[F - 2] * sw[0];
 #pragma unroll
     for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
-    T De = tp.g[1] * dw[0];
+    T De = -tp.h[1] * dw[0];                    // g[m] = (-1)^m h[m] exactly (make_taps): only h occupies SGPRs
 #pragma unroll
-    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    for (int q = 1; q <= SH; ++q) De = De + -tp.h[1 + 2 * q] * dw[q];
     xe = Se + De;
     // odd output o = 2p+1: S over odd m descending (F-1, ..., 1) -> s[p - (m-1)/2]; D over even m ascending -> d[p + m/2]
     T So = tp.h[F - 1] * sw[0];
 #pragma unroll
     for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
-    T Do = tp.g[0] * dw[0];
+    T Do = tp.h[0] * dw[0];
 #pragma unroll
-    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.h[2 * q] * dw[q];
     xo = So + Do;
 }
 
@@ -352,16 +352,16 @@ __device__ __forceinline__ void tail_inv_pair(const T *sp, int ss, const T *dp, 
     T Se = tp.h[FC - 2] * sw[0];
 #pragma unroll
     for (int q = 1; q <= SH; ++q) Se = Se + tp.h[FC - 2 - 2 * q] * sw[q];
-    T De = tp.g[1] * dw[0];
+    T De = -tp.h[1] * dw[0];                    // g[m] = (-1)^m h[m] exactly (make_taps): only h occupies SGPRs
 #pragma unroll
-    for (int q = 1; q <= SH; ++q) De = De + tp.g[1 + 2 * q] * dw[q];
+    for (int q = 1; q <= SH; ++q) De = De + -tp.h[1 + 2 * q] * dw[q];
     xe = Se + De;
     T So = tp.h[FC - 1] * sw[0];
 #pragma unroll
     for (int q = 1; q <= SH; ++q) So = So + tp.h[FC - 1 - 2 * q] * sw[q];
-    T Do = tp.g[0] * dw[0];
+    T Do = tp.h[0] * dw[0];
 #pragma unroll
-    for (int q = 1; q <= SH; ++q) Do = Do + tp.g[2 * q] * dw[q];
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.h[2 * q] * dw[q];
     xo = So + Do;
 }
 // e -> (e / d, e % d) without the emulated division when d is a power of two
@@ -707,8 +707,10 @@ __device__ __forceinline__ void inv_column(const T (&s)[PPL], const T (&d)[PPL],
     for (int p = 0; p < PPL; ++p) inv_pair<T, F>(&sx[p], &dx[p], tp, out[2 * p], out[2 * p + 1]);
 }
 
+// (10 taps, Float32: left to itself the compiler takes 175 VGPRs = 2 waves per SIMD; this kernel is latency-bound per wave, so the
+//  third resident wave is worth the few rematerialised values)
 template <typename T, int F, int PPL>
-__global__ void __launch_bounds__(64) k_inv2d_stream(Inv2DArgs<T, F> a)
+__global__ void __launch_bounds__(64, (F == 10 && sizeof(T) == 4 && PPL == 2) ? 3 : 1) k_inv2d_stream(Inv2DArgs<T, F> a)
 {
     constexpr int SH = (F - 2) / 2, HL = inv2d_halo_lanes(SH, PPL), VP = (64 - 2 * HL) * PPL, R = (SH <= 3) ? 4 : 8;
     static_assert(SH <= 4, "ring depth");

@@ -163,6 +163,17 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
     W.set_option("WL_TI_WS_CAP_MB", 8)                           # 12 spins of 1 MiB: groups of a few spins
     assert np.array_equal(host(W, W.denoise(bd, TI=True, nspin=(4, 3))), e)
     W.clear_options()
+    # ... and with the planes small enough to matter here sent through the batched fused-pair kernel (levels 1-2 and 3-4 in one
+    # launch each: virtual shifts, hard threshold fused into the stores of both levels; by default only planes >= 2048^2 take it)
+    W.set_option("WL_PAIR_BATCH_MIN", 0)
+    assert np.array_equal(host(W, W.denoise(bd, TI=True, nspin=(4, 3))), e)
+    es = _oracle_denoise(oracle, W, b, W.wavelet(W.WT.db4), 4, W.VisuShrink(W.SoftTH(), 2.0), True, (3, 5))
+    ys = host(W, W.denoise(bd, W.wavelet(W.WT.db4), L=4, dnt=W.VisuShrink(W.SoftTH(), 2.0), TI=True, nspin=(3, 5)))
+    assert np.array_equal(ys, es)
+    eh = _oracle_denoise(oracle, W, b, W.wavelet(W.WT.db2), 2, W.VisuShrink(W.HardTH(), 1.5), True, (2, 2))
+    yh = host(W, W.denoise(bd, W.wavelet(W.WT.db2), L=2, dnt=W.VisuShrink(W.HardTH(), 1.5), TI=True, nspin=(2, 2)))
+    assert np.array_equal(yh, eh)                                # (L = 2: the pair is the last launch -- its approximation is thresholded too)
+    W.clear_options()
     v = (doppler(4096) + 0.05 * np.random.default_rng(4).standard_normal(4096)).astype(dtype)
     e1 = _oracle_denoise(oracle, W, v, W.wavelet(W.WT.db4), 6, W.VisuShrink(W.SoftTH(), 2.0), True, (16,))
     y1 = host(W, W.denoise(W.to_device(v), W.wavelet(W.WT.db4), dnt=W.VisuShrink(W.SoftTH(), 2.0), TI=True, nspin=16))

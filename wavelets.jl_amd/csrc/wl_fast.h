@@ -81,7 +81,8 @@ hipError_t fwd2d_pair64_launch(hipStream_t st, const Taps<double> &taps, bool lv
 // blocks whose rows tile into strips of 1024 / 512.
 bool fwd2d_pair_ok(int F, int64_t ms, int64_t ns);
 hipError_t fwd2d_pair_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
-                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count);
+                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, int64_t nbatch = 1, int64_t bs_src = 0,
+                             int64_t bs_y = 0, int64_t bs_ll = 0, int src_mod = 0, int64_t spin0 = 0, const SrcView *thresh = nullptr);
 
 // Tile kernel for the cache-resident 2-D levels (wl_tile.hip): NL = 1..3 fused forward levels per launch, Float32, even F <= 10.
 bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N);

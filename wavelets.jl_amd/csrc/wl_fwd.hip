@@ -1277,6 +1277,29 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
 
         // ---- batch of independent 2-D blocks (box n0 x n1 x B, first two axes transformed: the shifted copies of a
         //      translation-invariant denoise): one launch of the LDS-exchange kernel per level, planes over blockIdx.y ----
+        // ... two levels per launch while the planes are big enough for the fused pair kernel to pay (many planes keep the chip full
+        //     where a single 2048^2 block would not)
+        if constexpr (sizeof(T) == 4) {
+            if (fastF && b.nd == 3 && b.nt == 2 && (L - l + 1) >= 2 && env_int("WL_PAIR_BATCH", 1) != 0 && n[2] >= 2 && n[2] <= 65535 &&
+                n[0] * n[1] >= (int64_t)env_int_raw("WL_PAIR_BATCH_MIN", 1 << 22) && fwd2d_pair_ok(F, n[0], n[1]) && cur_st.s[0] == 1 &&
+                (cur_st.s[1] % VEC) == 0 && (cur_st.s[2] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&
+                (b.full.s[2] % VEC) == 0 && aligned16(y) && aligned16(llbuf)) {
+                const bool view = (l == 1 && tl_srcview.mod > 0);
+                const bool thr = tl_srcview.th >= 0 && (view || (l > 1 && tl_srcview.used != 0 && tl_srcview.corner0 == n[0] && tl_srcview.corner1 == n[1]));
+                const bool lastp = (l + 1 == L);
+                int64_t hn2[3] = {n[0] >> 2, n[1] >> 2, n[2]};
+                Strides3 ll2_st = dense_strides(hn2);
+                WL_TRY(fwd2d_pair_launch(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], lastp ? (T *)nullptr : llbuf, hn2[0], n[0], n[1],
+                                         cu_count, n[2], cur_st.s[2], b.full.s[2], ll2_st.s[2], view ? tl_srcview.mod : 0,
+                                         view ? tl_srcview.spin0 : 0, thr ? &tl_srcview : nullptr));
+                if (view) tl_srcview.used = 1;
+                if (thr) { tl_srcview.corner0 = lastp ? 0 : hn2[0]; tl_srcview.corner1 = lastp ? 0 : hn2[1]; }
+                if (!dominant) dominant = "k_fwd2d_pair";
+                lstep = 2;
+                cur = llbuf; cur_st = ll2_st; pp ^= 1;
+                continue;
+            }
+        }
         if constexpr (sizeof(T) == 4) {
             if (fastF && b.nd == 3 && b.nt == 2 && fwd2d_lds_ok(F, 1, n[0], n[1]) && n[2] <= 65535 && cur_st.s[0] == 1 &&
                 (cur_st.s[1] % VEC) == 0 && (cur_st.s[2] % VEC) == 0 && aligned16(cur) && (b.full.s[1] % VEC) == 0 &&

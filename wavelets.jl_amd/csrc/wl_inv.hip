@@ -801,7 +801,8 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
     a.nstrips = (int)((h0 + VP - 1) / VP);
     int TP = i_env("WL_INV2D_TP", 64);
     if (TP < 8 || (TP % 8) != 0) TP = 64;                 // (a test knob must not be able to divide by zero)
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * 16) TP >>= 1;
+    const int64_t wpc = (i_env("WL_INV2D_WAVES", 16) > 0) ? i_env("WL_INV2D_WAVES", 16) : 16;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * nbatch < (int64_t)cu_count * wpc) TP >>= 1;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     a.tp = shrink_i<T, F>(taps);

@@ -40,10 +40,16 @@ struct Pair2DArgs {
     int TJ;                           // owned input columns per chunk (multiple of 32)
     int nstrips, nchunks;
     int rev;
+    // BT instances (the planes of a translation-invariant denoise batch over blockIdx.y): plane strides, the virtual shift of
+    // level 1 (plane p reads copy (spin0 + p) % src_mod with its columns rotated by (spin0 + p) / src_mod, as k_fwd2d_lds) and the
+    // hard threshold applied to every final coefficient as it is stored (th < 0: none)
+    int64_t bs_src, bs_y, bs_ll;
+    int src_mod; int64_t spin0;
+    int th; double t_unit, sigma_host; const double *mad_dev;
     TapsF<float, F> tp;
 };
 
-template <int F, int W, int LVL1>
+template <int F, int W, int LVL1, int BT = 0>
 __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
 {
     typedef float T;
@@ -79,9 +85,25 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     const int64_t jend = (j0 + a.TJ < ns) ? (j0 + a.TJ) : ns;
     const int S_own = (int)((jend - j0) >> 1);        // steps whose level-l outputs this chunk owns (multiple of 16)
     const int S = S_own + F;                          // the level-(l+1) column of ring columns c .. c+F-1 is taken up at step c + F
-    T *const yb = a.y;
-    T *const llb = a.ll ? a.ll : a.y;
+    T *const yb = a.y + (BT ? (int64_t)blockIdx.y * a.bs_y : 0);
+    T *const llb = a.ll ? (a.ll + (BT ? (int64_t)blockIdx.y * a.bs_ll : 0)) : yb;
     const int64_t ldl = a.ll ? a.ldll : a.ldy;
+    int64_t splane = BT ? (int64_t)blockIdx.y : 0, crot = 0;
+    if (BT && a.src_mod > 0) {
+        const int64_t spin = a.spin0 + (int64_t)blockIdx.y;
+        splane = spin % a.src_mod;
+        crot = spin / a.src_mod;
+    }
+    const T *const srcp = a.src + (BT ? splane * a.bs_src : 0);
+    // hard threshold (BT): |x| <= t in Float64 <=> |x| <= the largest Float32 <= t (see k_fwd2d_lds); tf < 0: nothing is zeroed
+    float tf = -1.f;
+    if (BT && a.th >= 0) {
+        const double tthr = ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit;
+        tf = (float)tthr;
+        if ((double)tf > tthr) tf = __uint_as_float(__float_as_uint(tf) - 1u);
+    }
+    auto thr = [&](const T v) __attribute__((always_inline)) { return (BT && __builtin_fabsf(v) <= tf) ? 0.f : v; };
+    const bool th_ll = BT && (a.ll == nullptr);          // last level of the transform: its approximation is final too
 
     if (wv == W + 1) {
         // =============================== the level-(l+1) wave ===============================
@@ -142,6 +164,13 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                 int64_t kd2 = k2 + SH;
                 if (kd2 >= nxj2) kd2 -= nxj2;
                 T *const ck = yb + k2 * a.ldy, *const ckd = yb + (nxj2 + kd2) * a.ldy, *const cl = llb + k2 * ldl;   // (uniform)
+                if constexpr (BT != 0) {
+#pragma unroll
+                    for (int q = 0; q < HS; ++q) {
+                        if (th_ll) P[q].x = thr(P[q].x);
+                        P[q].y = thr(P[q].y); Q[q].x = thr(Q[q].x); Q[q].y = thr(Q[q].y);
+                    }
+                }
                 if constexpr (HS == 4) {
                     *reinterpret_cast<T4 *>(cl + s2row) = T4{P[0].x, P[1].x, P[2].x, P[3].x};
                     *reinterpret_cast<T4 *>(ck + (hm2i + d2row)) = T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x};
@@ -168,7 +197,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         const int lp = NPL + hl;                           // lane index in the level-l exchange (lanes NPL .. NPL+3 own approximation rows)
         int hrow = strip * (4 * NPL) + 4 * NPL + hl;
         if (hrow >= msi) hrow -= msi;
-        const T *hbase = a.src + ((hl < 24) ? hrow : 0);
+        const T *hbase = srcp + ((hl < 24) ? hrow : 0);
         T hring[R];
 #pragma unroll
         for (int c = 0; c < R; ++c) hring[c] = 0.f;
@@ -176,6 +205,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         for (int c = 0; c < R - 2; ++c) {
             int64_t jc = j0 + c;
             if (jc >= ns) jc -= ns;
+            if (BT) { jc -= crot; if (jc < 0) jc += ns; }
             gload4(hring[c], hbase + jc * a.lds);
         }
 #pragma unroll
@@ -187,6 +217,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     int64_t jc = j0 + 2 * t + (R - 2) + e;
                     if (jc >= ns) jc -= ns;
                     if (jc >= ns) jc -= ns;
+                    if (BT) { jc -= crot; if (jc < 0) jc += ns; }
                     gload4(hring[(2 * u + R - 2 + e) % R], hbase + jc * a.lds);
                 }
             }
@@ -256,7 +287,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     const int ko = gi >> 1;
     int kod = ko + 4;  if (kod >= hmi) kod -= hmi;    // first d row of this lane
     const bool odd = (lp & 1) != 0;
-    const T *base = a.src + row;
+    const T *base = srcp + row;
     const int64_t kbase = j0 >> 1;
 
     T4 ring[R];
@@ -266,6 +297,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     for (int c = 0; c < R - 2; ++c) {
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
+        if (BT) { jc -= crot; if (jc < 0) jc += ns; }
         gload16(ring[c], base + jc * a.lds);
     }
 #pragma unroll
@@ -280,6 +312,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
+                if (BT) { jc -= crot; if (jc < 0) jc += ns; }
                 gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
             }
         }
@@ -363,6 +396,10 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             Q[q] = d;
         }
         *reinterpret_cast<T2 *>(slot) = T2{P[0].x, P[1].x};             // approximation column kbase + t -> ring
+        if constexpr (BT != 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { P[q].y = thr(P[q].y); Q[q].x = thr(Q[q].x); Q[q].y = thr(Q[q].y); }
+        }
         const int64_t k = kbase + t;
         int64_t kd = k + SH;
         if (kd >= nxj) kd -= nxj;
@@ -402,51 +439,70 @@ bool fwd2d_pair_ok(int F, int64_t ms, int64_t ns)
     return ms >= 512 && (ms % 512) == 0 && ns >= 64 && (ns % 32) == 0;
 }
 
+struct PairBatch { int64_t nbatch, bs_src, bs_y, bs_ll; int src_mod; int64_t spin0; const SrcView *thresh; };
+
 template <int F, int W>
 static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
-                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, const PairBatch *pb)
 {
     Pair2DArgs<F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
+    a.bs_src = pb ? pb->bs_src : 0; a.bs_y = pb ? pb->bs_y : 0; a.bs_ll = pb ? pb->bs_ll : 0;
+    a.src_mod = pb ? pb->src_mod : 0; a.spin0 = pb ? pb->spin0 : 0;
+    a.th = (pb && pb->thresh) ? pb->thresh->th : -1; a.t_unit = (pb && pb->thresh) ? pb->thresh->t_unit : 0.0;
+    a.sigma_host = (pb && pb->thresh) ? pb->thresh->sigma_host : 0.0; a.mad_dev = (pb && pb->thresh) ? pb->thresh->mad_dev : nullptr;
+    const int64_t nbatch = pb ? pb->nbatch : 1;
     a.nstrips = (int)(ms / (256 * W));
     int TJ = (int)opt("WL_TJ2", 128);
     if (TJ < 32) TJ = 32;
     TJ &= ~31;
     // one resident round of workgroups (W = 2: four 4-wave workgroups per CU): shorter chunks pay 3 (F - 2) halo columns each,
     // but a chip that is not full is latency-bound (8192^2: 1024 workgroups 116 us, 512 workgroups 129 us; 4096^2: 34.5 vs 39 us)
-    auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
+    auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj) * nbatch; };
     while (TJ > 32 && (TJ % 64) == 0 && nwgs(TJ) < (int64_t)cu_count * opt("WL_PAIR_WG_PER_CU", 4)) TJ >>= 1;
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
-    if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, W, 1>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
+    if (pb) {
+        if constexpr (W == 2) {          // (the batched instances exist for the default strip shape only)
+            if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 1, 1>), dim3(nwg, (unsigned)nbatch), dim3(64 * (W + 2)), 0, st, a);
+            else hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 0, 1>), dim3(nwg, (unsigned)nbatch), dim3(64 * (W + 2)), 0, st, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, W, 1>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
     else hipLaunchKernelGGL((k_fwd2d_pair<F, W, 0>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
     return hipGetLastError();
 }
 
 template <int F>
 static hipError_t launch_pair_f(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
-                                float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+                                float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, const PairBatch *pb)
 {
+    if (pb) return launch_pair_fw<F, 2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
     // strips of 512 rows by default: 4-wave workgroups, four per CU, beat 6-wave workgroups of 1024 rows (8192^2 db4: 116 vs 135 us)
     int W = (int)opt("WL_PAIR_W", 2);
     if (W != 2 && W != 4) W = 2;
     if ((ms % (256 * W)) != 0) W = 2;
-    if (W == 4) return launch_pair_fw<F, 4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    return launch_pair_fw<F, 2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    if (W == 4) return launch_pair_fw<F, 4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nullptr);
+    return launch_pair_fw<F, 2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, nullptr);
 }
 
 hipError_t fwd2d_pair_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
-                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
+                             float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, int64_t nbatch, int64_t bs_src, int64_t bs_y,
+                             int64_t bs_ll, int src_mod, int64_t spin0, const SrcView *thresh)
 {
+    PairBatch pbv = {nbatch, bs_src, bs_y, bs_ll, src_mod, spin0, thresh};
+    const PairBatch *pb = (nbatch > 1 || src_mod > 0 || thresh) ? &pbv : nullptr;
+    if (pb && nbatch > 65535) return hipErrorInvalidValue;
     switch (taps.F) {
-    case 2: return launch_pair_f<2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    case 4: return launch_pair_f<4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    case 6: return launch_pair_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    case 8: return launch_pair_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
-    case 10: return launch_pair_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count);
+    case 2: return launch_pair_f<2>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
+    case 4: return launch_pair_f<4>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
+    case 6: return launch_pair_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
+    case 8: return launch_pair_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
+    case 10: return launch_pair_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
     default: return hipErrorInvalidValue;
     }
 }

@@ -76,7 +76,7 @@ def one_case(r, verbose=False):
         knobs = {"WL_LDS_PAIR_MIN": 0, "WL_LDS_PAIR_MIN64": 0, "WL_LONG2D_MIN_ROWS": 256, "WL_TILE": int(r.integers(0, 2)),
                  "WL_PAIR_W": int(r.choice([2, 4])), "WL_PAIR_W64": int(r.choice([2, 4])), "WL_TJ2": int(r.choice([32, 64, 128])),
                  "WL_LONG_W": int(r.choice([0, 1, 2, 4])), "WL_LONG_TJ": int(r.choice([16, 22, 64, 128])),
-                 "WL_TILEB": int(r.integers(0, 2)), "WL_TILEB_MIN": int(r.choice([0, 1 << 21])), "WL_TILEB_MAX": int(r.choice([2048, 4096]))}
+                 "WL_INV_PAIR_MIN": int(r.choice([0, 1 << 24])), "WL_TILE_INV": int(r.integers(0, 2)), "WL_TILEB": int(r.integers(0, 2)), "WL_TILEB_MIN": int(r.choice([0, 1 << 21])), "WL_TILEB_MAX": int(r.choice([2048, 4096]))}
     if lifting and nd == 2 and r.random() < 0.35:              # the marching level kernels instead of the 64 x 64 tiles
         knobs = {"WL_LIFT_TILE": 0}
     for k, v in knobs.items():

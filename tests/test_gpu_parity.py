@@ -214,6 +214,33 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.idwtc(dev(W, ym), wt, 4)), oracle.dwtc_filter(ym, wt.qmf, 4, fw=False))
 
 
+def test_inverse_fused_pair_kernel(gpu, W, oracle):
+    """k_inv2d_pair (wl_inv.hip): levels 2 and 1 of a big Float32 reconstruction in one launch -- the level-2 output handed to the
+    level-1 waves through an LDS column ring.  By default only from 4096 x 4096 upwards; WL_INV_PAIR_MIN = 0 brings it down to sizes
+    the oracle checks bit for bit: every filter length it is instantiated for, square / wide / tall blocks, partial strips and
+    chunks (1536 x 1056, 3072 x 160), odd and even depths (the pair always ends at level 1).  10 taps keep the single-level kernel."""
+    W.set_option("WL_INV_PAIR_MIN", 0)
+    W.set_option("WL_TILE_INV", 0)
+    for shape, Ls in (((1024, 1024), (2, 3, 10)), ((2048, 512), (2, 4)), ((1024, 2048), (5,)), ((1536, 1056), (2,)), ((3072, 160), (2, 3))):
+        x = rng_array(shape, np.float32, sum(shape) + 1)
+        for fname in ("haar", "db2", "db3", "db4", "sym4", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                xr = host(W, W.idwt(dev(W, x), wt, L))
+                assert W.last_kernel() == ("k_inv2d_stream" if fname == "sym5" else "k_inv2d_pair"), (shape, fname, L, W.last_kernel())
+                assert np.array_equal(xr, oracle.dwt_filter(x, wt.qmf, L, fw=False)), (shape, fname, L)
+    # default dispatch at full size: the pair against two launches of the single-level kernel
+    import torch
+    xb = torch.randn(4096, 8192, generator=torch.Generator(device="cpu").manual_seed(3), dtype=torch.float32).cuda().t()
+    W.clear_options()
+    db4 = W.wavelet(W.WT.db4)
+    a = W.idwt(xb, db4, 12)
+    assert W.last_kernel() == "k_inv2d_pair"
+    W.set_option("WL_INV_PAIR", 0)
+    b = W.idwt(xb, db4, 12)
+    assert W.last_kernel() == "k_inv2d_stream" and torch.equal(a, b)
+
+
 def test_fused_level_pair_kernel(gpu, W, oracle):
     """k_fwd2d_stream2 (two 2-D levels per launch) is used from 4096^2 upwards by default; WL_FUSE2_MIN=0
     forces it on smaller blocks so that it can be checked bit for bit against the oracle and the generic

@@ -14,6 +14,7 @@
 // Arithmetic = the closed form of filtup! (wl_internal.h): x[o] = S + D with
 //   S = sum over m descending, (o-m) even, of h[m]*s[(o-m)/2];  D = sum over m ascending, (o+m-1) even, of g[m]*d[(o+m-1)/2]
 #include "wl_fast.h"
+#include "wl_dev.h"
 
 
 namespace wl {
@@ -810,6 +811,233 @@ static hipError_t launch_inv2d(hipStream_t st, const Taps<T> &taps, const T *x, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TWO fused 2-D inverse levels per launch (levels l+1 and l of a big Float32 block; the mirror of k_fwd2d_pair): the level-(l+1)
+// reconstruction -- the approximation quadrant of level l -- never goes to HBM.  A workgroup of three waves owns 4 VP = 448
+// output rows of level l and a chunk of TP output column pairs:
+//   * wave 0 runs the body of k_inv2d_stream on level l+1 for the 240 (VP + 128) approximation rows the other two waves need
+//     (two halo lanes per side: exactly the reach of the filter) and parks its output columns -- two per step -- in an 8-slot
+//     LDS column ring instead of storing them;
+//   * waves 1 and 2 run that body on level l for two adjacent strips of 2 VP rows; the scaling rows of their left-half columns
+//     come from the ring (one ds_read_b64 per step), the three detail quadrants from HBM as before.
+// Wave 0 makes one step per TWO barriers (dim-1 reconstruction of its raw columns | dim-2 combination + ring write), waves 1-2
+// one step per barrier, two barriers behind: ring column c is written before barrier 2 floor(c/2) + 1 and read after barrier
+// c + 2 - delta (delta = SH mod 2: the first ring column is the even column at or below p0 - SH).
+// Arithmetic: inv_column / inv_pair of the single-level kernel -- bit-identical to two launches of it.
+template <int F>
+struct InvPairArgs {
+    const float *x; int64_t ldx;        // coefficient array
+    const float *ll; int64_t ldl;       // reconstruction of level l+2 = approximation source of level l+1 (nullptr: x)
+    float *dst; int64_t ldd;            // level-l output, n0 x n1
+    int64_t n0, n1;
+    int TP;                             // level-l output column pairs per chunk (multiple of 8)
+    int nstrips, nchunks;
+    TapsI<float, F> tp;
+};
+
+template <int F, int MW>
+__global__ void __launch_bounds__(192, MW) k_inv2d_pair(InvPairArgs<F> a)
+{
+    typedef float T;
+    constexpr int PPL = 2, SH = (F - 2) / 2, HLB = inv2d_halo_lanes(SH, PPL), VP = (64 - 2 * HLB) * PPL, R = (SH <= 3) ? 4 : 8;
+    constexpr int HLA = (HLB == 0) ? 0 : 2;                 // (SH + 1) / 2 <= 2 lanes of reach; 64 - 2 HLA lanes x 4 rows = VP + 128
+    constexpr int RL = VP + 128 + 8, NSLOT = 8;
+    constexpr int DELTA = SH & 1, CA = (SH + 1) / 2;        // ring column 0 = level-l left-half column p0 - SH - DELTA = 2 (p0/2 - CA)
+    static_assert((64 - 2 * HLA) * 4 == VP + 128, "the level-(l+1) wave must cover both strips and their halo lanes");
+    __shared__ __attribute__((aligned(16))) T ring[NSLOT * RL];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int sA = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+    const int64_t h0 = a.n0 >> 1, h1 = a.n1 >> 1;           // level l: pairs per column / per row
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
+    const int S = (int)(pend - p0);                         // multiple of 8
+    const int TPA = (S + SH - 1 + DELTA) / 2 + 1;           // steps of the level-(l+1) wave: ring columns 0 .. S + SH - 1 + DELTA
+    const int NBAR = (SH + S + 2 > 2 * TPA) ? (SH + S + 2) : (2 * TPA);
+
+    if (wv == 0) {
+        // =============================== level l+1 -> ring ===============================
+        const int64_t h0a = h0 >> 1, h1a = h1 >> 1;
+        int64_t kw = (int64_t)sA * VP - HLB + (int64_t)(lane - HLA) * PPL;      // first coefficient pair of this lane (level l+1)
+        if (kw < 0) kw += h0a;
+        if (kw >= h0a) kw -= h0a;
+        if (kw >= h0a) kw = 0;                                                   // (lanes past the block: their rows are never read)
+        const bool park = lane >= HLA && lane < 64 - HLA;
+        const bool from_ll = (a.ll != nullptr);
+        const T *ls_base = (from_ll ? a.ll : a.x) + kw;
+        const int64_t ls_ld = from_ll ? a.ldl : a.ldx;
+        const T *ld_base = a.x + h0a + kw;
+        const T *rs_base = a.x + h1a * a.ldx + kw;
+        const T *rd_base = rs_base + h0a;
+        const int64_t p0a = (p0 >> 1) - CA;
+        T rLs[R][PPL], rLd[R][PPL], rRs[R][PPL], rRd[R][PPL];
+        T iS[R][2 * PPL], iD[R][2 * PPL];
+        auto load_raw = [&](const int64_t t, const int slot) __attribute__((always_inline)) {
+            int64_t js = p0a + t;
+            if (js < 0) js += h1a;
+            if (js >= h1a) js -= h1a;
+            int64_t jd = p0a + t + SH;
+            if (jd < 0) jd += h1a;
+            if (jd >= h1a) jd -= h1a;
+            ldn<T, PPL>(ls_base + js * ls_ld, rLs[slot]);
+            ldn<T, PPL>(ld_base + js * a.ldx, rLd[slot]);
+            ldn<T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
+            ldn<T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
+        };
+#pragma unroll
+        for (int c = 0; c < SH; ++c) load_raw(c - SH, (c - SH + R) % R);
+#pragma unroll
+        for (int c = 0; c < SH; ++c) {
+            inv_column<T, F, PPL>(rLs[(c - SH + R) % R], rLd[(c - SH + R) % R], a.tp, iS[(c - SH + R) % R]);
+            inv_column<T, F, PPL>(rRs[(c - SH + R) % R], rRd[(c - SH + R) % R], a.tp, iD[(c - SH + R) % R]);
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) load_raw(c, c);
+        for (int tb = 0; tb < TPA; tb += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int t = tb + u;
+                if (t < TPA) {                                               // (workgroup-uniform)
+                    inv_column<T, F, PPL>(rLs[u], rLd[u], a.tp, iS[u]);
+                    inv_column<T, F, PPL>(rRs[u], rRd[u], a.tp, iD[u]);
+                    if (t + R < TPA) load_raw(t + R, u);
+                    wg_lds_sync(true);                                       // barrier 2t
+                    T xe[2 * PPL], xo[2 * PPL];
+#pragma unroll
+                    for (int q = 0; q < 2 * PPL; ++q) {
+                        T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                        for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
+                        inv_pair<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+                    }
+                    if (park) {
+                        T *const c0 = ring + ((2 * t) & (NSLOT - 1)) * RL + 4 * (lane - HLA);
+                        stn<T, 4>(c0, xe);
+                        stn<T, 4>(c0 + RL, xo);                              // (2t + 1: the next slot, never the wrap -- NSLOT is even)
+                    }
+                    wg_lds_sync(true);                                       // barrier 2t + 1
+                }
+            }
+        }
+        for (int i = 2 * TPA; i < NBAR; ++i) wg_lds_sync(true);
+        return;
+    }
+
+    // =============================== level l, strips 2 sA and 2 sA + 1 ===============================
+    const int w = wv - 1;
+    const int64_t k0 = ((int64_t)2 * sA + w) * VP + (int64_t)(lane - HLB) * PPL;
+    int64_t kw = k0;
+    if (kw < 0) kw += h0;
+    if (kw >= h0) kw -= h0;
+    if (kw >= h0) kw = 0;
+    const bool store = lane >= HLB && lane < 64 - HLB && k0 < h0;
+    const T *ld_base = a.x + h0 + kw;
+    const T *rs_base = a.x + h1 * a.ldx + kw;
+    const T *rd_base = rs_base + h0;
+    const T *const lrow = ring + w * VP + PPL * lane;        // this lane's two scaling rows in a ring column
+    T rLd[R][PPL], rRs[R][PPL], rRd[R][PPL];
+    T iS[R][2 * PPL], iD[R][2 * PPL];
+    auto load_raw = [&](const int64_t t, T (&ld)[PPL], T (&rs)[PPL], T (&rd)[PPL]) __attribute__((always_inline)) {
+        int64_t js = p0 + t;
+        if (js < 0) js += h1;
+        int64_t jd = p0 + t + SH;
+        if (jd >= h1) jd -= h1;
+        ldn<T, PPL>(ld_base + js * a.ldx, ld);
+        ldn<T, PPL>(rs_base + jd * a.ldx, rs);
+        ldn<T, PPL>(rd_base + jd * a.ldx, rd);
+    };
+    T pLd[SH > 0 ? SH : 1][PPL], pRs[SH > 0 ? SH : 1][PPL], pRd[SH > 0 ? SH : 1][PPL];      // raw columns of the prologue steps
+#pragma unroll
+    for (int c = 0; c < SH; ++c) load_raw(c - SH, pLd[c], pRs[c], pRd[c]);
+#pragma unroll
+    for (int c = 0; c < R; ++c) load_raw(c, rLd[c], rRs[c], rRd[c]);
+    wg_lds_sync(true);                                       // barriers 0, 1
+    wg_lds_sync(true);
+    // step j (0 .. SH + S - 1) runs after barrier j + 2 and takes ring column j + DELTA
+#pragma unroll
+    for (int c = 0; c < SH; ++c) {
+        wg_lds_sync(true);
+        T sv[PPL];
+        ldn<T, PPL>(lrow + ((c + DELTA) & (NSLOT - 1)) * RL, sv);
+        inv_column<T, F, PPL>(sv, pLd[c], a.tp, iS[(c - SH + R) % R]);
+        inv_column<T, F, PPL>(pRs[c], pRd[c], a.tp, iD[(c - SH + R) % R]);
+    }
+    T *out = a.dst + 2 * k0;
+    for (int t0 = 0; t0 < S; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int t = t0 + u;
+            wg_lds_sync(true);                               // barrier SH + t + 2
+            T sv[PPL];
+            ldn<T, PPL>(lrow + ((t + SH + DELTA) & (NSLOT - 1)) * RL, sv);
+            inv_column<T, F, PPL>(sv, rLd[u], a.tp, iS[u]);
+            inv_column<T, F, PPL>(rRs[u], rRd[u], a.tp, iD[u]);
+            if (t + R < S) load_raw(t + R, rLd[u], rRs[u], rRd[u]);
+            T xe[2 * PPL], xo[2 * PPL];
+#pragma unroll
+            for (int q = 0; q < 2 * PPL; ++q) {
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
+                inv_pair<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+            }
+            if (store) {
+                const int64_t p = p0 + t;
+                stn<T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
+                stn<T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
+            }
+        }
+    }
+    for (int i = SH + S + 2; i < NBAR; ++i) wg_lds_sync(true);
+}
+
+bool inv2d_pair_ok(int F, int64_t n0, int64_t n1)
+{
+    // level l output n0 x n1; level l+1 output n0/2 x n1/2 must satisfy the single-level kernel's conditions too
+    // (10 taps: the two code paths together need 239 VGPRs -- two waves per SIMD -- and lose to two launches: 209 vs 188 us)
+    if (F < 2 || F > (int)opt("WL_INV_PAIR_FMAX", 8) || F > 10 || (F & 1)) return false;
+    return n0 >= 1024 && (n0 % 16) == 0 && n1 >= 64 && (n1 % 32) == 0 && n0 < ((int64_t)1 << 30);
+}
+
+template <int F>
+static hipError_t launch_inv2d_pair_f(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                                      float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    constexpr int SH = (F - 2) / 2, HLB = inv2d_halo_lanes(SH, 2), VP = (64 - 2 * HLB) * 2;
+    InvPairArgs<F> a;
+    a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
+    const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
+    a.nstrips = (int)((h0 + 2 * VP - 1) / (2 * VP));
+    int TP = i_env("WL_INVPAIR_TP", 64);
+    if (TP < 8 || (TP % 8) != 0) TP = 64;
+    while (TP > 16 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) < (int64_t)cu_count * 4) TP >>= 1;
+    a.TP = TP;
+    a.nchunks = (int)((h1 + TP - 1) / TP);
+    a.tp = shrink_i<float, F>(taps);
+    // four waves per SIMD: the 8-tap instance spills 18 VGPRs for it and is still far ahead of three waves without spills
+    // (8192^2 db4, both levels: 126 us against 175) -- like the single-level kernel this one is latency-bound per wave
+    constexpr int MW = (F <= 8) ? 4 : 2;
+    hipLaunchKernelGGL((k_inv2d_pair<F, MW>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(192), 0, st, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_inv2d_pair(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                                    float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    switch (taps.F) {
+    case 2: return launch_inv2d_pair_f<2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 4: return launch_inv2d_pair_f<4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 6: return launch_inv2d_pair_f<6>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 8: return launch_inv2d_pair_f<8>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 10: return launch_inv2d_pair_f<10>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 #define WL_DISPATCH_FI(F_, ...)                              \
     switch (F_) {                                            \
     case 2: { constexpr int FF = 2; __VA_ARGS__; } break;    \
@@ -908,6 +1136,25 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         Strides3 res_st = (l == 1) ? b.full : box_st;
         bool done = false;
 
+        // ---- big 2-D blocks: levels l and l-1 in one launch, the level-l reconstruction handed over through an LDS column ring ----
+        if constexpr (sizeof(T) == 4) {
+            // (l even: the pairs end at level 1, so the two biggest levels share a launch)
+            if (fastF && two_d && l >= 2 && (l % 2) == 0 && i_env("WL_INV_PAIR", 1) != 0 && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) &&
+                (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
+                int64_t n1[3];
+                level_box(b, l - 1, n1);                    // output extents of the shallower level
+                T *res1 = (l - 1 == 1) ? y : (pp ? w.B : w.A);
+                const int64_t r_ld = (l - 1 == 1) ? b.full.s[1] : n1[0];
+                if (n1[0] == 2 * n[0] && n1[1] == 2 * n[1] && n1[0] * n1[1] >= (int64_t)i_env("WL_INV_PAIR_MIN", 1 << 24) &&
+                    inv2d_pair_ok(F, n1[0], n1[1]) && (r_ld % VEC) == 0 && i_al16(res1)) {
+                    WL_TRYI(launch_inv2d_pair(st, taps, x, b.full.s[1], llsrc, llsrc_st.s[1], res1, r_ld, n1[0], n1[1], cu_count));
+                    dominant = "k_inv2d_pair";
+                    llsrc = res1; llsrc_st = dense_strides(n1); pp ^= 1;
+                    --l;                                     // two levels consumed
+                    continue;
+                }
+            }
+        }
         // ---- small 2-D blocks: two levels (l and l-1) per launch, LDS tiles (wl_tile.hip) ----
         if (fastF && two_d && path == 0 && l >= 2 && i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
             int64_t n1[3];

@@ -1,0 +1,112 @@
+"""Differential tests of the dispatch tiers against each other, on the device: every kernel family added for speed must give the
+bits of the family it replaces, on many more random shapes / depths / chunk lengths than the oracle-based parity tests can afford
+(those pin each family to the CPU oracle on a handful of shapes; a device-vs-device comparison costs milliseconds per case).
+Test infrastructure, not product code."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(torch, gen, shape, dtype):
+    # Julia (column-major) layout: a transposed view of a C-contiguous tensor
+    return torch.randn(shape[1], shape[0], generator=gen, dtype=dtype).cuda().t()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_inverse_pair_against_single_level_launches(gpu, W, seed):
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    hit = 0
+    for _ in range(60):
+        n0 = int(r.choice([1024, 1536, 2048, 2560, 3072, 4096]))
+        n1 = int(r.choice([64, 96, 160, 256, 512, 1056, 2048]))
+        if n0 * n1 > (1 << 23):
+            n1 = 256
+        wt = W.wavelet(getattr(W.WT, str(r.choice(["haar", "db2", "db3", "db4", "sym4"]))))
+        x = _rnd(torch, gen, (n0, n1), torch.float32)
+        L = int(r.integers(2, W.maxtransformlevels(x) + 1))
+        out = []
+        for on in (0, 1):
+            W.set_option("WL_INV_PAIR", on)
+            W.set_option("WL_INV_PAIR_MIN", 0)
+            W.set_option("WL_TILE_INV", int(r.integers(0, 2)) if on else 0)
+            W.set_option("WL_INVPAIR_TP", int(r.choice([16, 32, 64])))
+            out.append(W.idwt(x, wt, L))
+            hit += int(on and W.last_kernel() == "k_inv2d_pair")
+        W.clear_options()
+        assert torch.equal(out[0], out[1]), (n0, n1, L)
+    assert hit >= 20            # (the comparison must not be vacuous)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_lifting_tiles_against_marching_kernels(gpu, W, seed):
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    hit = 0
+    for _ in range(60):
+        n = int(r.choice([128, 192, 256, 320, 384, 512, 640, 1024, 1280, 2048]))
+        dt = torch.float32 if r.random() < 0.7 else torch.float64
+        sch = W.wavelet(getattr(W.WT, str(r.choice(["cdf97", "db2", "haar"]))), W.WT.Lifting)
+        x = _rnd(torch, gen, (n, n), dt)
+        L = int(r.integers(1, W.maxtransformlevels(x) + 1))
+        out = []
+        for on in (0, 1):
+            W.set_option("WL_LIFT_TILE", on)
+            W.set_option("WL_LIFT_TP", int(r.choice([0, 8, 24, 40, 64])))
+            y = W.dwt(x, sch, L)
+            hit += int(on and W.last_kernel() == "k_lift2d_tile")
+            out.append((y, W.idwt(y, sch, L)))
+        W.clear_options()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (n, dt, L)
+    assert hit >= 20
+
+
+@pytest.mark.parametrize("seed", [5])
+def test_forward_tile_and_pair_tiers_against_single_levels(gpu, W, seed):
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    seen = set()
+    for _ in range(60):
+        n0 = int(r.choice([512, 1024, 2048, 4096]))
+        n1 = int(r.choice([256, 512, 1024, 2048]))
+        wt = W.wavelet(getattr(W.WT, str(r.choice(["haar", "db2", "db3", "db4", "sym5"]))))
+        x = _rnd(torch, gen, (n0, n1), torch.float32)
+        L = int(r.integers(2, W.maxtransformlevels(x) + 1))
+        out = []
+        pair = r.random() < 0.5          # this case: the fused pair (which the no-staging tile kernel would pre-empt) or that tile kernel
+        for on in (0, 1):
+            W.set_option("WL_TILEB", int(on and not pair))
+            W.set_option("WL_TILEB_MIN", 0)
+            W.set_option("WL_TILEB_MAX", 4096)
+            W.set_option("WL_LDS_PAIR_MIN", 0 if (on and pair) else (1 << 62))
+            out.append(W.dwt(x, wt, L))
+            if on:
+                seen.add(W.last_kernel())
+        W.clear_options()
+        assert torch.equal(out[0], out[1]), (n0, n1, L)
+    assert "k_fwd2d_tileB" in seen and "k_fwd2d_pair" in seen
+
+
+def test_ti_denoise_fused_tiers_against_separate_passes(gpu, W):
+    """batched fused pair + thresholds applied at the stores, against level-by-level launches and the separate threshold pass"""
+    import torch
+    r = np.random.default_rng(6)
+    gen = torch.Generator(device="cpu").manual_seed(106)
+    for _ in range(16):
+        n = int(r.choice([512, 1024]))
+        wt = W.wavelet(getattr(W.WT, str(r.choice(["db2", "db4", "sym5"]))))
+        x = _rnd(torch, gen, (n, n), torch.float32)
+        nspin = (int(r.integers(1, 5)), int(r.integers(1, 5)))
+        L = int(r.integers(1, 7))
+        out = []
+        for on in (0, 1):
+            W.set_option("WL_PAIR_BATCH", on)
+            W.set_option("WL_PAIR_BATCH_MIN", 0)
+            W.set_option("WL_TI_FUSE_TH", on)
+            out.append(W.denoise(x, wt, L=L, TI=True, nspin=nspin))
+        W.clear_options()
+        assert torch.equal(out[0], out[1]), (n, nspin, L)

@@ -209,6 +209,26 @@ __device__ __forceinline__ void wait_vm(V &a, V &b)
 {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
+// The same wait with the count chosen by a wave-uniform flag at run time: vmcnt(N) when flag != 0, vmcnt(0) otherwise.  The
+// branch lives INSIDE the asm statement for the reason gload16_if exists: a C++ `if` around two wait_vm calls makes the ring
+// registers phis, and hipcc placed the phi copies of the drain side BEFORE its s_waitcnt (k_fwd2d_lds_long up to round 3:
+// found by tools/isa_check.py) -- a copy of a register whose load may still be in flight.
+template <int N, typename V>
+__device__ __forceinline__ void wait_vm_sel(V &a, V &b, int flag)
+{
+    asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lwl_drain%=\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lwl_waited%=\n"
+                 ".Lwl_drain%=:\n\ts_waitcnt vmcnt(0)\n.Lwl_waited%=:"
+                 : "+v"(a), "+v"(b) : "n"(N), "s"(flag) : "memory", "scc");
+}
+// Every outstanding load has landed before any of the R registers of a ring is read, copied or reused.  For the kernels whose
+// march ends without a consuming step (2 taps: the steps past the chunk neither load nor produce), so that the last prefetches
+// -- columns nobody needs -- cannot land in registers the compiler has meanwhile given to something else.
+template <int R, typename V>
+__device__ __forceinline__ void drain_ring(V (&ring)[R])
+{
+#pragma unroll
+    for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
+}
 
 
 }  // namespace wl

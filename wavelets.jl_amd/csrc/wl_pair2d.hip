@@ -274,6 +274,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
 #pragma unroll
             for (int u = 0; u < U; ++u) hstep(t0 + u, u, true, true, true);
         }
+        if constexpr (F == 2) drain_ring(hring);           // (see the main waves)
 #pragma unroll
         for (int u = 0; u < F; ++u) hstep(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
         return;
@@ -425,7 +426,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         for (int u = 0; u < U; ++u) step(t0 + u, u, true, true, true);
     }
     // F steps past the chunk: columns S_own .. S_own+F-3 of the approximation feed the last level-(l+1) columns; loads are needed
-    // up to step S_own + F - 3 (requested PFD steps ahead)
+    // up to step S_own + F - 3 (requested PFD steps ahead).  2 taps: none of these steps waits for a load, yet the last PFD
+    // steps' prefetches (columns nobody needs) are still on their way -- they must not land in registers the compiler reuses
+    if constexpr (F == 2) drain_ring(ring);
 #pragma unroll
     for (int u = 0; u < F; ++u) step(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
 }

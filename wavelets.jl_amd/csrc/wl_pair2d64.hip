@@ -245,6 +245,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
 #pragma unroll
         for (int u = 0; u < U; ++u) step(t0 + u, u, true, true, true);
     }
+    // 2 taps: none of the steps below waits for a load, yet the last PFD steps' prefetches are still on their way
+    if constexpr (F == 2) drain_ring(ring);
 #pragma unroll
     for (int u = 0; u < F; ++u) step(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
 }

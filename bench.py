@@ -46,8 +46,9 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r03"      # profiles/<round>_c3_kernel_stats.csv is the committed rocprofv3 summary of this command
-NROT = 3                   # distinct input arrays the timed steps rotate over
+PROFILE_ROUND = "r04"      # profiles/<round>_<config>_kernel_stats.csv are the committed rocprofv3 summaries of these commands
+NROT = 3                   # distinct input arrays the timed steps rotate over (8192^2: 3 x 256 MiB > the 256 MiB Infinity Cache)
+NROT_1D = 5                # ... for the 64 MiB 1-D configs (5 x 64 MiB in + 64 MiB out > 256 MiB)
 
 
 def parse():
@@ -216,6 +217,9 @@ class HipBackend:
     def dwtc(self, y, x):
         self.W.dwtc_(y, x, self.db4, 16)
 
+    def dwtc_levels(self, y, x, L):
+        self.W.dwtc_(y, x, self.db4, L)
+
     def dwt2(self, y, x):
         self.W.dwt_oop_(y, x, self.db4, 13)
 
@@ -283,36 +287,67 @@ def rccl_info(dist, device, backend_name):
     return info
 
 
-def multi_gpu_line(args, rank, world, dist, sharding, device, backend):
-    """--gpus N > 1: the sharded C5 batch is the top-level metric; the C3 weak-scaling figure is nested."""
+def c5_roofline(backend, x, y, ncol, rank, dist, sharding, device):
+    """`roofline` of the C5 line: the first pass of every rank's shard -- k_fwd1d_multi, levels 1-4 in one launch (an L = 4 call is
+    exactly that launch): it reads the shard once and writes it once = 8 B/sample.  Per-rank figure (HIP events on the launch
+    stream around a back-to-back train, median of chunks); the line carries rank 0's and the slowest rank's duration."""
+    if backend.name == "stub":
+        return {"bound": "hbm", "kernel": "stub-copy", "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                "note": "stub run: not measured"}
+    ms = _event_train_ms([lambda: backend.dwtc_levels(y, x, 4)], 20, chunk=5)
+    kname = backend.kernel()
+    ms_max = sharding.max_over_ranks(ms, dist, device)
+    alg = 2 * ncol * (1 << 16) * 4
+    ach = alg / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": f"{kname} (first launch of every shard: levels 1-4)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+           "avg_launch_ms": round(ms, 5), "avg_launch_ms_slowest_rank": round(ms_max, 5), "per": "rank (one GPU)", "signals_in_launch": ncol,
+           "timing": "HIP events on the launch stream inside a back-to-back train of 20 launches (median of chunks of 5), rank 0",
+           "traffic_note": "traffic: see profiles/pmc_c5.json (8192-signal shard, static)"}
+    pmc = os.path.join(ROOT, "profiles", "pmc_c5.json")
+    if os.path.exists(pmc):
+        try:
+            j = json.load(open(pmc))
+            if j.get("kernel_short") == kname and j.get("signals_in_launch"):
+                out["traffic"] = int(j["hbm_bytes_per_launch"] * (ncol / j["signals_in_launch"]))
+                out["traffic_note"] = j.get("note", "") + f" (static: profiles/pmc_c5.json, scaled from {j['signals_in_launch']} to {ncol} signals)"
+        except Exception:
+            pass
+    rp = _rocprof_summary(kname, "c5")
+    if rp is not None:
+        rp["note"] = "8192-signal shard (the per-GPU shard at 8 GPUs)"
+        rp["achieved"] = round(2 * 8192 * (1 << 16) * 4 / (rp["avg_launch_ms"] * 1e-3) / 1e9, 1)
+        rp["frac"] = round(rp["achieved"] / HBM_PEAK_GBPS, 4)
+        out["rocprof"] = rp
+    return out
+
+
+def multi_gpu_line(args, rank, world, dist, sharding, device, backend, steps=None, warm=None, nested=True):
+    """The sharded C5 batch as the top-level metric: `--gpus N > 1`, `--gpus 1 --workload c5`, and (with few steps) the
+    `c5_batched` object of the one-GPU C3 line -- the same keys everywhere, so the N = 1 point and the N > 1 points of the
+    scaling curve compare like for like.  nested: also report the C3 weak-scaling figure (every rank its own image) and, for
+    N > 1, the whole batch on rank 0 alone measured in the SAME job."""
     n = 1 << 16
+    steps = args.steps if steps is None else steps
     lo, hi = sharding.shard_range(args.c5_signals, rank, world)
     ncol = hi - lo
     x, y = backend.make_shard(ncol, 4242 + 1000 * rank)
-    warm = min(args.warmup, 20)          # a 16 GiB / N shard per step: a handful of warm-up steps reach steady clocks
-    dt = timed_steps(lambda i: backend.dwtc(y, x), backend, dist, sharding, device, args.steps, warm)
+    warm = min(args.warmup, 20) if warm is None else warm   # a 16 GiB / N shard per step: a handful of warm-up steps reach steady clocks
+    dt = timed_steps(lambda i: backend.dwtc(y, x), backend, dist, sharding, device, steps, warm)
     kernel = backend.kernel()
     checksum = sharding.sum_over_ranks(float(y.double().sum().item()), dist, device)
     cols = sharding.sum_over_ranks(float(ncol), dist, device)
     total = args.c5_signals * n
-    ms = dt / args.steps * 1e3
-    value = total / (dt / args.steps) / 1e6
+    ms = dt / steps * 1e3
+    value = total / (dt / steps) / 1e6
+    roof = c5_roofline(backend, x, y, ncol, rank, dist, sharding, device)
     del x, y
     if backend.name == "hip":
         backend.W.destroy_contexts()
         torch.cuda.empty_cache()
-    # nested: every rank its own 8192 x 8192 image, rotating over NROT inputs (weak scaling of independent images)
-    imgs = [backend.make_image(42 + 1000 * rank + 17 * j) for j in range(NROT)]
-    yout = imgs[0][1]
-    steps3 = max(20, min(args.steps * 10, 200))
-    dt3 = timed_steps(lambda i: backend.dwt2(yout, imgs[i % NROT][0]), backend, dist, sharding, device, steps3, min(args.warmup * 10, 100),
-                      precondition=100 if backend.name == "hip" else 0)
-    k3 = backend.kernel()
-    ms3 = dt3 / steps3 * 1e3
-    nimg = imgs[0][0].numel()
     out = {
         "metric": "Msamples/s, batched column-wise db4 dwt 65536 x 2^16 f32 sharded over the GPUs (BASELINE.json configs[4])",
-        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warm,
         "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (standard normal, generated on each device, seed 4242 + 1000*rank), resident in HBM",
         "config": {"workload": f"batched column-wise dwt db4 {args.c5_signals} x 2^16 f32, L=16, {world} shards",
@@ -321,13 +356,43 @@ def multi_gpu_line(args, rank, world, dist, sharding, device, backend):
                    "collectives": "1 broadcast of the taps (256 B), MAX / SUM all-reduces of 8 B; no signal data crosses GPUs",
                    "kernel": kernel, "gpus_requested": args.gpus, "warmup_requested": args.warmup},
         "gpus_requested": args.gpus,
-        "achieved_hbm_GBps_algorithmic": round(8.0 * total / (dt / args.steps) / 1e9, 1),
+        "achieved_hbm_GBps_algorithmic": round(8.0 * total / (dt / steps) / 1e9, 1),
+        "hbm_frac_whole_transform_per_gpu": round(8.0 * total / (dt / steps) / 1e9 / world / HBM_PEAK_GBPS, 4),
         "checksum_all_ranks": checksum, "c5_signals_covered": cols,
+        "roofline": roof,
         "rccl": rccl_info(dist, device, backend.name),
-        "c3_weak_scaling": {"workload": "2-D dwt db4 filter 8192x8192 f32, L=13, one independent image per GPU", "scaling": "weak",
-                            "steps": steps3, "ms_per_step": round(ms3, 5), "value": round(world * nimg / ms3 / 1e3, 1),
-                            "unit": "Msamples/s", "kernel": k3, "inputs_rotated": NROT},
     }
+    if nested and world > 1 and backend.name == "hip":
+        # the N = 1 point of the same curve, measured in this job: rank 0 alone transforms the WHOLE batch (16 GiB in, 16 GiB out,
+        # 16 GiB workspace) while the other ranks wait at the barrier
+        single = None
+        if rank == 0:
+            try:
+                xa, ya = backend.make_shard(args.c5_signals, 4242)
+                med, mn, _ = _event_each_ms([lambda: backend.dwtc(ya, xa)], 6, warm=2, warm_ms=0.0)
+                single = {"workload": "the whole batch on rank 0 alone", "ms_per_step_median": round(med, 4), "ms_per_step_min": round(mn, 4),
+                          "Msamples_per_s": round(total / med / 1e3, 1), "speedup_of_this_line": round(med / ms, 3)}
+                del xa, ya
+                backend.W.destroy_contexts()
+                torch.cuda.empty_cache()
+            except Exception as e:                        # pragma: no cover  (e.g. not enough free HBM on rank 0)
+                single = {"error": type(e).__name__}
+        if dist is not None:
+            dist.barrier()
+        out["single_gpu_same_batch"] = single
+    if nested:
+        # every rank its own 8192 x 8192 image, rotating over NROT inputs (weak scaling of independent images)
+        imgs = [backend.make_image(42 + 1000 * rank + 17 * j) for j in range(NROT)]
+        yout = imgs[0][1]
+        steps3 = max(20, min(steps * 10, 200))
+        dt3 = timed_steps(lambda i: backend.dwt2(yout, imgs[i % NROT][0]), backend, dist, sharding, device, steps3, min(args.warmup * 10, 100),
+                          precondition=100 if backend.name == "hip" else 0)
+        k3 = backend.kernel()
+        ms3 = dt3 / steps3 * 1e3
+        nimg = imgs[0][0].numel()
+        out["c3_weak_scaling"] = {"workload": "2-D dwt db4 filter 8192x8192 f32, L=13, one independent image per GPU", "scaling": "weak",
+                                  "steps": steps3, "ms_per_step": round(ms3, 5), "value": round(world * nimg / ms3 / 1e3, 1),
+                                  "unit": "Msamples/s", "kernel": k3, "inputs_rotated": NROT}
     if backend.name == "stub":
         out["stub"] = True
         out["metric"] = "STUB (launcher test, no transform ran): " + out["metric"]
@@ -381,8 +446,10 @@ def main():
     gc.freeze()
     gc.disable()
 
-    if world > 1 and args.workload is None:
-        out = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device))
+    if (world > 1 and args.workload is None) or args.workload == "c5":
+        # the sharded C5 batch: the metric of every N > 1 line, and of `--gpus 1 --workload c5` (the like-for-like N = 1 point)
+        out = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device),
+                             steps=(args.steps if world > 1 else min(args.steps, 60)), nested=(args.workload is None))
         if rank == 0 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_leg(W, "c5", W.wavelet(W.WT.db4), 16)
         finish(out, rank, dist)
@@ -444,17 +511,22 @@ def main():
     if rank == 0 and workload == "c3" and not args.no_depths:
         out["by_depth"] = by_depth_leg(W, xs, yout, wt, esize)
     if rank == 0:
-        out["roofline"] = roofline_leg(W, xs, wt, batched, esize, args, kernel)
+        out["roofline"] = roofline_leg(W, xs, wt, batched, esize, max(20, min(args.steps, 200)), kernel, tag=workload,
+                                       live_pmc=(world == 1 and workload == "c3"))
     if rank == 0 and world == 1 and not batched and not args.no_pipelined:
         out["pipelined"] = pipelined_leg(W, xs, wt, L, args)
     if workload == "c3" and world == 1 and not args.no_c5:
         del yout, xs, x
         torch.cuda.empty_cache()
-        out["c5_batched"] = c5_one_gpu_leg(W, device, args)
+        out["c5_batched"] = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device),
+                                           steps=8, warm=2, nested=False)
+        out["c5_batched"]["note"] = ("the N = 1 point of the multi-GPU curve: the same object `--gpus N` prints as its top level "
+                                     "(8 steps here; `--gpus 1 --workload c5` runs it with --steps)")
     if rank == 0 and world == 1 and workload == "c3" and not args.no_secondary:
         xs = x = yout = None
         torch.cuda.empty_cache()
         out["secondary_configs"] = secondary_leg(W, device)
+        out["reference_gpu_benchmark_shapes"] = reference_shapes_leg(W, device)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_leg(W, workload, wt, L)
     finish(out, rank, dist)
@@ -490,26 +562,6 @@ def by_depth_leg(W, xs, yout, wt, esize):
     return res
 
 
-def c5_one_gpu_leg(W, device, args):
-    """The whole C5 batch (65536 x 2^16 f32 = 16 GiB in, 16 GiB out, 16 GiB workspace) on ONE GPU: the N = 1 point of the
-    multi-GPU curve (`--gpus N` reports the same batch sharded N ways as its top-level value)."""
-    n = 1 << 16
-    _, x, wt, L, _ = make_workload(W, "c5", device, 4242, ncols=args.c5_signals)
-    y = W.similar(x)
-    W.reserve_workspace(x, L)
-    fn = lambda: W.dwtc_(y, x, wt, L)
-    med, mn, mean = _event_each_ms([fn], 8, warm=2)
-    kernel = W.last_kernel()
-    total = args.c5_signals * n
-    del x, y
-    W.destroy_contexts()                     # (the batch's workspace)
-    torch.cuda.empty_cache()
-    return {"workload": f"batched column-wise dwt db4, {args.c5_signals} signals x 2^16 f32, L=16, one GPU",
-            "signals_total": args.c5_signals, "reps": 8, "ms_per_step_median": round(med, 4), "ms_per_step_min": round(mn, 4),
-            "Msamples_per_s": round(total / med / 1e3, 1), "aggregate_algorithmic_GBps": round(8.0 * total / med / 1e6, 1),
-            "frac": round(8.0 * total / med / 1e6 / HBM_PEAK_GBPS, 4), "kernel": kernel}
-
-
 def pipelined_leg(W, xs, wt, L, args, nstreams=4):
     """Reported beside `value`, never instead of it: the same K transforms issued round-robin on `nstreams` HIP streams
     (one library context and one output array per stream).  Independent transforms -- a sequence of images -- overlap the
@@ -539,63 +591,125 @@ def pipelined_leg(W, xs, wt, L, args, nstreams=4):
 def secondary_leg(W, device, reps=20):
     """Device-timed runs of the other BASELINE.json configs and of the section-8(f) rows (parity-test configs, not the
     headline).  Protocol: untimed conditioning calls (5, then enough to fill 40 ms of device time), then `reps` calls enqueued
-    back to back with ONE HIP EVENT PAIR PER CALL; the
-    figure is the MEDIAN (the minimum is printed beside it), so a single hiccup -- a host garbage collection, a first-use
-    code-object load -- cannot poison it."""
+    back to back with ONE HIP EVENT PAIR PER CALL; the figure is the MEDIAN (the minimum is printed beside it), so a single
+    hiccup -- a host garbage collection, a first-use code-object load -- cannot poison it.
+    Cache-cold by construction (round 4): every leg rotates over distinct inputs whose total size exceeds the 256 MiB
+    Infinity Cache -- 5 arrays for the 64 MiB 1-D configs, 3 for the 256 MiB 2-D ones -- as the headline does; `inputs_rotated`
+    is printed with every figure.  C2 / C4 also carry a `roofline` object of their dominant kernel (same schema as the
+    headline's)."""
     res = []
 
-    def run(label, L, dtag, x, fn, alg_bytes):
+    def run(label, L, dtag, xs, mkfn, alg_bytes, roofline=None):
+        x = xs[0]
         W.reserve_workspace(x, L, full=True) if _reserve_has_full(W) else W.reserve_workspace(x, L)
-        med, mn, mean = _event_each_ms([fn], reps)
-        res.append({"workload": label, "L": int(L), "dtype": dtag, "reps": reps, "ms_per_step": round(med, 5), "ms_min": round(mn, 5),
-                    "ms_mean": round(mean, 5), "Msamples_per_s": round(x.numel() / med / 1e3, 1),
-                    "algorithmic_GBps": round(alg_bytes / med / 1e6, 1), "frac": round(alg_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
-                    "kernel": W.last_kernel()})
+        med, mn, mean = _event_each_ms([mkfn(t) for t in xs], reps)
+        row = {"workload": label, "L": int(L), "dtype": dtag, "reps": reps, "inputs_rotated": len(xs), "ms_per_step": round(med, 5),
+               "ms_min": round(mn, 5), "ms_mean": round(mean, 5), "Msamples_per_s": round(x.numel() / med / 1e3, 1),
+               "algorithmic_GBps": round(alg_bytes / med / 1e6, 1), "frac": round(alg_bytes / med / 1e6 / HBM_PEAK_GBPS, 4),
+               "kernel": W.last_kernel()}
+        if roofline is not None:
+            row["roofline"] = roofline(row["kernel"])
+        res.append(row)
 
-    for name in ("c1", "c2", "c4", "c5"):
-        label, x, wt, L, dtag = make_workload(W, name, device, 42)
-        y = W.similar(x)
-        fn = (lambda: W.dwtc_(y, x, wt, L)) if name == "c5" else (lambda: W.dwt_oop_(y, x, wt, L))
-        run(label, L, dtag, x, fn, 2 * x.numel() * x.element_size())
-        del x, y
+    for name in ("c1", "c2", "c4"):
+        made = [make_workload(W, name, device, 42 + 17 * j) for j in range(NROT_1D)]
+        label, _, wt, L, dtag = made[0]
+        xs = [m[1] for m in made]
+        y = W.similar(xs[0])
+        rf = None
+        if name in ("c2", "c4"):
+            rf = (lambda kern, xs=xs, wt=wt, name=name: roofline_leg(W, xs, wt, False, xs[0].element_size(), 100, kern, tag=name))
+        run(label, L, dtag, xs, (lambda t, y=y, wt=wt, L=L: (lambda: W.dwt_oop_(y, t, wt, L))), 2 * xs[0].numel() * xs[0].element_size(), rf)
+        del xs, y, made
         torch.cuda.empty_cache()
     # the inverse of the headline config and the section 8(f) rows (3-D, modwt, denoise), same protocol
     g = torch.Generator(device="cpu").manual_seed(7)
     db4 = W.wavelet(W.WT.db4)
-    x2 = torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t()
-    y2 = W.similar(x2)
-    a2 = 2 * x2.numel() * 4
-    run("2-D idwt db4 filter 8192x8192 f32", 13, "f32", x2, lambda: W.idwt_oop_(y2, x2, db4, 13), a2)
+    x2s = [torch.randn(8192, 8192, generator=g, dtype=torch.float32).to(device).t() for _ in range(NROT)]
+    y2 = W.similar(x2s[0])
+    a2 = 2 * x2s[0].numel() * 4
+    run("2-D idwt db4 filter 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.idwt_oop_(y2, t, db4, 13)), a2)
+    sym5 = W.wavelet(W.WT.sym5)
+    run("2-D idwt sym5 (10 taps, the reference's DEFAULT_WAVELET) filter 8192x8192 f32", 13, "f32", x2s,
+        lambda t: (lambda: W.idwt_oop_(y2, t, sym5, 13)), a2)
     cdf = W.wavelet(W.WT.cdf97, W.WT.Lifting)
-    run("2-D dwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, cdf, 13), a2)
-    run("2-D idwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2, lambda: W.idwt_oop_(y2, x2, cdf, 13), a2)
+    run("2-D dwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.dwt_oop_(y2, t, cdf, 13)), a2)
+    run("2-D idwt cdf9/7 lifting 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.idwt_oop_(y2, t, cdf, 13)), a2)
     sym8 = W.wavelet(W.WT.sym8)
-    run("2-D dwt sym8 (16 taps) filter 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, sym8, 13), a2)
+    run("2-D dwt sym8 (16 taps) filter 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.dwt_oop_(y2, t, sym8, 13)), a2)
+    run("2-D idwt sym8 (16 taps) filter 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.idwt_oop_(y2, t, sym8, 13)), a2)
     batt6 = W.wavelet(W.WT.batt6)
-    run("2-D dwt batt6 (59 taps) filter 8192x8192 f32", 13, "f32", x2, lambda: W.dwt_oop_(y2, x2, batt6, 13), a2)
-    del x2, y2
+    run("2-D dwt batt6 (59 taps) filter 8192x8192 f32", 13, "f32", x2s, lambda t: (lambda: W.dwt_oop_(y2, t, batt6, 13)), a2)
+    del x2s, y2
     torch.cuda.empty_cache()
-    x2d = torch.randn(8192, 8192, generator=g, dtype=torch.float64).to(device).t()
-    y2d = W.similar(x2d)
-    run("2-D dwt db4 filter 8192x8192 f64", 13, "f64", x2d, lambda: W.dwt_oop_(y2d, x2d, db4, 13), 2 * x2d.numel() * 8)
+    x2d = [torch.randn(8192, 8192, generator=g, dtype=torch.float64).to(device).t() for _ in range(NROT)]
+    y2d = W.similar(x2d[0])
+    run("2-D dwt db4 filter 8192x8192 f64", 13, "f64", x2d, lambda t: (lambda: W.dwt_oop_(y2d, t, db4, 13)), 2 * x2d[0].numel() * 8)
+    run("2-D idwt db4 filter 8192x8192 f64", 13, "f64", x2d, lambda t: (lambda: W.idwt_oop_(y2d, t, db4, 13)), 2 * x2d[0].numel() * 8)
     del x2d, y2d
     torch.cuda.empty_cache()
-    x3 = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0)
-    y3 = W.similar(x3)
-    run("3-D dwt db4 filter 512^3 f32", 9, "f32", x3, lambda: W.dwt_oop_(y3, x3, db4, 9), 2 * x3.numel() * 4)
+    x3 = [torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0) for _ in range(2)]   # 2 x 512 MiB
+    y3 = W.similar(x3[0])
+    run("3-D dwt db4 filter 512^3 f32", 9, "f32", x3, lambda t: (lambda: W.dwt_oop_(y3, t, db4, 9)), 2 * x3[0].numel() * 4)
     del x3, y3
-    xm = torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device)
-    run("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, "f32", xm, lambda: W.modwt(xm, db4, 8), (1 + 9) * xm.numel() * 4)
+    xm = [torch.randn(1 << 24, generator=g, dtype=torch.float32).to(device) for _ in range(2)]     # (the 9 x 64 MiB output alone exceeds the cache)
+    run("1-D modwt db4 2^24 f32 (output 2^24 x 9)", 8, "f32", xm, lambda t: (lambda: W.modwt(t, db4, 8)), (1 + 9) * xm[0].numel() * 4)
     del xm
     # translation-invariant denoise (denoising.jl:36-67), default wavelet sym5, 8 x 8 spins as one device-resident batch:
     # 64 forward + 64 inverse transforms of the image per call; algorithmic bytes = (read + write) per spin and direction
-    xd = torch.randn(2048, 2048, generator=g, dtype=torch.float32).to(device).t()
+    xd = [torch.randn(2048, 2048, generator=g, dtype=torch.float32).to(device).t()]
     run("2-D denoise TI 8x8 spins sym5 2048x2048 f32 (64 dwt + 64 idwt, fused batch)", 6, "f32", xd,
-        lambda: W.denoise(xd, TI=True), 64 * 2 * 2 * xd.numel() * 4)
+        lambda t: (lambda: W.denoise(t, TI=True)), 64 * 2 * 2 * xd[0].numel() * 4)
     del xd
     W.destroy_contexts()
     torch.cuda.empty_cache()
     return res
+
+
+def reference_shapes_leg(W, device, reps=20):
+    """The reference's own GPU benchmark (benchmark/gpu_benchmark.jl:57-67,70-80,83-96,98-106,109-118,138-148; BASELINE.md
+    section 1): 1-D db4 dwt / idwt of 2^16, 2^18, 2^20 f32 with L = min(8, max); 1-D wpt / iwpt of 2^14, 2^16, 2^18 (full
+    tree); 2-D 512 / 1024 / 2048 with L = min(4, max); 3-D 32 / 64 / 128 with L = min(3, max); 1-D cdf9/7 lifting 2^16 ... 2^20.
+    Like the reference's harness these go through the ALLOCATING calls (dwt(x, wt, L): `similar` + transform) on ONE resident
+    input -- sizes at which a transform is launch-latency, not bandwidth: the figure that matters is microseconds per call."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    db4 = W.wavelet(W.WT.db4)
+    cdf = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    rows = []
+
+    def run(label, x, fn, L):
+        med, mn, _ = _event_each_ms([fn], reps, warm=5, warm_ms=10.0)
+        rows.append({"case": label, "L": L, "us_per_call": round(med * 1e3, 2), "us_min": round(mn * 1e3, 2),
+                     "Msamples_per_s": round(x.numel() / med / 1e3, 1), "kernel": W.last_kernel()})
+
+    for pw in (16, 18, 20):
+        x = torch.randn(1 << pw, generator=g, dtype=torch.float32).to(device)
+        L = min(8, W.maxtransformlevels(x))
+        run(f"1D filter dwt 2^{pw}", x, lambda: W.dwt(x, db4, L), L)
+        yc = W.dwt(x, db4, L)
+        run(f"1D filter idwt 2^{pw}", x, lambda: W.idwt(yc, db4, L), L)
+        run(f"1D lifting dwt 2^{pw}", x, lambda: W.dwt(x, cdf, L), L)
+        yl = W.dwt(x, cdf, L)
+        run(f"1D lifting idwt 2^{pw}", x, lambda: W.idwt(yl, cdf, L), L)
+    for pw in (14, 16, 18):
+        x = torch.randn(1 << pw, generator=g, dtype=torch.float32).to(device)
+        run(f"1D filter wpt 2^{pw}", x, lambda: W.wpt(x, db4), W.maxtransformlevels(x))
+        wp = W.wpt(x, db4)
+        run(f"1D filter iwpt 2^{pw}", x, lambda: W.iwpt(wp, db4), W.maxtransformlevels(x))
+    for n in (512, 1024, 2048):
+        x = torch.randn(n, n, generator=g, dtype=torch.float32).to(device).t()
+        L = min(4, W.maxtransformlevels(x))
+        run(f"2D filter dwt {n}x{n}", x, lambda: W.dwt(x, db4, L), L)
+        yc = W.dwt(x, db4, L)
+        run(f"2D filter idwt {n}x{n}", x, lambda: W.idwt(yc, db4, L), L)
+    for n in (32, 64, 128):
+        x = torch.randn(n, n, n, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0)
+        L = min(3, W.maxtransformlevels(x))
+        run(f"3D filter dwt {n}^3", x, lambda: W.dwt(x, db4, L), L)
+        yc = W.dwt(x, db4, L)
+        run(f"3D filter idwt {n}^3", x, lambda: W.idwt(yc, db4, L), L)
+    return {"source": "benchmark/gpu_benchmark.jl shapes (randn Float32, db4 / cdf9/7), allocating calls, one resident input, median of "
+                      f"{reps} event-timed calls", "rows": rows}
 
 
 def _reserve_has_full(W):
@@ -606,11 +720,11 @@ def _reserve_has_full(W):
         return False
 
 
-def _rocprof_summary(kname_substr):
+def _rocprof_summary(kname_substr, tag="c3"):
     """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this same
-    command (profiles/<round>_c3_kernel_stats.csv), so that the line can be checked against profiles/ without a GPU."""
+    command (profiles/<round>_<tag>_kernel_stats.csv), so that the line can be checked against profiles/ without a GPU."""
     import csv
-    rel = os.path.join("profiles", f"{PROFILE_ROUND}_c3_kernel_stats.csv")
+    rel = os.path.join("profiles", f"{PROFILE_ROUND}_{tag}_kernel_stats.csv")
     path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None
@@ -625,37 +739,99 @@ def _rocprof_summary(kname_substr):
             "avg_launch_ms": round(float(best["AverageNs"]) * 1e-6, 5)}
 
 
-def roofline_leg(W, xs, wt, batched, esize, args, main_kernel):
+# levels finished by ONE launch of the kernel that consumes the full-size input (an L = Ldom call is exactly that launch)
+DOMINANT_LEVELS = {"k_fwd2d_stream2": 2, "k_fwd2d_pair": 2, "k_fwd2d_pair64": 2, "k_fwd1d_multi": 4}
+
+
+def _measure_traffic_live(tag):
+    """HBM bytes per launch of the dominant kernel of config `tag`, measured NOW with rocprofv3 (--pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate passes with --kernel-trace only, through the torch-free harness tools/wlbench.bin), FETCH_SIZE
+    doubled (MI355X_MICROARCH.md: gfx950 counts half of the 16-B/lane coalesced reads).  None when rocprofv3 / the harness
+    are not there or a pass fails -- the caller then falls back to the committed collection and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("WL_BENCH_NO_LIVE_PMC") == "1" or shutil.which("rocprofv3") is None:
+        return None
+    harness = os.path.join(ROOT, "tools", "wlbench.bin")
+    rp = os.path.join(ROOT, "tools", "rp.sh")
+    if not (os.path.exists(harness) and os.path.exists(rp)):
+        return None
+    cases = {"c3": (["L=2"], "k_fwd2d_pair<8, 2, 1, 0>"),
+             "c2": (["n0=16777216", "n1=1", "L=4"], "k_fwd1d_multi<float, 8, 1>"),
+             "c5": (["dwtc=1", "n0=65536", "n1=8192", "L=4"], "k_fwd1d_multi<float, 8, 1>")}
+    if tag not in cases:
+        return None
+    argv, head = cases[tag]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="wl_pmc_")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "wavelets.jl_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+    env["RP_MAX_ITERS"] = "80"
+    try:
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, name)
+            subprocess.run(["bash", rp, d, "live", f"--kernel-trace --pmc {name}", harness] + argv + ["reps=12", "warm=3", "check=0"],
+                           env=env, timeout=90, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for h in hits:
+                for r in csv.DictReader(open(h)):
+                    if head in r["Kernel_Name"] and r["Counter_Name"] == name:
+                        vals.append(float(r["Counter_Value"]))
+            if len(vals) < 4:
+                return None
+            out[name] = (sum(vals) / len(vals), len(vals))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch = out["FETCH_SIZE"][0] * 1024 * 2
+    write = out["WRITE_SIZE"][0] * 1024
+    return {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),
+            "launches": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]], "kernel": head}
+
+
+def roofline_leg(W, xs, wt, batched, esize, reps, main_kernel, tag="c3", live_pmc=False):
     """Dominant kernel = the launch that consumes the full-size input.  Its algorithmic bytes are
     2*N*sizeof(T): it reads every input sample once and writes N coefficients (8 B/sample
-    f32) -- that holds for the single-level kernels and for the fused-pair kernel, which finishes TWO levels
-    in the same pass (3/4 N level-1 details + 1/4 N level-2 coefficients; the level-1 approximation never leaves the chip).
-    A call with L = 1 (L = 2 for the fused pair; L = 4 for the multi-level line kernel of the batched transform) is exactly
+    f32) -- that holds for the single-level kernels and for the fused kernels, which finish several levels in the same pass
+    (pair: 3/4 N level-1 details + 1/4 N level-2 coefficients; the level-1 approximation never leaves the chip).
+    A call with L = 1 (L = 2 for the fused pair; L = 4 for the multi-level line kernel) is exactly
     one launch of that kernel (its first-level template instance, which rocprofv3 --stats reports under its own name).
     `frac` uses HIP events on the launch stream around a train of such launches rotating over the inputs (live, this run);
-    `rocprof` repeats the computation from the committed rocprofv3 summary."""
-    Ldom = {"k_fwd2d_stream2": 2, "k_fwd2d_pair": 2, "k_fwd1d_multi": 4}.get(main_kernel, 1)
+    `rocprof` repeats the computation from the committed rocprofv3 summary; `traffic` = HBM bytes per launch from the PMC
+    counters: measured in this run when rocprofv3 is present (live_pmc), otherwise the committed collection."""
+    Ldom = DOMINANT_LEVELS.get(main_kernel, 1)
     x = xs[0]
     y1 = W.similar(x)
     mk = (lambda t: (lambda: W.dwtc_(y1, t, wt, Ldom))) if batched else (lambda t: (lambda: W.dwt_oop_(y1, t, wt, Ldom)))
     fns = [mk(t) for t in xs]
-    reps = max(20, min(args.steps, 200))
     train_ms = _event_train_ms(fns, reps)
     med_ms, min_ms, avg_ms = _event_each_ms(fns, reps, warm=3)
     kname = W.last_kernel()
     alg_bytes = 2 * x.numel() * esize
     achieved = alg_bytes / (train_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    note = "traffic: no PMC summary committed for this kernel yet"
-    if os.path.exists(pmc):
-        try:
-            j = json.load(open(pmc))
-            if j.get("kernel_short") == kname:
-                traffic = j.get("hbm_bytes_per_launch")
-                note = j.get("note", "") + " (static: read from the committed profiles/pmc_latest.json, not measured by this run)"
-        except Exception:
-            pass
+    traffic, note = None, "traffic: no PMC summary committed for this kernel yet"
+    live = _measure_traffic_live(tag) if live_pmc else None
+    if live is not None:
+        traffic = live["hbm_bytes_per_launch"]
+        note = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (--kernel-trace only) of "
+                f"tools/wlbench.bin on the same kernel ({live['kernel']}, {live['launches'][0]} / {live['launches'][1]} launches); FETCH_SIZE x2 per "
+                f"MI355X_MICROARCH.md (gfx950); fetch {live['fetch_bytes_corrected']} B + write {live['write_bytes']} B; "
+                f"traffic/algorithmic = {traffic / alg_bytes:.3f}")
+    else:
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json" if tag == "c3" else f"pmc_{tag}.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("kernel_short") == kname:
+                    traffic = j.get("hbm_bytes_per_launch")
+                    note = j.get("note", "") + f" (static: read from the committed profiles/{os.path.basename(pmc)}, not measured by this run)"
+            except Exception:
+                pass
     levels = {1: "level 1", 2: "levels 1-2", 4: "levels 1-4"}[Ldom]
     out = {"bound": "hbm", "kernel": f"{kname} (first launch: {levels})",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -666,11 +842,12 @@ def roofline_leg(W, xs, wt, batched, esize, args, main_kernel):
                                   "note": "one event pair per launch"},
            "launches_timed": reps, "traffic_note": note,
            "frac_of_measured_copy_6290GBps": round(achieved / 6290.0, 4)}
-    rp = _rocprof_summary(kname)
+    rp = _rocprof_summary(kname, tag)
     if rp is not None:
         rp["achieved"] = round(alg_bytes / (rp["avg_launch_ms"] * 1e-3) / 1e9, 1)
         rp["frac"] = round(rp["achieved"] / HBM_PEAK_GBPS, 4)
         out["rocprof"] = rp
+    del y1
     return out
 
 

@@ -24,6 +24,46 @@ struct P {
     int acq_all;            // every wave runs the acquire fence (1) or thread 0 only (0)
 };
 
+// ---- (d): the hand-over data (the 1/16 "approximation") travels with sc1 stores / loads (write-through to, and read from,
+// the memory side: visible to the other XCDs' L2s without a release fence = without writing back a whole L2) ----
+typedef float F4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1(float4 *p, float4 v)
+{
+    F4v w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ float4 ld_sc1(const float4 *p)
+{
+    F4v w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+    return make_float4(w.x, w.y, w.z, w.w);
+}
+template <bool IN_SC1>
+__device__ __forceinline__ void tile_phase_sc1(const float4 *in, float4 *yout, float4 *bout, int tid)
+{
+    float4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = IN_SC1 ? ld_sc1(in + tid + 256 * r) : in[tid + 256 * r];
+    float4 s;
+    s.x = v[0].x + v[1].x + v[2].x + v[3].x; s.y = v[0].y + v[1].y + v[2].y + v[3].y;
+    s.z = v[0].z + v[1].z + v[2].z + v[3].z; s.w = v[0].w + v[1].w + v[2].w + v[3].w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yout[tid + 256 * r] = v[r];
+    if (tid < 64) st_sc1(bout + tid, s);
+}
+__device__ __forceinline__ bool arrive_sc1(unsigned *c, unsigned expected, int tid)
+{
+    __shared__ unsigned last1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have reached the memory side
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last1 = (old == expected - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    return last1 != 0;
+}
+
 __device__ __forceinline__ void tile_phase(const float4 *in, float4 *yout, float4 *bout, int tid)
 {
     float4 v[4];
@@ -91,6 +131,36 @@ __global__ void __launch_bounds__(256) k_chain(P a)
     if (tid <= 64) a.cnt[tid] = 0;                     // self-cleaning: the next launch starts from zero
 }
 
+__global__ void __launch_bounds__(256) k_chain_sc1(P a)
+{
+    __shared__ float lds[256];
+    const int tid = threadIdx.x;
+    const unsigned t0 = blockIdx.x;
+    tile_phase_sc1<false>(a.src + (size_t)t0 * 1024, a.y + (size_t)t0 * 1024, a.b0 + (size_t)t0 * 64, tid);
+    const unsigned t1 = t0 >> 4;
+    if (!arrive_sc1(a.cnt + t1, 16, tid)) return;
+    tile_phase_sc1<true>(a.b0 + (size_t)t1 * 1024, a.y + (size_t)(1024 + t1) * 1024, a.b1 + (size_t)t1 * 64, tid);
+    if (!arrive_sc1(a.cnt + 64, 64, tid)) return;
+    {
+        float4 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ld_sc1(a.b1 + tid + 256 * r);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += v[r].x + v[r].y + v[r].z + v[r].w;
+        for (int p = 0; p < a.np; ++p) {
+            lds[tid] = acc;
+            __syncthreads();
+            acc = lds[(tid + 1) & 255] * 0.5f + lds[(tid + 3) & 255] * 0.25f;
+            __syncthreads();
+        }
+        float4 *yout = a.y + (size_t)(1024 + 64) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v[r].x += acc; yout[tid + 256 * r] = v[r]; }
+    }
+    if (tid <= 64) __hip_atomic_store(a.cnt + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // persistent variant: G workgroups, device-wide barrier between phases (sense = phase number * G)
 __device__ __forceinline__ void grid_barrier(unsigned *c, unsigned target, int tid)
 {
@@ -155,6 +225,15 @@ int main(int argc, char **argv)
             unsigned c[65]; CK(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost));
             unsigned bad = 0; for (int i = 0; i < 65; ++i) bad += c[i];
             printf("(b) one launch, last arriver (acquire by %s): %.2f us per chain (counters left: %u)\n", acq ? "every wave" : "thread 0", ms * 1000.f / reps, bad);
+        }
+        {
+            CK(hipMemset(cnt, 0, 1024));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_chain_sc1, dim3(1024), dim3(256), 0, st, a);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned c[65]; CK(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost));
+            unsigned bad = 0; for (int i = 0; i < 65; ++i) bad += c[i];
+            printf("(d) one launch, last arriver, sc1 hand-over data, no fences: %.2f us per chain (counters left: %u)\n", ms * 1000.f / reps, bad);
         }
         for (int G : {256, 1024}) {
             CK(hipMemsetAsync(cnt + 65, 0, 4, st));

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 setsid rocprofv3 $OPTS --output-format csv -d "$OUT" -o "$NAME" -- "$@" > "$OUT/$NAME.log" 2>&1 &
 PID=$!
 last=-1; stable=0
-for i in $(seq 1 240); do
+for i in $(seq 1 ${RP_MAX_ITERS:-240}); do
   sleep 0.5
   if ! kill -0 $PID 2>/dev/null; then break; fi
   sz=$(find "$OUT" -name "${NAME}_*.csv" -printf "%s+" 2>/dev/null)

@@ -80,7 +80,7 @@ function Transforms._dwt!(y::ROCArray{T,N}, x::ROCArray{T,N}, filter::OrthoFilte
                           fw::Bool) where {T<:Union{Float32,Float64},N}
     size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
     q = filter.qmf                                  # Float64 taps; converted to T inside, like makereverseqmfpair
-    check(ccall((:wl_dwt_filter, LIB), Cint,
+    GC.@preserve y x check(ccall((:wl_dwt_filter, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), q, length(q), L, fw, stream()))
     return y
@@ -96,7 +96,7 @@ function flatten(s::GLS)
 end
 function Transforms._dwt!(y::ROCArray{T,N}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64},N}
     isup, nc, sh, cf = flatten(scheme)
-    check(ccall((:wl_dwt_lifting, LIB), Cint,
+    GC.@preserve y check(ccall((:wl_dwt_lifting, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
                  Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), N, dims3(y), length(isup), isup, nc, sh, cf,
@@ -110,7 +110,7 @@ for (f, fw) in ((:dwt, true), (:idwt, false))
     @eval function Transforms.$f(x::ROCArray{T,N}, scheme::GLS, L::Integer=Util.maxtransformlevels(x)) where {T<:Union{Float32,Float64},N}
         y = similar(x)
         isup, nc, sh, cf = flatten(scheme)
-        check(ccall((:wl_dwt_lifting_oop, LIB), Cint,
+        GC.@preserve y x check(ccall((:wl_dwt_lifting_oop, LIB), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
                      Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
                     ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), length(isup), isup, nc, sh, cf,
@@ -124,7 +124,7 @@ function Transforms._wpt!(y::ROCVector{T}, x::ROCVector{T}, filter::OrthoFilter,
                           fw::Bool) where {T<:Union{Float32,Float64}}
     size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
     t = UInt8.(tree)
-    check(ccall((:wl_wpt_filter, LIB), Cint,
+    GC.@preserve y x check(ccall((:wl_wpt_filter, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{UInt8}, Int64, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(x), length(x), filter.qmf, length(filter.qmf), t, length(t), fw, stream()))
     return y
@@ -132,7 +132,7 @@ end
 function Transforms._wpt!(y::ROCVector{T}, scheme::GLS, tree::BitVector, fw::Bool) where {T<:Union{Float32,Float64}}
     isup, nc, sh, cf = flatten(scheme)
     t = UInt8.(tree)
-    check(ccall((:wl_wpt_lifting, LIB), Cint,
+    GC.@preserve y check(ccall((:wl_wpt_lifting, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
                  Cdouble, Cdouble, Ptr{UInt8}, Int64, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), length(y), length(isup), isup, nc, sh, cf, scheme.norm1, scheme.norm2,
@@ -144,7 +144,7 @@ end
 for (f, fw) in ((:dwtc, true), (:idwtc, false))
     @eval function $f(x::ROCMatrix{T}, filter::OrthoFilter, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T}
         y = similar(x)
-        check(ccall((:wl_dwtc_filter, LIB), Cint,
+        GC.@preserve y x check(ccall((:wl_dwtc_filter, LIB), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
                     ctx(), DT[T], pointer(y), pointer(x), size(x, 1), size(x, 2), size(x, 1),
                     filter.qmf, length(filter.qmf), L, $fw, stream()))
@@ -156,7 +156,7 @@ for (f, fw) in ((:dwtc, true), (:idwtc, false))
     @eval function $f(x::ROCMatrix{T}, scheme::GLS, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T<:Union{Float32,Float64}}
         y = similar(x)                              # out of place straight from x: no copy, no in-place staging
         isup, nc, sh, cf = flatten(scheme)
-        check(ccall((:wl_dwtc_lifting_oop, LIB), Cint,
+        GC.@preserve y x check(ccall((:wl_dwtc_lifting_oop, LIB), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
                      Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
                     ctx(), DT[T], pointer(y), pointer(x), size(y, 1), size(y, 2), size(y, 1), length(isup), isup, nc, sh, cf,
@@ -205,7 +205,7 @@ function Transforms.modwt(x::ROCVector{T}, wt::OrthoFilter, L::Integer=Util.maxm
     L >= 1 || throw(ArgumentError("L must be >= 1"))
     n = length(x)
     out = similar(x, n, L + 1)
-    check(ccall((:wl_modwt, LIB), Cint,
+    GC.@preserve out x check(ccall((:wl_modwt, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(out), n, pointer(x), n, wt.qmf, length(wt.qmf), L, stream()))
     return out
@@ -213,7 +213,7 @@ end
 function Transforms.imodwt(xw::ROCMatrix{T}, wt::OrthoFilter) where {T<:Union{Float32,Float64}}
     n, nc = size(xw)
     x = similar(xw, n)
-    check(ccall((:wl_imodwt, LIB), Cint,
+    GC.@preserve x xw check(ccall((:wl_imodwt, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Float64}, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(x), pointer(xw), n, n, nc, wt.qmf, length(wt.qmf), stream()))
     return x
@@ -228,35 +228,35 @@ const THCODE = Dict(HardTH => Cint(0), SoftTH => Cint(1), SemiSoftTH => Cint(2),
 t_is_f64(::Type{T}, t) where {T} = Cint(promote_type(T, typeof(t)) === Float64 && T !== Float64)
 function Threshold.threshold!(x::ROCArray{T}, th::Union{HardTH,SoftTH,SemiSoftTH,SteinTH}, t::Real) where {T<:Union{Float32,Float64}}
     @assert t >= 0
-    check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+    GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], Float64(t), t_is_f64(T, t), stream()))
     return x
 end
 function Threshold.threshold!(x::ROCArray{T}, th::Union{PosTH,NegTH}) where {T<:Union{Float32,Float64}}
-    check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+    GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], 0.0, Cint(0), stream()))
     return x
 end
 function Threshold.threshold!(x::ROCArray{T}, ::BiggestTH, m::Int) where {T<:Union{Float32,Float64}}
     @assert m >= 0
-    check(ccall((:wl_threshold_biggest, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+    GC.@preserve x check(ccall((:wl_threshold_biggest, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(x), length(x), m, stream()))
     return x
 end
 function Threshold.mad!(y::ROCArray{T}) where {T<:Union{Float32,Float64}}
     r = Ref{Cdouble}(0)
-    check(ccall((:wl_mad, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cvoid}),
+    GC.@preserve y check(ccall((:wl_mad, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), length(y), r, stream()))
     return T(r[])
 end
 function Util.circshift!(b::ROCVector{T}, a::ROCVector{T}, shift::Integer) where {T<:Union{Float32,Float64}}
-    check(ccall((:wl_circshift, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
+    GC.@preserve b a check(ccall((:wl_circshift, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(b), pointer(a), 1, Int64[length(a)], Int64[shift], stream()))
     return b
 end
 function Threshold.arrayadd!(y::ROCArray{T}, z::ROCArray{T}) where {T<:Union{Float32,Float64}}
     length(y) == length(z) || throw(DimensionMismatch("lengths must be equal"))
-    check(ccall((:wl_arrayadd, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+    GC.@preserve y z check(ccall((:wl_arrayadd, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(z), length(y), stream()))
     return y
 end
@@ -283,7 +283,7 @@ function Threshold.denoise(x::ROCArray{T,N}, wt::OrthoFilter=Threshold.DEFAULT_W
     estnoise === noisest || (sigma >= 0 && isfinite(sigma)) || throw(AssertionError("t >= 0"))   # threshold_main.jl:24
     y = similar(x)
     nsp = N == 1 ? Int64[prod(nspt), 1, 1] : Int64[nspt..., 1]      # vectors: prod(nspin) spins shifted by 0 .. pns-1 (denoising.jl:38-42)
-    check(ccall((:wl_denoise_ti_filter, LIB), Cint,
+    GC.@preserve y x check(ccall((:wl_denoise_ti_filter, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Cdouble, Ptr{Int64},
                  Cdouble, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), wt.qmf, length(wt.qmf), L, THCODE[typeof(dnt.th)],

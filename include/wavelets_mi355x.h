@@ -172,7 +172,9 @@ WL_API int wl_dwtc_lifting_oop(wl_ctx *ctx, int dtype, void *y, const void *x,
 
 /* ---- wavelet packet transform (1-D) --------------------------------------------------- */
 /* y = wpt(x, filter, tree) / iwpt.  tree: one byte per node of the BitVector
- * (length 2^maxtransformlevels(n) - 1, util_main.jl:301-344), HOST pointer.
+ * (length 2^maxtransformlevels(n) - 1, util_main.jl:301-344), HOST pointer; it is copied before the call returns (the node
+ * bits of partially split depths travel through a pinned staging buffer of the context) and the stream is NOT synchronised.
+ * A call with a partially split tree is not capturable in a hipGraph (its staging copy would be replayed with stale bits).
  * replaces _wpt!(y, x, filter, tree, fw) -- transforms_filter.jl:301-359.               */
 WL_API int wl_wpt_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n,
                   const double *qmf, int flen,
@@ -184,6 +186,18 @@ WL_API int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
                    const int32_t *step_shift, const double *coefs_flat,
                    double norm1, double norm2,
                    const uint8_t *tree, int64_t ntree, int fw, void *stream);
+
+/* wpt(x, wt, L::Integer) / iwpt(x, wt, L) / wpt!(y, x, filter, L) / wpt!(y, scheme, L): the FULL tree of depth L
+ * (= maketree(length(x), L, :full), transforms_main.jl:134-176) without a tree vector.  A tree of an n-sample signal has
+ * n - 1 nodes; building, validating and scanning it on the host costs more than the transform itself from a few 10^5
+ * samples on, and these entry points never look at one.  0 <= L <= maxtransformlevels(n), else WL_EINVAL_L.
+ * Same results as the tree forms with the full tree; no stream synchronisation; capturable in a hipGraph.              */
+WL_API int wl_wpt_filter_full(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n,
+                       const double *qmf, int flen, int L, int fw, void *stream);
+WL_API int wl_wpt_lifting_full(wl_ctx *ctx, int dtype, void *y, int64_t n,
+                        int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                        const int32_t *step_shift, const double *coefs_flat,
+                        double norm1, double norm2, int L, int fw, void *stream);
 
 /* ---- maximal-overlap DWT, 1-D -------------------------- */
 /* floor(log2(n)) -- replaces maxmodwttransformlevels, src/Util/non_dyadic.jl:24-25.        */

@@ -1285,6 +1285,68 @@ def test_wpt_bitexact(gpu, W, oracle, dtype):
         W.wpt(dev(W, x), wt, bad)
 
 
+def test_wpt_fast_paths_bitexact_and_pinned(gpu, W, oracle):
+    """Round 4: fully split depths run on k_wpt_fwd_multi (up to 3 depths per pass over HBM) and k_wpt_fwd_tail / k_wpt_inv_tail
+    (every depth of the segments that fit a workgroup in ONE launch), lifting depths on the fused line kernel -- bit-equal to the
+    oracle, and `last_kernel` pins that the fast tier actually ran (transforms_filter.jl:301-359, transforms_lifting.jl:283-319)."""
+    cases = [
+        # n, dtype, depth (None = maxtransformlevels), filters, expected forward kernel, expected inverse kernel
+        (1 << 18, np.float32, 6, ("db4", "haar"), "k_wpt_fwd_multi", "k_inv1d_stream"),
+        (1 << 18, np.float32, None, ("db4",), "k_wpt_fwd_multi", "k_wpt_inv_tail"),
+        (1 << 16, np.float32, 5, ("sym5",), "k_wpt_fwd_multi", None),
+        (1 << 14, np.float64, None, ("db2", "db4"), "k_wpt_fwd_multi", "k_wpt_inv_tail"),
+        (1 << 12, np.float32, None, ("db4", "sym5", "haar"), "k_wpt_fwd_tail", "k_wpt_inv_tail"),
+        (1 << 11, np.float64, 11, ("db3",), "k_wpt_fwd_tail", "k_wpt_inv_tail"),
+        (256, np.float32, 8, ("db4",), "k_wpt_fwd_tail", "k_wpt_inv_tail"),
+        (3 << 14, np.float32, 4, ("db4",), "k_wpt_fwd_multi", None),          # 49152: segments 49152 .. 6144, no power of two
+    ]
+    for n, dtype, depth, filters, kf, ki in cases:
+        x = rng_array((n,), dtype, n % 1000)
+        L = W.maxtransformlevels(n) if depth is None else depth
+        tree = W.maketree(n, L, "full")
+        for fname in filters:
+            wt = W.wavelet(getattr(W.WT, fname))
+            ye = oracle.wpt_filter(x, wt.qmf, tree)
+            y = host(W, W.wpt(dev(W, x), wt, tree))
+            assert W.last_kernel() == kf, (n, L, fname, W.last_kernel())
+            assert np.array_equal(y, ye), (n, L, fname)
+            xr = host(W, W.iwpt(dev(W, ye), wt, tree))
+            if ki is not None:
+                assert W.last_kernel() == ki, (n, L, fname, W.last_kernel())
+            assert np.array_equal(xr, oracle.wpt_filter(ye, wt.qmf, tree, fw=False)), (n, L, fname)
+            # the per-depth tier gives the same bits
+            W.set_option("WL_WPT_FAST", 0)
+            assert np.array_equal(host(W, W.wpt(dev(W, x), wt, tree)), ye)
+            W.clear_options()
+    # lifting: every fully split depth = one fused lifting level over the segments
+    for n, L in ((1 << 16, 6), (1 << 18, 3)):
+        x = rng_array((n,), np.float32, 5)
+        tree = W.maketree(n, L, "full")
+        for sname in ("cdf97", "db2"):
+            sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+            ye = oracle.wpt_lifting(x, sch, tree)
+            assert np.array_equal(host(W, W.wpt(dev(W, x), sch, tree)), ye), (n, sname)
+            assert W.last_kernel().startswith("k_lift1d") or W.last_kernel().startswith("k_tail_lift"), W.last_kernel()
+            assert np.array_equal(host(W, W.iwpt(dev(W, ye), sch, tree)), oracle.wpt_lifting(ye, sch, tree, fw=False))
+    # a partially split tree: the node bits are staged by the call -- the caller may reuse its buffer at once
+    import torch
+    n = 1 << 14
+    x = rng_array((n,), np.float32, 9)
+    rs = np.random.default_rng(12)
+    t = np.zeros(n - 1, dtype=np.uint8)
+    t[0] = 1
+    for i in range(1, len(t)):
+        t[i] = 1 if (t[(i + 1) // 2 - 1] and rs.random() < 0.7) else 0
+    wt = W.wavelet(W.WT.db4)
+    ye = oracle.wpt_filter(x, wt.qmf, t.copy())
+    xd = dev(W, x)
+    tt = t.copy()
+    yd = W.wpt(xd, wt, tt)
+    tt[:] = 1                                   # (before any synchronisation)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(W, yd), ye)
+
+
 # ---- BASELINE.json full sizes: size-independent properties -------------------------------------------
 def test_full_size_properties(gpu, W, oracle):
     """configs[1..3] at full size: round trip, linearity, energy, and exact equality with the oracle on

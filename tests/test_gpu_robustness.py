@@ -264,6 +264,31 @@ def test_hipgraph_capture_and_replay(gpu, W, oracle):
             e = oracle.dwt_lifting(inputs[k], wt, L) if lifting else oracle.dwt_filter(inputs[k], wt.qmf, L)
             assert np.array_equal(W.to_host(y), e), (shape, dtype, L, k)
         del graph
+    # wavelet packets (round 4: no stream synchronisation inside wl_wpt_*): full trees are capturable
+    for n, dtype, wt, L in (((1 << 18), np.float32, W.wavelet(W.WT.db4), 6), ((1 << 14), np.float32, W.wavelet(W.WT.db4), 14),
+                            ((1 << 16), np.float32, W.wavelet(W.WT.cdf97, W.WT.Lifting), 4)):
+        lifting = not hasattr(wt, "qmf")
+        inputs = [rng_array((n,), dtype, 31 + k) for k in range(3)]
+        tree = W.maketree(n, L, "full")
+        x = W.to_device(inputs[0])
+        with torch.cuda.stream(s):
+            W.reserve_workspace(x, L, full=True)
+            y = W.wpt(x, wt, tree)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            if lifting:
+                y.copy_(x)
+                W.wpt_(y, wt, tree)
+            else:
+                W.wpt_(y, x, wt, tree)
+        for k in (1, 2, 0):
+            x.copy_(W.to_device(inputs[k]))
+            graph.replay()
+            torch.cuda.synchronize()
+            e = oracle.wpt_lifting(inputs[k], wt, tree) if lifting else oracle.wpt_filter(inputs[k], wt.qmf, tree)
+            assert np.array_equal(W.to_host(y), e), (n, L, k)
+        del graph
 
 
 def test_calls_leave_the_current_device_alone_two_gpus(gpu, W, oracle):

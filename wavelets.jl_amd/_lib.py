@@ -65,6 +65,9 @@ SIGNATURES = {
     "wl_wpt_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, _f64p, C.c_int, _u8p, C.c_int64, C.c_int, _vp]),
     "wl_wpt_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _i32p, _i32p, _i32p, _f64p,
                                  C.c_double, C.c_double, _u8p, C.c_int64, C.c_int, _vp]),
+    "wl_wpt_filter_full": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, _f64p, C.c_int, C.c_int, C.c_int, _vp]),
+    "wl_wpt_lifting_full": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _i32p, _i32p, _i32p, _f64p,
+                                      C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
     "wl_maxmodwttransformlevels": (C.c_int, [C.c_int64]),
     "wl_modwt": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _f64p, C.c_int, C.c_int, _vp]),
     "wl_imodwt": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _f64p, C.c_int, _vp]),

@@ -31,6 +31,24 @@ int wl_ensure_ws(wl_ctx *ctx, size_t bytes)
     return WL_OK;
 }
 
+int wl_stage_to_device(wl_ctx *ctx, void *dst, const void *host, size_t bytes, hipStream_t st)
+{
+    const int k = ctx->stage_next;
+    ctx->stage_next = (k + 1) % wl_ctx::kStage;
+    if (ctx->stage_ev[k]) WL_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));      // the copy that last used this slot
+    else WL_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    if (ctx->stage_bytes[k] < bytes) {
+        if (ctx->stage[k]) { WL_HIP(ctx, hipHostFree(ctx->stage[k])); ctx->stage[k] = nullptr; ctx->stage_bytes[k] = 0; }
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        if (hipHostMalloc(&ctx->stage[k], want, hipHostMallocDefault) != hipSuccess) { ctx->stage[k] = nullptr; return WL_ENOMEM; }
+        ctx->stage_bytes[k] = want;
+    }
+    std::memcpy(ctx->stage[k], host, bytes);
+    WL_HIP(ctx, hipMemcpyAsync(dst, ctx->stage[k], bytes, hipMemcpyHostToDevice, st));
+    WL_HIP(ctx, hipEventRecord(ctx->stage_ev[k], st));
+    return WL_OK;
+}
+
 namespace {
 
 inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int64_t)1 << L)) == 0; }
@@ -320,9 +338,13 @@ int wl_ctx_destroy(wl_ctx *ctx)
     if (!ctx) return WL_EINVAL_ARG;
     {
         CallScope scope(ctx);                  // free on the context's device, leave the caller's device current
-        if (ctx->ws || ctx->aux) (void)hipDeviceSynchronize();
+        if (ctx->ws || ctx->aux || ctx->stage_ev[0]) (void)hipDeviceSynchronize();
         if (ctx->ws) (void)hipFree(ctx->ws);
         if (ctx->aux) (void)hipFree(ctx->aux);
+        for (int k = 0; k < wl_ctx::kStage; ++k) {
+            if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+            if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+        }
     }
     delete ctx;
     return WL_OK;
@@ -558,84 +580,162 @@ static bool isvalidtree(int64_t n, const uint8_t *b, int64_t nb, int64_t *last_s
 template <typename T>
 static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
                     const Taps<T> *taps, const LiftScheme<T> *sc,
-                    const uint8_t *tree, int64_t ntree, int64_t last_set, int fw)
+                    const uint8_t *tree, int64_t ntree, int64_t last_set, int fw, int full_depth = -1)
 {
+    // full_depth >= 0: the full tree of that depth, no tree vector (tree == nullptr)
     const bool lifting = (sc != nullptr);
     Extent3 full = {{n, 1, 1}};
     Strides3 fst = {{1, n, n}};
-    if (ntree == 0 || !tree[0]) {
+    if (full_depth >= 0 ? full_depth == 0 : (ntree == 0 || !tree[0])) {
         if (y != x) WL_HIP(ctx, generic_copy_box<T>(st, x, fst, y, fst, full));
         ctx->last_kernel = "copy";
         return WL_OK;
     }
-    // only the nodes up to the last set one are ever looked at on the device (whole depths: round up to 2^(d+1) - 1)
+    const int Lmax = wl_maxtransformlevels(n);
+    // depths in processing order, skipping depths where no node is set (pure copy-through); kind 2: every segment splits
+    std::vector<int> depths, kind;
+    bool any_partial = false;
+    for (int L = Lmax; L > 0; --L) {
+        int d = fw ? Lmax - L : L - 1;
+        if (full_depth >= 0) {
+            if (d < full_depth) { depths.push_back(d); kind.push_back(2); }
+            continue;
+        }
+        int64_t first = ((int64_t)1 << d) - 1, cnt = (int64_t)1 << d;
+        int64_t nset = 0;
+        if (first <= last_set)
+            for (int64_t k = 0; k < cnt; ++k) nset += tree[first + k] != 0;
+        if (nset) { depths.push_back(d); kind.push_back(nset == cnt ? 2 : 1); any_partial = any_partial || nset != cnt; }
+    }
+    const int K = (int)depths.size();
+    // only the nodes up to the last set one are ever looked at on the device (whole depths: round up to 2^(d+1) - 1), and only
+    // when some depth is PARTIALLY split: the kernels of fully split depths take no mask.  The bits travel through the
+    // context's pinned staging ring -- the caller's (pageable) buffer is not referenced after this call returns and the stream
+    // is not synchronised (round 3 did hipStreamSynchronize here, against the header's contract).
     int64_t ncopy = 1;
     while (ncopy - 1 <= last_set && ncopy - 1 < ntree) ncopy <<= 1;
     ncopy = (ncopy - 1 < ntree) ? ncopy - 1 : ntree;
-    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)ncopy + 256);
+    if (full_depth >= 0) ncopy = 0;
+    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)(any_partial ? ncopy : 0) + 256);
     if (rc) return rc;
     Work<T> w = carve<T>(ctx->ws, n);
     uint8_t *dtree = (uint8_t *)ctx->ws + ws_elems(n) * sizeof(T);
-    WL_HIP(ctx, hipMemcpyAsync(dtree, tree, (size_t)ncopy, hipMemcpyHostToDevice, st));
-    // `tree` is the caller's pageable buffer and may be freed as soon as this call returns: the copy must have read it by
-    // then (trees are tiny next to the transform, and wpt is not a throughput path)
-    WL_HIP(ctx, hipStreamSynchronize(st));
-
-    const int Lmax = wl_maxtransformlevels(n);
-    // depths in processing order, skipping depths where no node is set (pure copy-through)
-    std::vector<int> depths;
-    for (int L = Lmax; L > 0; --L) {
-        int d = fw ? Lmax - L : L - 1;
-        int64_t first = ((int64_t)1 << d) - 1, cnt = (int64_t)1 << d;
-        bool any = false;
-        if (first <= last_set)
-            for (int64_t k = 0; k < cnt && !any; ++k) any = tree[first + k] != 0;
-        if (any) depths.push_back(d);
+    if (any_partial) {
+        rc = wl_stage_to_device(ctx, dtree, tree, (size_t)ncopy, st);
+        if (rc) return rc;
     }
-    const int K = (int)depths.size();
-    const T *cur = x;
-    bool fast_used = false;
-    for (int i = 0; i < K; ++i) {
-        const int d = depths[i];
-        const int64_t nj = n >> d, nseg = (int64_t)1 << d;
-        Extent3 ext = {{nj, nseg, 1}};
-        Strides3 bst = {{1, nj, n}};
-        Extent3 lo = {{nj >> 1, nseg, 1}};
-        const uint8_t *mask = dtree + (((int64_t)1 << d) - 1);
-        if (lifting) {
-            // reads of `cur` all happen in the first kernel, so in-place (cur == y) is safe
+    const bool fast = (ctx->path == 0) && opt("WL_WPT_FAST", 1) != 0;
+
+    if (lifting) {
+        // wpt!(y, scheme, ...) is in place for the caller.  A fused lifting level cannot run in place (its [s ; d] outputs land
+        // where other waves still read interleaved input; lifting_lines_fast would stage and copy back: three launches), so fully
+        // split depths ping-pong between y and a work buffer -- one launch per depth -- and an odd count ends with one copy.
+        const char *name = "k_generic_lift_wpt";
+        T *cur = y;
+        for (int i = 0; i < K; ++i) {
+            const int d = depths[i];
+            const int64_t nj = n >> d, nseg = (int64_t)1 << d;
+            // fully split depth: one lifting level (all steps fused) of nseg lines of length nj
+            if (kind[i] == 2 && fast) {
+                int handled = 0, herr = 0;
+                const char *kn = nullptr;
+                T *out = (cur == y) ? w.T0 : y;
+                rc = lifting_lines_fast<T>(ctx->ws, ctx->cu_count, st, nj, nseg, nj, out, cur, *sc, 1, fw, &handled, &kn, &herr);
+                if (rc) { ctx->last_hip = herr; return rc; }
+                if (handled) { name = kn ? kn : "k_lift1d_stream"; cur = out; continue; }
+            }
+            if (cur != y) { WL_HIP(ctx, generic_copy_box<T>(st, cur, fst, y, fst, full)); cur = y; }
+            Extent3 ext = {{nj, nseg, 1}};
+            Strides3 bst = {{1, nj, n}};
+            Extent3 lo = {{nj >> 1, nseg, 1}};
+            const uint8_t *mask = (kind[i] == 2) ? nullptr : dtree + (((int64_t)1 << d) - 1);
+            // reads of y all happen in the first kernel, so in place is safe
             if (fw) {
-                WL_HIP(ctx, generic_lift_split<T>(st, cur, bst, w.W, bst, ext, 0, mask));
+                WL_HIP(ctx, generic_lift_split<T>(st, y, bst, w.W, bst, ext, 0, mask));
                 for (int s = 0; s < sc->nsteps; ++s)
                     WL_HIP(ctx, generic_lift_step<T>(st, sc->step[s], w.W, bst, ext, 0, mask));
                 WL_HIP(ctx, generic_lift_finish_fwd<T>(st, sc->norm1, sc->norm2, w.W, bst, y, bst, (T *)nullptr, bst, ext, 0, lo, mask));
             } else {
-                WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc->norm1, sc->norm2, cur, bst, (const T *)nullptr, bst, w.W, bst, ext, 0, lo, mask));
+                WL_HIP(ctx, generic_lift_norm_inv<T>(st, sc->norm1, sc->norm2, y, bst, (const T *)nullptr, bst, w.W, bst, ext, 0, lo, mask));
                 for (int s = 0; s < sc->nsteps; ++s)
                     WL_HIP(ctx, generic_lift_step<T>(st, sc->step[s], w.W, bst, ext, 0, mask));
                 WL_HIP(ctx, generic_lift_merge<T>(st, w.W, bst, y, bst, ext, 0, mask));
             }
-            cur = y;
-        } else {
-            T *out = ((K - 1 - i) % 2 == 0) ? y : w.T0;
-            // fully split depth: every segment is a line of the streaming kernels
-            bool all_set = true;
-            for (int64_t k = 0; k < nseg && all_set; ++k) all_set = tree[(((int64_t)1 << d) - 1) + k] != 0;
-            if (all_set && ctx->path == 0) {
-                hipError_t he = hipSuccess;
-                bool ok = fw ? fast_lines_fwd_level<T>(st, *taps, cur, nj, out, nj, out + (nj >> 1), nj, nj, nseg, ctx->cu_count, &he)
-                             : fast_lines_inv_level<T>(st, *taps, cur, nj, cur + (nj >> 1), nj, out, nj, nj, nseg, ctx->cu_count, &he);
-                if (he != hipSuccess) return hip_fail(ctx, he);
-                if (ok) { cur = out; fast_used = true; continue; }
-            }
-            if (fw)
-                WL_HIP(ctx, generic_fwd_filter_pass<T>(st, *taps, cur, bst, out, bst, (T *)nullptr, bst, ext, 0, lo, mask));
-            else
-                WL_HIP(ctx, generic_inv_filter_pass<T>(st, *taps, cur, bst, (const T *)nullptr, bst, out, bst, ext, 0, lo, mask));
-            cur = out;
         }
+        if (cur != y) WL_HIP(ctx, generic_copy_box<T>(st, cur, fst, y, fst, full));
+        ctx->last_kernel = name;
+        return WL_OK;
     }
-    ctx->last_kernel = lifting ? "k_generic_lift_wpt" : (fast_used ? (fw ? "k_fwd1d_stream" : "k_inv1d_stream") : "k_generic_filter_wpt");
+
+    // ---- filter bank: plan the launches first (the output ping-pongs between y and a work buffer and must end in y) ----
+    struct Step { int kindk; int d; int nd; };          // 0 generic / line kernel (one depth), 1 multi (nd fused depths), 2 tail (nd depths)
+    std::vector<Step> plan;
+    const int F = taps->F;
+    const int TSw = wpt_tile_samples<T>();
+    for (int i = 0; i < K;) {
+        const int d = depths[i];
+        int run = 0;                                     // fully split depths d, d +- 1, ... in processing order
+        while (fast && i + run < K && kind[i + run] == 2 && depths[i + run] == (fw ? d + run : d - run)) ++run;
+        if (run >= 1 && fw) {
+            const int64_t nj = n >> d;
+            if (wpt_tail_ok<T>(F, n, nj, run)) { plan.push_back({2, d, run}); i += run; continue; }
+            int to_tail = 0;                             // depths until the segments fit a workgroup
+            while ((nj >> to_tail) > TSw) ++to_tail;
+            int lim = run < to_tail ? run : to_tail;
+            if (lim < 1) lim = 1;
+            const int stages = (lim + 2) / 3;
+            int NL = (lim + stages - 1) / stages;
+            while (NL >= 1 && !wpt_fwd_multi_ok<T>(F, n, nj, NL)) --NL;
+            if (NL >= 1 && (NL > 1 || opt("WL_WPT_MULTI1", 0))) { plan.push_back({1, d, NL}); i += NL; continue; }
+        } else if (run >= 1 && !fw) {
+            // deepest first: take every depth of the run whose segments still fit a workgroup
+            int nd = 0;
+            while (nd < run && wpt_tail_ok<T>(F, n, n >> (d - nd), nd + 1)) ++nd;
+            if (nd >= 1) { plan.push_back({2, d - nd + 1, nd}); i += nd; continue; }
+        }
+        plan.push_back({0, d, 1});
+        ++i;
+    }
+    const int P = (int)plan.size();
+    const T *cur = x;
+    const char *name = "k_generic_filter_wpt";
+    for (int i = 0; i < P; ++i) {
+        const Step &sp = plan[i];
+        const int d = sp.d;
+        T *out = ((P - 1 - i) % 2 == 0) ? y : w.T0;
+        if (sp.kindk == 1) {
+            WL_HIP(ctx, wpt_fwd_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd));
+            name = "k_wpt_fwd_multi";
+        } else if (sp.kindk == 2) {
+            WL_HIP(ctx, wpt_tail_launch<T>(st, *taps, fw, cur, out, n, n >> d, sp.nd));
+            if (std::strcmp(name, "k_wpt_fwd_multi") != 0) name = fw ? "k_wpt_fwd_tail" : "k_wpt_inv_tail";
+        } else {
+            const int64_t nj = n >> d, nseg = (int64_t)1 << d;
+            Extent3 ext = {{nj, nseg, 1}};
+            Strides3 bst = {{1, nj, n}};
+            Extent3 lo = {{nj >> 1, nseg, 1}};
+            int ki = 0;
+            while (depths[ki] != d) ++ki;
+            const bool all_set = kind[ki] == 2;
+            bool done = false;
+            if (all_set && ctx->path == 0) {             // fully split depth: every segment is a line of the streaming kernels
+                hipError_t he = hipSuccess;
+                done = fw ? fast_lines_fwd_level<T>(st, *taps, cur, nj, out, nj, out + (nj >> 1), nj, nj, nseg, ctx->cu_count, &he)
+                          : fast_lines_inv_level<T>(st, *taps, cur, nj, cur + (nj >> 1), nj, out, nj, nj, nseg, ctx->cu_count, &he);
+                if (he != hipSuccess) return hip_fail(ctx, he);
+                if (done && std::strncmp(name, "k_wpt", 5) != 0) name = fw ? "k_fwd1d_stream" : "k_inv1d_stream";
+            }
+            if (!done) {
+                const uint8_t *mask = all_set ? nullptr : dtree + (((int64_t)1 << d) - 1);
+                if (fw)
+                    WL_HIP(ctx, generic_fwd_filter_pass<T>(st, *taps, cur, bst, out, bst, (T *)nullptr, bst, ext, 0, lo, mask));
+                else
+                    WL_HIP(ctx, generic_inv_filter_pass<T>(st, *taps, cur, bst, (const T *)nullptr, bst, out, bst, ext, 0, lo, mask));
+            }
+        }
+        cur = out;
+    }
+    ctx->last_kernel = name;
     return WL_OK;
 }
 
@@ -683,6 +783,47 @@ int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
     int rc = make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
     if (rc) return rc;
     return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, tree, ntree, last_set, fw);
+}
+
+int wl_wpt_filter_full(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n, const double *qmf, int flen, int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x || !qmf) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (n < 1) return WL_EDIMS;
+    if (y == x) return WL_EALIAS;
+    if (L < 0 || L > wl_maxtransformlevels(n)) return WL_EINVAL_L;
+    WL_SCOPE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == WL_F32) {
+        Taps<float> t; make_taps<float>(qmf, flen, t);
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)x, n, &t, nullptr, nullptr, 0, -1, fw, L);
+    }
+    Taps<double> t; make_taps<double>(qmf, flen, t);
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)x, n, &t, nullptr, nullptr, 0, -1, fw, L);
+}
+
+int wl_wpt_lifting_full(wl_ctx *ctx, int dtype, void *y, int64_t n,
+                        int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                        const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                        int L, int fw, void *stream)
+{
+    if (!ctx || !y) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (n < 1) return WL_EDIMS;
+    if (L < 0 || L > wl_maxtransformlevels(n)) return WL_EINVAL_L;
+    WL_SCOPE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == WL_F32) {
+        LiftScheme<float> sc;
+        int rc = make_scheme<float>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
+        if (rc) return rc;
+        return wpt_impl<float>(ctx, st, (float *)y, (const float *)y, n, nullptr, &sc, nullptr, 0, -1, fw, L);
+    }
+    LiftScheme<double> sc;
+    int rc = make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, fw, sc);
+    if (rc) return rc;
+    return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, nullptr, 0, -1, fw, L);
 }
 
 }  // extern "C"

@@ -13,7 +13,17 @@ struct wl_ctx {
     const char *last_kernel = "none";
     int cu_count = 256;
     wl::Opts opts;                      // wl_ctx_set_option
+    // pinned host staging for small host arguments that a kernel reads from device memory (the node bits of a partially split
+    // packet tree): the caller's buffer is copied here synchronously, the copy to the device is asynchronous.  A ring of slots,
+    // each guarded by an event, so that a call only ever waits for the copy issued kStage calls earlier.
+    enum { kStage = 4 };
+    void *stage[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[kStage] = {0, 0, 0, 0};
+    hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr};
+    int stage_next = 0;
 };
+// copy `bytes` host bytes to device memory `dst` on stream st without synchronising the stream (wl_api.hip)
+int wl_stage_to_device(wl_ctx *ctx, void *dst, const void *host, size_t bytes, hipStream_t st);
 
 // Installed by every ABI entry point for the duration of the call: makes the context's device current (and restores
 // the caller's device on exit, so a call never changes the process's current device) and publishes the context's

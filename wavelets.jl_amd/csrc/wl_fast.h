@@ -185,4 +185,11 @@ template <typename T>
 bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
                       T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
 
+// ---- fully split depths of the packet transform (wl_wpt.hip) ----
+template <typename T> int wpt_tile_samples();
+template <typename T> bool wpt_fwd_multi_ok(int F, int64_t n, int64_t nj, int NL);
+template <typename T> hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL);
+template <typename T> bool wpt_tail_ok(int F, int64_t n, int64_t nj, int ndepth);
+template <typename T> hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth);
+
 }  // namespace wl

@@ -140,6 +140,39 @@ function Transforms._wpt!(y::ROCVector{T}, scheme::GLS, tree::BitVector, fw::Boo
     return y
 end
 
+# wpt(x, wt, L::Integer) / wpt!(y, x, filter, L::Integer) / wpt!(y, scheme, L::Integer) of the reference build
+# maketree(length(x), L, :full) -- a BitVector of n - 1 nodes -- and walk it (transforms_main.jl:134-176).  For device
+# arrays the depth is all the library needs: these methods are more specific than the reference's generic ones.
+for (f, fw) in ((:wpt!, true), (:iwpt!, false))
+    @eval function Transforms.$f(y::ROCVector{T}, x::ROCVector{T}, filter::OrthoFilter,
+                                 L::Integer=Util.maxtransformlevels(x)) where {T<:Union{Float32,Float64}}
+        size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
+        0 <= L <= Util.maxtransformlevels(x) || throw(AssertionError("0 <= L <= maxtransformlevels(n)"))   # maketree's @assert
+        GC.@preserve y x check(ccall((:wl_wpt_filter_full, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), pointer(x), length(x), filter.qmf, length(filter.qmf), L, $fw, stream()))
+        return y
+    end
+    @eval function Transforms.$f(y::ROCVector{T}, scheme::GLS, L::Integer=Util.maxtransformlevels(y)) where {T<:Union{Float32,Float64}}
+        0 <= L <= Util.maxtransformlevels(y) || throw(AssertionError("0 <= L <= maxtransformlevels(n)"))
+        isup, nc, sh, cf = flatten(scheme)
+        GC.@preserve y check(ccall((:wl_wpt_lifting_full, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                     Cdouble, Cdouble, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), length(y), length(isup), isup, nc, sh, cf, scheme.norm1, scheme.norm2,
+                    L, $fw, stream()))
+        return y
+    end
+end
+for (f, fb) in ((:wpt, :wpt!), (:iwpt, :iwpt!))
+    @eval function Transforms.$f(x::ROCVector{T}, filter::OrthoFilter, L::Integer=Util.maxtransformlevels(x)) where {T<:Union{Float32,Float64}}
+        return Transforms.$fb(similar(x), x, filter, L)
+    end
+    @eval function Transforms.$f(x::ROCVector{T}, scheme::GLS, L::Integer=Util.maxtransformlevels(x)) where {T<:Union{Float32,Float64}}
+        return Transforms.$fb(copy(x), scheme, L)
+    end
+end
+
 # ---- dwtc / idwtc: named but never defined by the reference (transforms_main.jl:179-181)
 for (f, fw) in ((:dwtc, true), (:idwtc, false))
     @eval function $f(x::ROCMatrix{T}, filter::OrthoFilter, L::Integer=Util.maxtransformlevels(size(x, 1))) where {T}

@@ -427,11 +427,19 @@ def idwtc_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
 
 
 # ---- wavelet packet transforms -------------------------------------------------------------------
+class _FullTree(int):
+    """wpt(x, wt, L::Integer): the full tree of depth L -- never materialised (a tree has n - 1 nodes; the library's
+    wl_wpt_*_full entry points take the depth)."""
+
+
 def _tree_arg(n, tree_or_L):
     if tree_or_L is None:
-        return Util.maketree(n, Util.maxtransformlevels(n), "full")
+        return _FullTree(Util.maxtransformlevels(n))
     if isinstance(tree_or_L, (int, np.integer)):
-        return Util.maketree(n, int(tree_or_L), "full")
+        L = int(tree_or_L)
+        if not 0 <= L <= Util.maxtransformlevels(n):
+            raise AssertionError("0 <= L <= maxtransformlevels(n)")       # maketree's @assert (util_main.jl:316-344)
+        return _FullTree(L)
     t = np.asarray(tree_or_L)
     if t.dtype == np.bool_:
         t = t.view(np.uint8)                 # BitVector -> one byte per node, no copy
@@ -443,6 +451,11 @@ def _wpt_filter_call(y, x, filt, tree, fw):
     lib = _lib.load()
     h, st = _context(x.device)
     q = np.ascontiguousarray(filt.qmf, dtype=np.float64)
+    if isinstance(tree, _FullTree):
+        rc = lib.wl_wpt_filter_full(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.numel(),
+                                    _f64p(q), len(q), int(tree), 1 if fw else 0, st)
+        _check(rc, h)
+        return y
     rc = lib.wl_wpt_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.numel(),
                            _f64p(q), len(q), tree.ctypes.data_as(C.POINTER(C.c_uint8)), len(tree),
                            1 if fw else 0, st)
@@ -455,6 +468,11 @@ def _wpt_lifting_call(y, sch, tree, fw):
     lib = _lib.load()
     h, st = _context(y.device)
     iu, nc, sh, cf = sch.flatten()
+    if isinstance(tree, _FullTree):
+        rc = lib.wl_wpt_lifting_full(h, _dtype_code(y), C.c_void_p(y.data_ptr()), y.numel(), len(iu), _i32p(iu), _i32p(nc),
+                                     _i32p(sh), _f64p(cf), sch.norm1, sch.norm2, int(tree), 1 if fw else 0, st)
+        _check(rc, h)
+        return y
     rc = lib.wl_wpt_lifting(h, _dtype_code(y), C.c_void_p(y.data_ptr()), y.numel(), len(iu), _i32p(iu), _i32p(nc),
                             _i32p(sh), _f64p(cf), sch.norm1, sch.norm2,
                             tree.ctypes.data_as(C.POINTER(C.c_uint8)), len(tree), 1 if fw else 0, st)

@@ -104,8 +104,11 @@ WL_API int wl_ctx_destroy(wl_ctx *ctx);
  * elements: the context grows to that on their first call (grow-only; a call that grows the
  * workspace synchronises the device).  wl_ctx_workspace_held reports the current size.    */
 WL_API size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L);
-/* Upper bound for EVERY entry point on this shape (lifting, long / odd filters, 3-D, the generic kernel family, wpt): reserve
- * this much and no later transform of that shape allocates or synchronises, whatever path it takes.                      */
+/* Upper bound for every TRANSFORM entry point on this shape (wl_dwt_*, wl_dwtc_*, wl_wpt_*: lifting, long / odd filters,
+ * 3-D, the generic kernel family): reserve this much and no later transform of that shape allocates or synchronises,
+ * whatever path it takes.  NOT covered: wl_denoise_ti_filter, whose batch of shifted copies needs about
+ * (6.5 * prod(nspin) + nspin[0]) N elements (capped, see WL_TI_WS_CAP_MB) -- a plain one-spin denoise about 5.5 N -- and grows
+ * the workspace (synchronising) on its first call like any other path; wl_modwt / wl_imodwt allocate nothing here.      */
 WL_API size_t wl_workspace_bytes_full(int dtype, int ndims, const int64_t *dims, int L);
 WL_API int wl_ctx_reserve(wl_ctx *ctx, size_t bytes);
 WL_API size_t wl_ctx_workspace_held(const wl_ctx *ctx);

@@ -206,6 +206,15 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
         with pytest.raises(TypeError):
             W.denoise(xd, dnt=W.VisuShrink(th, 1.0), TI=True)
     # a custom estimator that returns NaN or a negative value trips @assert t >= 0 instead of being replaced silently
-    for bad in (float("nan"), -1.0, float("inf")):
+    for bad in (float("nan"), -1.0):
         with pytest.raises(AssertionError):
             W.denoise(xd, TI=True, estnoise=lambda a, w: bad)
+    # ... while +Inf passes it, as in the reference: t = Inf thresholds every coefficient, the result is all zeros
+    yinf = host(W, W.denoise(xd, TI=True, nspin=4, estnoise=lambda a, w: float("inf")))
+    assert np.array_equal(yinf, np.zeros_like(yinf))
+    # the plain denoise keeps the reference's own sequence (no shifted copy, no averaging): signed zeros survive
+    xz = -np.abs(x) * 1e-30                     # every coefficient below the threshold; an all-negative-zero input for L = 0
+    for Lz in (0, 3):
+        ez = _oracle_denoise(oracle, W, xz, wt, Lz, vs, False, None)
+        yz = host(W, W.denoise(W.to_device(xz), L=Lz))
+        assert np.array_equal(yz, ez) and np.array_equal(np.signbit(yz), np.signbit(ez)), Lz

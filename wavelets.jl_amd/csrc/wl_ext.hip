@@ -879,7 +879,9 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     }
     const size_t zr_elems = virt ? (size_t)N * (size_t)nsp0 : 0;
     const size_t cap = (size_t)opt("WL_TI_WS_CAP_MB", 8192) << 20;
-    auto need = [&](int64_t B) { return (ws_elems(N * B, ndims) + (size_t)2 * N * B + zr_elems + (size_t)n0 + 64) * sizeof(T); };
+    // (one spin: no shifted copy Z, see below)
+    const size_t ncopies = (pns == 1) ? 1 : 2;
+    auto need = [&](int64_t B) { return (ws_elems(N * B, ndims) + ncopies * (size_t)N * B + zr_elems + (size_t)n0 + 64) * sizeof(T); };
     int64_t B = pns;
     while (B > 1 && need(B) > cap) B = (B + 1) / 2;
     if (B > 65535) B = 65535;
@@ -891,7 +893,7 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     if (rc != WL_OK) return rc;
     T *tw = (T *)ctx->ws;                                   // transform workspace of the batch box (with the generic buffers)
     T *Z = tw + ws_elems(N * B, ndims);
-    T *XT = Z + N * B;
+    T *XT = Z + (pns == 1 ? 0 : N * B);
     T *ZR = XT + N * B;                                     // row-shifted copies (virtual shifts only)
     T *dr = ZR + zr_elems;                                  // detail range of the noise estimate (n0/2 samples)
     const unsigned nbk = ext_blocks(N * B, 4, ctx->cu_count);
@@ -919,6 +921,36 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
             rc = median_impl<T>(ctx, st, dr, nd, nullptr, (T *)nullptr);
             if (rc != WL_OK) return rc;
         }
+    }
+    // ---- one spin of shift zero (the plain, not translation-invariant denoise routed here so that sigma stays on the device):
+    //      y = idwt(threshold!(dwt(x))) with no shifted copy, no accumulation and no scaling -- the reference's own sequence
+    //      (denoising.jl:69-80), signed zeros included, and a quarter of the batch path's memory ----
+    if (pns == 1) {
+        BoxSpec b1;
+        b1.nd = ndims; b1.nt = ndims;
+        b1.dims[0] = n0; b1.dims[1] = n1; b1.dims[2] = 1;
+        b1.full = dense_strides(b1.dims);
+        const T *coef_src = x;
+        if (L > 0) {
+            rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, b1, XT, x, taps, L, &ctx->last_kernel, &ctx->last_hip);
+            if (rc != WL_OK) return rc;
+            coef_src = XT;
+        } else {
+            hipLaunchKernelGGL((k_copy_range<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, XT, x, N);
+            coef_src = XT;
+        }
+        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(ext_blocks(N, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, XT, N, th, &sel->result, t_unit,
+                           sigma_host, vec_ok16(XT));
+        if (L > 0) {
+            const char *kn = nullptr;
+            rc = filter_inv_levels<T>(tw, true, ctx->cu_count, ctx->path, st, b1, y, coef_src, taps, L, &kn, &ctx->last_hip);
+            if (rc != WL_OK) return rc;
+        } else {
+            hipLaunchKernelGGL((k_copy_range<T>), dim3(ext_blocks(N, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, coef_src, N);
+        }
+        ctx->last_kernel = "denoise_one_spin";
+        WL_HIP(ctx, hipGetLastError());
+        return WL_OK;
     }
     // ---- the spins, B at a time ----
     BoxSpec bb;
@@ -950,6 +982,8 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
             shifted = tl_srcview.used != 0;
             th_c0 = tl_srcview.corner0; th_c1 = tl_srcview.corner1;
             tl_srcview.mod = 0; tl_srcview.th = -1;
+            // WL_RETRY_NOVIEW: no view-aware tier took level 1 -- nothing was enqueued (and nothing read from ZR): materialise below
+            if (rc == WL_RETRY_NOVIEW) { rc = WL_OK; shifted = false; }
             if (rc != WL_OK) return rc;
             thresholded_l1 = shifted && fuse_th;
         }
@@ -1113,7 +1147,9 @@ int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndi
     if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
     // threshold!(xt, dnt.th, sigma*t) (denoising.jl:58) has methods for Hard / Soft / Semisoft / Stein only (threshold_main.jl:21-80)
     if (th < WL_TH_HARD || th > WL_TH_STEIN) return WL_EINVAL_ARG;
-    if (sigma_host != sigma_host || sigma_host == HUGE_VAL) return WL_EINVAL_ARG;    // NaN / +Inf from a custom estimator: @assert t >= 0 territory
+    // a custom estimator's value: NaN trips the reference's `@assert t >= 0` (threshold_main.jl:24) and so does Inf * 0; +Inf
+    // alone passes it -- every coefficient is thresholded -- and is accepted here as well (negative = "estimate on the device")
+    if (sigma_host != sigma_host || (sigma_host >= 0 && !(sigma_host * t_unit >= 0))) return WL_EINVAL_ARG;
     for (int d = 0; d < ndims; ++d)
         if (dims[d] < 1 || nspin[d] < 1) return WL_EDIMS;
     if (ndims == 2 && dims[0] != dims[1]) return WL_EINVAL_CUBE;            // iscube(x) (denoising.jl:29)

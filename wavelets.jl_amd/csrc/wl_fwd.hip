@@ -1317,6 +1317,8 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 continue;
             }
         }
+        // a virtually shifted source is only valid for the two batch tiers above: anything else would read planes it does not hold
+        if (l == 1 && tl_srcview.mod > 0) return WL_RETRY_NOVIEW;
         // ---- two levels of a block too big for one resident round of the staging tile kernel (2048 rows): tiles without staging ----
         if constexpr (sizeof(T) == 4) {
             if (fastF && two_d && env_int("WL_TILEB", 1) && (L - l + 1) >= 2 && n[0] <= env_int("WL_TILEB_MAX", 2048) &&

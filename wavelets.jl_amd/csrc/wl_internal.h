@@ -121,6 +121,9 @@ hipError_t generic_copy_box(hipStream_t st, const T *src, Strides3 sst, T *dst, 
 // without having them returns WL_RETRY_GEN (internal) and the ABI layer repeats the call with the full workspace
 // (out-of-place filter transforms only, so repeating is harmless).
 constexpr int WL_RETRY_GEN = -1000;
+// (internal) level 1 of a batch was asked to read virtually shifted planes (SrcView) but no tier that understands the view
+// is eligible: returned BEFORE anything is enqueued -- the source holds fewer planes than the batch box declares
+constexpr int WL_RETRY_NOVIEW = -1001;
 inline size_t ws_ab_each(int64_t N, int nt) { return (size_t)((N >> nt) + 64); }
 inline size_t ws_ab_elems(int64_t N, int nt) { return 2 * ws_ab_each(N, nt); }
 inline size_t ws_elems(int64_t N, int nt = 1) { return ws_ab_elems(N, nt) + (size_t)(3 * N + 64); }

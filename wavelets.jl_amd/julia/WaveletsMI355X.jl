@@ -313,7 +313,7 @@ function Threshold.denoise(x::ROCArray{T,N}, wt::OrthoFilter=Threshold.DEFAULT_W
     end
     Util.iscube(x) || throw(ArgumentError("array must be square/cube"))
     sigma = estnoise === noisest ? -1.0 : Float64(estnoise(x, wt))
-    estnoise === noisest || (sigma >= 0 && isfinite(sigma)) || throw(AssertionError("t >= 0"))   # threshold_main.jl:24
+    estnoise === noisest || (sigma >= 0 && sigma * dnt.t >= 0) || throw(AssertionError("t >= 0"))   # threshold_main.jl:24 (+Inf passes, NaN does not)
     y = similar(x)
     nsp = N == 1 ? Int64[prod(nspt), 1, 1] : Int64[nspt..., 1]      # vectors: prod(nspin) spins shifted by 0 .. pns-1 (denoising.jl:38-42)
     GC.@preserve y x check(ccall((:wl_denoise_ti_filter, LIB), Cint,

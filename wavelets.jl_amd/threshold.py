@@ -234,18 +234,22 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
         # (wl_denoise_ti_filter) -- all spins transformed / thresholded / inverted together, the noise estimate consumed on
         # the device, nothing allocated per spin, no host synchronisation.  Same arithmetic in the same order as the loop below.
         sig = -1.0 if estnoise is noisest else float(estnoise(x, wt))
-        if estnoise is not noisest and not (sig >= 0 and np.isfinite(sig)):
-            raise AssertionError("t >= 0")               # (@assert t >= 0 in threshold!, threshold_main.jl:24; NaN fails it too)
+        if estnoise is not noisest and not (sig >= 0 and sig * float(dnt.t) >= 0):
+            raise AssertionError("t >= 0")               # (@assert t >= 0 in threshold!, threshold_main.jl:24, t = sigma * dnt.t: NaN
+            #                                              fails it, +Inf passes -- everything is thresholded -- as in the reference)
         y = similar(x)
         h, st = _context(x.device)
         q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
         # vectors: prod(nspin) spins shifted by 0 .. pns-1 whatever nspin's length (denoising.jl:38-42)
         nsl = [int(np.prod(nsp))] if x.dim() == 1 else list(nsp)
         nsv = (C.c_int64 * 3)(*(nsl + [1] * (3 - len(nsl))))
-        _check(_lib.load().wl_denoise_ti_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
-                                                q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), dnt.th.code, float(dnt.t), nsv,
-                                                sig, st), h)
-        return y
+        rc = _lib.load().wl_denoise_ti_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
+                                              q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), dnt.th.code, float(dnt.t), nsv,
+                                              sig, st)
+        if not (one_spin and _lib.STATUS.get(rc) == "WL_ENOMEM"):
+            _check(rc, h)
+            return y
+        # (one spin and no room for its workspace: the reference's own sequence below, which needs far less)
     sigma = estnoise(x, wt)
     t = sigma * dnt.t
     if TI:

@@ -173,6 +173,16 @@ WL_API int wl_dwtc_lifting_oop(wl_ctx *ctx, int dtype, void *y, const void *x,
                         const int32_t *step_shift, const double *coefs_flat,
                         double norm1, double norm2, int L, int fw, void *stream);
 
+/* ---- a batch of independent 2-D transforms ----------------------------------------------- */
+/* y[:, :, i] = dwt(x[:, :, i], filter, L) (fw = 0: idwt) for i = 0 .. nimages-1: nimages images of dims[0] x dims[1]
+ * (column-major, dense), image i at element offset i * image_stride of x and of y (image_stride >= dims[0] * dims[1]).
+ * The same results as nimages calls of wl_dwt_filter with ndims = 2 -- the reference has no batched form
+ * (transforms_filter.jl:113-188 is the per-image loop) -- but every level is ONE launch over all images: mid-size images,
+ * whose single transform is launch latency rather than bandwidth, fill the chip together.  Workspace:
+ * wl_workspace_bytes(dtype, 1, {nimages * image_stride}, L) is an upper bound for the fast paths.                          */
+WL_API int wl_dwt_filter_batch(wl_ctx *ctx, int dtype, void *y, const void *x, const int64_t *dims, int64_t nimages,
+                        int64_t image_stride, const double *qmf, int flen, int L, int fw, void *stream);
+
 /* ---- wavelet packet transform (1-D) --------------------------------------------------- */
 /* y = wpt(x, filter, tree) / iwpt.  tree: one byte per node of the BitVector
  * (length 2^maxtransformlevels(n) - 1, util_main.jl:301-344), HOST pointer; it is copied before the call returns (the node

@@ -1347,6 +1347,25 @@ def test_wpt_fast_paths_bitexact_and_pinned(gpu, W, oracle):
     assert np.array_equal(host(W, yd), ye)
 
 
+def test_batch_of_images_bitexact(gpu, W, oracle):
+    """wl_dwt_filter_batch: B independent images, every level one launch over all of them == B single transforms (the oracle's)"""
+    import torch
+    for (n0, n1, nb, L, fname, dtype) in ((512, 512, 5, 4, "db4", np.float32), (1024, 512, 3, 9, "sym5", np.float32), (2048, 2048, 2, 11, "db4", np.float32),
+                                           (256, 256, 7, 8, "db2", np.float64), (96, 160, 4, 5, "db4", np.float32), (64, 64, 9, 6, "haar", np.float32)):
+        wt = W.wavelet(getattr(W.WT, fname))
+        xs = [rng_array((n0, n1), dtype, 100 + i) for i in range(nb)]
+        xb = torch.stack([W.to_device(a).t().contiguous() for a in xs]).permute(2, 1, 0)      # n0 x n1 x B, column-major
+        assert xb.stride() == (1, n0, n0 * n1)
+        yb = W.dwt_batch(xb, wt, L)
+        for i in range(nb):
+            e = oracle.dwt_filter(xs[i], wt.qmf, L)
+            assert np.array_equal(yb[:, :, i].cpu().numpy(), e), (n0, n1, L, fname, i)
+        xr = W.idwt_batch(yb, wt, L)
+        for i in range(nb):
+            e = oracle.dwt_filter(oracle.dwt_filter(xs[i], wt.qmf, L), wt.qmf, L, fw=False)
+            assert np.array_equal(xr[:, :, i].cpu().numpy(), e), (n0, n1, L, fname, i)
+
+
 # ---- BASELINE.json full sizes: size-independent properties -------------------------------------------
 def test_full_size_properties(gpu, W, oracle):
     """configs[1..3] at full size: round trip, linearity, energy, and exact equality with the oracle on

@@ -16,7 +16,7 @@ from .util import (maxtransformlevels, sufficientpoweroftwo, detailindex, detail
                    ndyadicscales, maketree, isvalidtree, iscube, isdyadic,
                    dyadicdetailindex, dyadicdetailrange, dyadicscalingrange, dyadicdetailn, maxdyadiclevel, tl2dyadiclevel,
                    dyadiclevel2tl, mirror, upsample, downsample, wcount, testfunction)
-from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwtc, dwtc_, idwtc_, wpt, iwpt, wpt_, iwpt_,
+from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwtc, dwtc_, idwtc_, wpt, iwpt, wpt_, iwpt_, dwt_batch, idwt_batch,
                          to_device, to_host, similar, julia_layout, is_julia_layout,
                          reserve_workspace, workspace_held, set_kernel_path, last_kernel, destroy_contexts, set_option, clear_options, options,
                          DimensionMismatch, ArgumentError, HIPError)
@@ -27,7 +27,7 @@ from . import _lib
 
 __all__ = [
     "WT", "Util", "wavelet", "OrthoFilter", "GLS",
-    "dwt", "idwt", "dwt_", "idwt_", "dwt_oop_", "idwt_oop_", "dwtc", "idwtc", "dwtc_", "idwtc_", "wpt", "iwpt", "wpt_", "iwpt_",
+    "dwt", "idwt", "dwt_", "idwt_", "dwt_oop_", "idwt_oop_", "dwtc", "idwtc", "dwtc_", "idwtc_", "wpt", "iwpt", "wpt_", "iwpt_", "dwt_batch", "idwt_batch",
     "maxtransformlevels", "sufficientpoweroftwo", "detailindex", "detailrange", "detailn",
     "ndyadicscales", "maketree", "isvalidtree", "iscube", "isdyadic",
     "dyadicdetailindex", "dyadicdetailrange", "dyadicscalingrange", "dyadicdetailn", "maxdyadiclevel", "tl2dyadiclevel",

@@ -62,6 +62,7 @@ SIGNATURES = {
                                   _f64p, C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
     "wl_dwtc_lifting_oop": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, _i32p, _i32p, _i32p,
                                   _f64p, C.c_double, C.c_double, C.c_int, C.c_int, _vp]),
+    "wl_dwt_filter_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64p, C.c_int64, C.c_int64, _f64p, C.c_int, C.c_int, C.c_int, _vp]),
     "wl_wpt_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, _f64p, C.c_int, _u8p, C.c_int64, C.c_int, _vp]),
     "wl_wpt_lifting": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _i32p, _i32p, _i32p, _f64p,
                                  C.c_double, C.c_double, _u8p, C.c_int64, C.c_int, _vp]),

@@ -785,6 +785,35 @@ int wl_wpt_lifting(wl_ctx *ctx, int dtype, void *y, int64_t n,
     return wpt_impl<double>(ctx, st, (double *)y, (const double *)y, n, nullptr, &sc, tree, ntree, last_set, fw);
 }
 
+int wl_dwt_filter_batch(wl_ctx *ctx, int dtype, void *y, const void *x, const int64_t *dims, int64_t nimages, int64_t image_stride,
+                        const double *qmf, int flen, int L, int fw, void *stream)
+{
+    if (!ctx || !y || !x || !dims || !qmf) return WL_EINVAL_ARG;
+    if (dtype != WL_F32 && dtype != WL_F64) return WL_EINVAL_DTYPE;
+    if (flen < 2 || flen > WL_MAX_FLEN) return WL_EINVAL_FILTER;
+    if (dims[0] < 1 || dims[1] < 1 || nimages < 1 || image_stride < dims[0] * dims[1]) return WL_EDIMS;
+    if (L < 0) return WL_EINVAL_L;
+    if (!sufficientpoweroftwo(dims[0], L) || !sufficientpoweroftwo(dims[1], L)) return WL_EINVAL_SIZE;
+    if (y == x) return WL_EALIAS;
+    BoxSpec b;
+    b.nd = 3; b.nt = 2;
+    b.dims[0] = dims[0]; b.dims[1] = dims[1]; b.dims[2] = nimages;
+    b.full.s[0] = 1; b.full.s[1] = dims[0]; b.full.s[2] = image_stride;
+    WL_SCOPE(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    // images in groups of at most 65535 (one grid row / plane per image in the batched kernels)
+    const size_t es = dtype == WL_F32 ? 4 : 8;
+    for (int64_t i0 = 0; i0 < nimages; i0 += 65535) {
+        b.dims[2] = (nimages - i0 < 65535) ? (nimages - i0) : 65535;
+        char *yy = (char *)y + (size_t)i0 * image_stride * es;
+        const char *xx = (const char *)x + (size_t)i0 * image_stride * es;
+        int rc = dtype == WL_F32 ? dwt_filter_impl<float>(ctx, st, b, (float *)yy, (const float *)xx, qmf, flen, L, fw)
+                                 : dwt_filter_impl<double>(ctx, st, b, (double *)yy, (const double *)xx, qmf, flen, L, fw);
+        if (rc) return rc;
+    }
+    return WL_OK;
+}
+
 int wl_wpt_filter_full(wl_ctx *ctx, int dtype, void *y, const void *x, int64_t n, const double *qmf, int flen, int L, int fw, void *stream)
 {
     if (!ctx || !y || !x || !qmf) return WL_EINVAL_ARG;

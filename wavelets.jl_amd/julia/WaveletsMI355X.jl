@@ -198,6 +198,20 @@ for (f, fw) in ((:dwtc, true), (:idwtc, false))
     end
 end
 
+# ---- a batch of independent images: x[:, :, i] -> dwt(x[:, :, i], filter, L), every level ONE launch over all images ----
+# (no counterpart in the reference: its 2-D transform is per image, transforms_filter.jl:113-188)
+for (f, fw) in ((:dwt_batch, true), (:idwt_batch, false))
+    @eval function $f(x::ROCArray{T,3}, filter::OrthoFilter,
+                      L::Integer=min(Util.maxtransformlevels(size(x, 1)), Util.maxtransformlevels(size(x, 2)))) where {T<:Union{Float32,Float64}}
+        y = similar(x)
+        GC.@preserve y x check(ccall((:wl_dwt_filter_batch, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Int64, Int64, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(y), pointer(x), Int64[size(x, 1), size(x, 2)], size(x, 3), size(x, 1) * size(x, 2),
+                    filter.qmf, length(filter.qmf), L, $fw, stream()))
+        return y
+    end
+end
+
 # ---- multi-GPU dwtc: shard the columns of a batch over the devices of one node --------------------------------------
 # The path has no exchange step (SURVEY.md 8e): columns are independent, so rank r of `world` transforms the contiguous
 # column block `shard_range(nsignals, r, world)` on its own GPU with its own context; only the wavelet description (a few

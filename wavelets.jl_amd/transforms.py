@@ -426,6 +426,36 @@ def idwtc_(y, x, wt, L: Optional[int] = None) -> torch.Tensor:
     return _xwtc(x, wt, L, False, y)
 
 
+# ---- a batch of independent images --------------------------------------------------------------
+def _xwt_batch(x, wt, L, fw, y=None):
+    """x: n0 x n1 x B (column-major: image i = x[:, :, i]); every image gets its own 2-D transform, all in one chain of
+    launches (wl_dwt_filter_batch).  The reference has no batched form: this equals `stack(dwt(x[:, :, i], wt, L) for i)`."""
+    x = _prep_in(x)
+    if x.dim() != 3:
+        raise TypeError("dwt_batch expects an n0 x n1 x B array")
+    if not isinstance(wt, OrthoFilter):
+        raise TypeError("dwt_batch is defined for orthogonal filters")
+    n0, n1, nb = (int(v) for v in x.shape)
+    L = min(Util.maxtransformlevels(n0), Util.maxtransformlevels(n1)) if L is None else int(L)
+    y = similar(x) if y is None else y
+    lib = _lib.load()
+    h, st = _context(x.device)
+    q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
+    dims = (C.c_int64 * 2)(n0, n1)
+    rc = lib.wl_dwt_filter_batch(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), dims, nb, n0 * n1,
+                                 _f64p(q), len(q), L, 1 if fw else 0, st)
+    _check(rc, h)
+    return y
+
+
+def dwt_batch(x, wt, L: Optional[int] = None, y=None) -> torch.Tensor:
+    return _xwt_batch(x, wt, L, True, y)
+
+
+def idwt_batch(x, wt, L: Optional[int] = None, y=None) -> torch.Tensor:
+    return _xwt_batch(x, wt, L, False, y)
+
+
 # ---- wavelet packet transforms -------------------------------------------------------------------
 class _FullTree(int):
     """wpt(x, wt, L::Integer): the full tree of depth L -- never materialised (a tree has n - 1 nodes; the library's

@@ -101,8 +101,10 @@ WL_API int wl_ctx_destroy(wl_ctx *ctx);
  * ndims = 1 and dims[0] = len * nsignals).  wl_ctx_reserve grows the context's workspace
  * once so that later calls of that kind never allocate.  Lifting transforms, long (> 10 taps
  * in 2-D) / odd-length filters, 3-D boxes and the generic kernel family use up to 4 N more
- * elements: the context grows to that on their first call (grow-only; a call that grows the
- * workspace synchronises the device).  wl_ctx_workspace_held reports the current size.    */
+ * elements: the context grows to that on their first call.  Growth inside a transform call is STREAM-ORDERED (hipFreeAsync /
+ * hipMallocAsync on the call's stream: the old block is released behind the work already queued, nothing waits on the host and
+ * the device is not synchronised); wl_ctx_reserve itself, which takes no stream, synchronises the device when it has to grow.
+ * wl_ctx_workspace_held reports the current size.                                                                          */
 WL_API size_t wl_workspace_bytes(int dtype, int ndims, const int64_t *dims, int L);
 /* Upper bound for every TRANSFORM entry point on this shape (wl_dwt_*, wl_dwtc_*, wl_wpt_*: lifting, long / odd filters,
  * 3-D, the generic kernel family): reserve this much and no later transform of that shape allocates or synchronises,

@@ -15,19 +15,42 @@ using namespace wl;
 
 thread_local const wl::Opts *wl::tl_opts = nullptr;
 
-int wl_ensure_ws(wl_ctx *ctx, size_t bytes)
+int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st, bool ordered)
 {
     if (bytes <= ctx->ws_bytes) return WL_OK;
-    // grow-only; the old block may still be in use by kernels queued on the caller's
-    // stream, so synchronise the device before freeing it (rare: only on growth).
-    WL_HIP(ctx, hipDeviceSynchronize());
-    if (ctx->ws) { WL_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    // Grow-only.  The old block may still be in use by kernels queued on the caller's stream.
+    //  * ordered (growth inside a transform call, round 4): STREAM-ORDERED -- the old block is released and the new one allocated
+    //    in the order of the call's stream (hipFreeAsync / hipMallocAsync), nothing waits on the host, the device is not
+    //    synchronised.  A context belongs to one stream (header), so every user of the old block is ahead of the release.
+    //  * otherwise (wl_ctx_reserve, which takes no stream): device synchronisation, then the same pool on the null stream,
+    //    synchronised before returning so that the block is usable from any stream.
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    const bool pool = wl::opt("WL_WS_SYNC_ALLOC", 0) == 0;
     void *p = nullptr;
-    size_t want = (bytes + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) { ctx->last_hip = (int)e; return WL_ENOMEM; }
+    if (ordered && pool && (ctx->ws == nullptr || ctx->ws_pooled)) {
+        if (ctx->ws) { WL_HIP(ctx, hipFreeAsync(ctx->ws, st)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+        hipError_t e = hipMallocAsync(&p, want, st);
+        if (e != hipSuccess) { (void)hipGetLastError(); ctx->last_hip = (int)e; return WL_ENOMEM; }
+        ctx->ws = p; ctx->ws_bytes = want; ctx->ws_pooled = true;
+        return WL_OK;
+    }
+    WL_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->ws) {
+        if (ctx->ws_pooled) { WL_HIP(ctx, hipFreeAsync(ctx->ws, nullptr)); WL_HIP(ctx, hipStreamSynchronize(nullptr)); }
+        else WL_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr; ctx->ws_bytes = 0;
+    }
+    hipError_t e;
+    if (pool) {
+        e = hipMallocAsync(&p, want, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    } else {
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ctx->last_hip = (int)e; return WL_ENOMEM; }
     ctx->ws = p;
     ctx->ws_bytes = want;
+    ctx->ws_pooled = pool;
     return WL_OK;
 }
 
@@ -54,6 +77,7 @@ namespace {
 inline bool sufficientpoweroftwo(int64_t n, int L) { return L < 62 && (n % ((int64_t)1 << L)) == 0; }
 
 inline int ensure_ws(wl_ctx *ctx, size_t bytes) { return wl_ensure_ws(ctx, bytes); }
+inline int ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st) { return wl_ensure_ws(ctx, bytes, st, true); }
 
 // makescheme (transforms_lifting.jl:13-25)
 template <typename T>
@@ -220,7 +244,7 @@ int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T
     // never modified by a filter transform, so repeating is harmless.
     const size_t ab_bytes = ws_ab_elems(N, b.nt) * sizeof(T), full_bytes = ws_elems(N, b.nt) * sizeof(T);
     const bool want_gen = (ctx->path != 0) || (b.nd == 3) || (flen % 2 != 0) || (flen > 10 && b.nt > 1);
-    int rc = ensure_ws(ctx, want_gen ? full_bytes : ab_bytes);
+    int rc = ensure_ws(ctx, want_gen ? full_bytes : ab_bytes, st);
     if (rc) return rc;
     Taps<T> taps;
     make_taps<T>(qmf, flen, taps);
@@ -229,7 +253,7 @@ int dwt_filter_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T
         rc = fw ? filter_fwd_levels<T>(ctx->ws, have_gen, ctx->cu_count, ctx->path, st, b, y, x, taps, L, &ctx->last_kernel, &ctx->last_hip)
                 : filter_inv_levels<T>(ctx->ws, have_gen, ctx->cu_count, ctx->path, st, b, y, x, taps, L, &ctx->last_kernel, &ctx->last_hip);
         if (rc != WL_RETRY_GEN) return rc;
-        rc = ensure_ws(ctx, full_bytes);
+        rc = ensure_ws(ctx, full_bytes, st);
         if (rc) return rc;
     }
     return WL_EINVAL_ARG;
@@ -252,7 +276,7 @@ int dwt_lifting_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const 
         ctx->last_kernel = "copy";
         return WL_OK;
     }
-    rc = ensure_ws(ctx, ws_elems(N) * sizeof(T));
+    rc = ensure_ws(ctx, ws_elems(N) * sizeof(T), st);
     if (rc) return rc;
     if (ctx->path == 0 && b.nt == 1 && b.full.s[0] == 1) {
         int handled = 0;
@@ -339,7 +363,7 @@ int wl_ctx_destroy(wl_ctx *ctx)
     {
         CallScope scope(ctx);                  // free on the context's device, leave the caller's device current
         if (ctx->ws || ctx->aux || ctx->stage_ev[0]) (void)hipDeviceSynchronize();
-        if (ctx->ws) (void)hipFree(ctx->ws);
+        if (ctx->ws) { if (ctx->ws_pooled) { (void)hipFreeAsync(ctx->ws, nullptr); (void)hipStreamSynchronize(nullptr); } else (void)hipFree(ctx->ws); }
         if (ctx->aux) (void)hipFree(ctx->aux);
         for (int k = 0; k < wl_ctx::kStage; ++k) {
             if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -616,7 +640,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     while (ncopy - 1 <= last_set && ncopy - 1 < ntree) ncopy <<= 1;
     ncopy = (ncopy - 1 < ntree) ? ncopy - 1 : ntree;
     if (full_depth >= 0) ncopy = 0;
-    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)(any_partial ? ncopy : 0) + 256);
+    int rc = ensure_ws(ctx, ws_elems(n) * sizeof(T) + (size_t)(any_partial ? ncopy : 0) + 256, st);
     if (rc) return rc;
     Work<T> w = carve<T>(ctx->ws, n);
     uint8_t *dtree = (uint8_t *)ctx->ws + ws_elems(n) * sizeof(T);

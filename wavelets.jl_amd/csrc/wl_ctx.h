@@ -7,6 +7,7 @@ struct wl_ctx {
     int device = 0;
     void *ws = nullptr;                 // grow-only transform workspace
     size_t ws_bytes = 0;
+    bool ws_pooled = false;             // allocated from the stream-ordered pool (hipMallocAsync): released with hipFreeAsync
     void *aux = nullptr;                // small persistent block: order-statistic selection state (wl_ext.hip)
     int last_hip = 0;
     int path = 0;                       // 0 auto, 1 generic only
@@ -65,5 +66,6 @@ inline int hip_fail(wl_ctx *ctx, hipError_t e)
         if (e__ != hipSuccess) return hip_fail((ctx), e__); \
     } while (0)
 
-// grow the workspace to at least `bytes` (synchronises the device when it has to reallocate)
-int wl_ensure_ws(wl_ctx *ctx, size_t bytes);
+// grow the workspace to at least `bytes`: stream-ordered on `st` (no synchronisation) when `ordered`, otherwise with a device
+// synchronisation (wl_ctx_reserve)
+int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st = nullptr, bool ordered = false);

@@ -252,7 +252,7 @@ template <typename T>
 int modwt_impl(wl_ctx *ctx, hipStream_t st, T *out, int64_t ldo, const T *x, int64_t N, const double *qmf, int flen, int L)
 {
     constexpr int V = 16 / sizeof(T);
-    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
+    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T), st, true);
     if (rc != WL_OK) return rc;
     ModwtTaps tp;
     make_modwt_taps(qmf, flen, tp);
@@ -285,7 +285,7 @@ template <typename T>
 int imodwt_impl(wl_ctx *ctx, hipStream_t st, T *x, const T *xw, int64_t ldw, int64_t N, int ncols, const double *qmf, int flen)
 {
     constexpr int V = 16 / sizeof(T);
-    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T));
+    int rc = wl_ensure_ws(ctx, (size_t)2 * N * sizeof(T), st, true);
     if (rc != WL_OK) return rc;
     ModwtTaps tp;
     make_modwt_taps(qmf, flen, tp);
@@ -885,10 +885,10 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     int64_t B = pns;
     while (B > 1 && need(B) > cap) B = (B + 1) / 2;
     if (B > 65535) B = 65535;
-    rc = wl_ensure_ws(ctx, need(B));
+    rc = wl_ensure_ws(ctx, need(B), st, true);
     while (rc == WL_ENOMEM && B > 1) {                      // (another allocator may own most of the HBM: smaller groups of spins)
         B = (B + 1) / 2;
-        rc = wl_ensure_ws(ctx, need(B));
+        rc = wl_ensure_ws(ctx, need(B), st, true);
     }
     if (rc != WL_OK) return rc;
     T *tw = (T *)ctx->ws;                                   // transform workspace of the batch box (with the generic buffers)

@@ -1525,6 +1525,18 @@ def test_whole_c5_batch_on_one_gpu(gpu, W):
     assert W.workspace_held() <= 2 ** 34 + 4096, W.workspace_held()
     for j in (0, 1, 32767, 32768, 65534, 65535):
         assert torch.equal(W.dwt(x[:, j].contiguous(), wt, 16), y[:, j]), j
+    # round 4: EVERY column, not a sample -- the 1-D transform of each of the 65536 signals (a different kernel chain: one line
+    # instead of a batch; itself pinned to the oracle at this length by test_full_size_properties) must give the bits of the
+    # batch's column.  Mismatches are counted on the device; ~25 us per column.
+    col = torch.empty(n, dtype=torch.float32, device=gpu)
+    yc = torch.empty(n, dtype=torch.float32, device=gpu)
+    bad = torch.zeros((), dtype=torch.int64, device=gpu)
+    W.reserve_workspace(col, 16)
+    for j in range(ns):
+        col.copy_(x[:, j])
+        W.dwt_oop_(yc, col, wt, 16)
+        bad += (yc != y[:, j]).any()
+    assert int(bad.item()) == 0, "%d of %d columns of the batch differ from their 1-D transform" % (int(bad.item()), ns)
     xr = W.idwtc(y, wt, 16)
     assert (xr - x).abs().max().item() < 1e-4
     del x, y, xr

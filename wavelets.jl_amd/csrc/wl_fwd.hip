@@ -1181,8 +1181,18 @@ static hipError_t launch_fwd1d_multi(hipStream_t st, const Taps<T> &taps, bool l
     a.src = src; a.src_ls = src_ls; a.y = y; a.y_ls = y_ls; a.sdst = sdst; a.s_ls = s_ls; a.n = n; a.NL = NL;
     // tile = 32 KiB of input for long lines; shorter tiles (down to 4 KiB) when there would otherwise be
     // fewer workgroups than CUs -- a workgroup's latency chain (stage, NL levels, barriers) is ~constant
-    a.TS = env_int("WL_TS", (int)(16384 / sizeof(T)));
-    if (a.TS < 256 || (a.TS % 64) != 0) a.TS = (int)(16384 / sizeof(T));
+    a.TS = env_int("WL_TS", 0);
+    if (a.TS < 256 || (a.TS % 64) != 0) {
+        a.TS = (int)(16384 / sizeof(T));
+        // Long lines: shave the tile so that level 1 -- TS / 2 + 2 H1 pairs, 256 threads x (16 / sizeof(T)) pairs per round -- takes
+        // TWO rounds of the workgroup instead of two and a sliver (TS = 4096, db4, 4 levels: 521 thread groups for 512 slots per two
+        // rounds; level 2 likewise 265 for 256): 7 rounds per tile become 5 for 5 % fewer samples.  Same bits (tiles are a
+        // partition, the last one is partial).  r04: C5 first pass 910 -> 869 us, C2 49.0 -> 47.1 us.  Lines of a few tiles keep
+        // the power of two (a partial last tile would be most of the work).
+        const int H1 = (F - 2) * ((1 << (NL - 1)) - 1);
+        const int fit = ((a.TS - 4 * H1) / 64) * 64;
+        if (env_int("WL_TS_FIT", 1) && n >= 8 * (int64_t)a.TS && fit >= a.TS / 2) a.TS = fit;
+    }
     while (a.TS > (int)(4096 / sizeof(T)) && ((n + a.TS - 1) / a.TS) * nlines < 512) a.TS >>= 1;
     a.tp = shrink<T, F>(taps);
     const int H0 = (F - 2) * ((1 << NL) - 1), H1 = (F - 2) * ((1 << (NL - 1)) - 1);

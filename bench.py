@@ -11,22 +11,26 @@ data already resident in HBM; output array and workspace are allocated once, out
   --gpus N > 1         workload C5 = configs[4]: batched column-wise dwt, WT.db4, 65536 signals x 2^16 Float32, L = 16, the
                        batch block-partitioned over the N ranks (one process per GPU, sharding.shard_range; rank 0's taps reach
                        the other ranks by one RCCL broadcast; no signal data crosses GPUs).  value = whole batch / max-over-ranks
-                       time ("scaling": "strong").  The C3 weak-scaling figure (every rank its own 8192 x 8192 image) is kept
-                       as the nested object `c3_weak_scaling`.
+                       time ("scaling": "strong").  Nested: `c3_weak_scaling` (every rank its own 8192 x 8192 image) and
+                       `single_gpu_same_batch` (the whole batch on rank 0 alone, measured in the same job: the N = 1 point).
+  --gpus 1 --workload c5   the same line for N = 1 (the object `c5_batched` of the default line has the same keys).
                        Started plainly (`python bench.py --gpus N`) the script re-launches ITSELF through torch.distributed.run
                        with N ranks; under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 Objects on the JSON line:
-  roofline       the dominant kernel = the launch that consumes the full-size input (C3: k_fwd2d_pair, levels 1-2 fused; it reads
-                 N samples and writes N coefficients = 8 B/sample): algorithmic bytes / average launch duration, HIP events
-                 on the launch stream around a train of such launches; `rocprof` = the same figure from the committed
-                 rocprofv3 summary under profiles/; `traffic` = HBM bytes per launch from the committed PMC passes
+  roofline       the dominant kernel = the launch that consumes the full-size input (C3: k_fwd2d_pair, levels 1-2 fused; C5: every
+                 rank's first k_fwd1d_multi pass, levels 1-4): algorithmic bytes / average launch duration, HIP events on the launch
+                 stream around a train of such launches; `rocprof` = the same figure from the committed rocprofv3 summary under
+                 profiles/; `traffic` = HBM bytes per launch from the PMC counters, MEASURED IN THIS RUN for C3 when rocprofv3 is
+                 present (two separate --pmc passes of tools/wlbench.bin), else the committed collection
   by_depth       ms per transform and fraction of the 8 TB/s roofline at L = 1, 4, 13
   cpu_baseline   the oracle's sources (literal C restatement of the reference's single-threaded loops) built -O3 -march=native
                  on THIS host and timed on a bounded sample: 1 warm-up + 3 repetitions, median; 1 core (the reference has no
                  threading) and, beside it, the OpenMP-over-lines variant on all host cores
-  secondary_configs   the other BASELINE configs and section-8(f) rows: >= 20 repetitions, one HIP event pair per repetition,
-                 median and minimum (one runtime hiccup cannot poison a figure)
+  secondary_configs   the other BASELINE configs and section-8(f) rows, cache-cold (5 inputs in rotation for the 64 MiB 1-D configs,
+                 3 for the 256 MiB 2-D ones): >= 20 repetitions, one HIP event pair per repetition, median and minimum; C2 and C4
+                 carry their own `roofline` object
+  reference_gpu_benchmark_shapes   the shapes of the reference's benchmark/gpu_benchmark.jl through the allocating calls
 
 Other workloads (parity-test configs, not the headline): --workload c1|c2|c4|c5.
 """
@@ -519,9 +523,9 @@ def main():
         del yout, xs, x
         torch.cuda.empty_cache()
         out["c5_batched"] = multi_gpu_line(args, rank, world, dist, sharding, device, HipBackend(W, sharding, dist, device),
-                                           steps=8, warm=2, nested=False)
+                                           steps=12, warm=6, nested=False)
         out["c5_batched"]["note"] = ("the N = 1 point of the multi-GPU curve: the same object `--gpus N` prints as its top level "
-                                     "(8 steps here; `--gpus 1 --workload c5` runs it with --steps)")
+                                     "(12 steps after 6 warm-up steps here; `--gpus 1 --workload c5` runs it with --steps)")
     if rank == 0 and world == 1 and workload == "c3" and not args.no_secondary:
         xs = x = yout = None
         torch.cuda.empty_cache()

@@ -80,6 +80,19 @@ elif case == "c1":
     x = torch.rand(1 << 20, generator=g, dtype=torch.float64).cuda()
     y = W.similar(x)
     fn = lambda: W.dwt_oop_(y, x, W.wavelet(W.WT.db2), 20)
+elif case == "lift1d_l1":                    # one launch of the C4 dominant kernel (k_lift1d_stream, level 1)
+    x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.dwt_oop_(y, x, sch, 1)
+elif case == "wpt":
+    x = torch.randn(1 << 22, generator=g, dtype=torch.float32).cuda()
+    y = W.similar(x)
+    fn = lambda: W.wpt_(y, x, db4, 6)
+elif case == "batch2d":
+    x = torch.randn(64, 2048, 2048, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
+    y = W.similar(x)
+    fn = lambda: W.dwt_batch(x, db4, 11, y=y)
 elif case == "denoise":
     x = torch.randn(2048, 2048, generator=g, dtype=torch.float32).cuda().t()
     fn = lambda: W.denoise(x, TI=True)

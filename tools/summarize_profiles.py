@@ -3,7 +3,7 @@ under profiles/: per-config bench lines, rocprofv3 kernel-stats CSVs, the PMC co
 profiles/pmc_latest.json (bytes per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 note) and the perf matrix."""
 import csv, glob, json, os, shutil, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -21,10 +21,14 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
-for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise", "dwt2d_f64", "dwt2d_db8"):
+for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise", "dwt2d_f64", "dwt2d_db8", "wpt", "batch2d"):
     p = find(f"stats_{k}", "*kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(DST, f"{R}_{k}_kernel_stats.csv"))
+for name in ("wpt_timings.md", "batch_of_images.md", "native_mgpu_1rank.json"):
+    q = os.path.join(SRC, name)
+    if os.path.exists(q) and os.path.getsize(q) > 50:
+        shutil.copy(q, os.path.join(DST, f"{R}_{name}"))
 p = os.path.join(SRC, "perf_matrix.md")
 if os.path.exists(p) and os.path.getsize(p) > 100:
     shutil.copy(p, os.path.join(DST, f"{R}_perf_matrix.md"))
@@ -44,6 +48,37 @@ def counters(sub):
         out[k] = (sum(v) / len(v), len(v))
     return out, p
 
+
+def config_pmc(tag, head, short, alg, signals=None, what=""):
+    """profiles/pmc_<tag>.json: HBM bytes per launch of the dominant kernel of a secondary config (same corrections as the headline)"""
+    global HEAD
+    keep_head = HEAD
+    HEAD = head
+    got = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        c, _ = counters(f"pmc_{tag}_{name}")
+        if name in c:
+            got[name] = c[name]
+    HEAD = keep_head
+    if len(got) != 2:
+        return
+    fetch = got["FETCH_SIZE"][0] * 1024 * 2
+    write = got["WRITE_SIZE"][0] * 1024
+    out = {"kernel": f"wl::{head} ({what})", "kernel_short": short, "FETCH_SIZE_KB_raw": round(got["FETCH_SIZE"][0], 1),
+           "WRITE_SIZE_KB_raw": round(got["WRITE_SIZE"][0], 1), "launches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]],
+           "fetch_bytes_corrected": int(fetch), "write_bytes": int(write), "hbm_bytes_per_launch": int(fetch + write),
+           "algorithmic_bytes_per_launch": alg,
+           "note": (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only (collection {R}); per-launch "
+                    "averages in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950). traffic/algorithmic = %.3f" % ((fetch + write) / alg))}
+    if signals:
+        out["signals_in_launch"] = signals
+    json.dump(out, open(os.path.join(DST, f"pmc_{tag}.json"), "w"), indent=1)
+
+
+config_pmc("c2", "k_fwd1d_multi<float, 8, 1>", "k_fwd1d_multi", 2 * (1 << 24) * 4, what="first launch of the 1-D db4 dwt of 2^24 f32: levels 1-4")
+config_pmc("c5", "k_fwd1d_multi<float, 8, 1>", "k_fwd1d_multi", 2 * 8192 * (1 << 16) * 4, signals=8192,
+           what="first launch of the batched dwt of an 8192 x 2^16 f32 shard: levels 1-4")
+config_pmc("c4", "k_lift1d_stream<float, 0, 1>", "k_lift1d_stream", 2 * (1 << 24) * 4, what="level 1 of the 1-D cdf9/7 lifting dwt of 2^24 f32")
 
 pm = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):

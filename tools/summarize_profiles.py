@@ -28,7 +28,12 @@ for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "mo
 for name in ("wpt_timings.md", "batch_of_images.md", "native_mgpu_1rank.json"):
     q = os.path.join(SRC, name)
     if os.path.exists(q) and os.path.getsize(q) > 50:
-        shutil.copy(q, os.path.join(DST, f"{R}_{name}"))
+        if name.endswith(".json"):          # (RCCL prints its banner on stdout: keep the JSON line only)
+            js = [l for l in open(q).read().splitlines() if l.startswith("{")]
+            if js:
+                open(os.path.join(DST, f"{R}_{name}"), "w").write(js[-1] + "\n")
+        else:
+            shutil.copy(q, os.path.join(DST, f"{R}_{name}"))
 p = os.path.join(SRC, "perf_matrix.md")
 if os.path.exists(p) and os.path.getsize(p) > 100:
     shutil.copy(p, os.path.join(DST, f"{R}_perf_matrix.md"))

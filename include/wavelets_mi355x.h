@@ -272,6 +272,13 @@ WL_API int wl_rmul(wl_ctx *ctx, int dtype, void *y, int64_t n, double s, void *s
 WL_API int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
                          const double *qmf, int flen, int L, int th, double t_unit, const int64_t *nspin,
                          double sigma_host, void *stream);
+/* The same for a lifting scheme (wt::GLS; scheme arguments as wl_dwt_lifting): shifted signals run as one batched-lines
+ * transform, shifted images one 2-D lifting transform per plane; sigma and everything else stay on the device.
+ * replaces the translation-invariant branch of denoise(x, wt::GLS; TI=true), denoising.jl:36-67 (round 4).               */
+WL_API int wl_denoise_ti_lifting(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                          int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef,
+                          const int32_t *step_shift, const double *coefs_flat, double norm1, double norm2,
+                          int L, int th, double t_unit, const int64_t *nspin, double sigma_host, void *stream);
 
 /* ---- introspection (tests / bench) ---------------------------------------------------- */
 /* Select the kernel family: 0 = auto (fast paths where they apply), 1 = generic kernels

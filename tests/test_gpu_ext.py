@@ -218,3 +218,28 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
         ez = _oracle_denoise(oracle, W, xz, wt, Lz, vs, False, None)
         yz = host(W, W.denoise(W.to_device(xz), L=Lz))
         assert np.array_equal(yz, ez) and np.array_equal(np.signbit(yz), np.signbit(ez)), Lz
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_denoise_ti_lifting_batch_bitexact(gpu, W, oracle, dtype):
+    """wl_denoise_ti_lifting (round 4): the translation-invariant branch of denoise for lifting schemes as one device-resident
+    batch -- value for value the reference's per-spin sequence (denoising.jl:36-67) as restated by the oracle"""
+    for sname in ("cdf97", "db2"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        v = (doppler(2048) + 0.05 * np.random.default_rng(14).standard_normal(2048)).astype(dtype)
+        for nsp, L, dnt in ((8, 6, W.VisuShrink(2048)), (5, 3, W.VisuShrink(W.SoftTH(), 1.5)), (3, 0, W.VisuShrink(W.HardTH(), 0.7))):
+            e = _oracle_denoise(oracle, W, v, sch, L, dnt, True, (nsp,))
+            y = host(W, W.denoise(W.to_device(v), sch, L=L, dnt=dnt, TI=True, nspin=nsp))
+            assert W.last_kernel() == "denoise_ti_lifting" and np.array_equal(y, e), (sname, nsp, L)
+        a = (doppler(256)[:, None] * doppler(256)[None, :] + 0.05 * np.random.default_rng(15).standard_normal((256, 256))).astype(dtype)
+        for nsp, L, dnt in (((3, 2), 5, W.VisuShrink(256)), ((2, 2), 2, W.VisuShrink(W.SteinTH(), 1.2))):
+            e = _oracle_denoise(oracle, W, a, sch, L, dnt, True, nsp)
+            y = host(W, W.denoise(W.to_device(a), sch, L=L, dnt=dnt, TI=True, nspin=nsp))
+            assert W.last_kernel() == "denoise_ti_lifting" and np.array_equal(y, e), (sname, nsp, L)
+        # spins in several groups (small buffer cap) and a custom estimate handed over as a host scalar
+        W.set_option("WL_TI_WS_CAP_MB", 1)
+        e = _oracle_denoise(oracle, W, a, sch, 4, W.VisuShrink(256), True, (3, 3))
+        assert np.array_equal(host(W, W.denoise(W.to_device(a), sch, L=4, TI=True, nspin=(3, 3))), e)
+        W.clear_options()
+        y2 = host(W, W.denoise(W.to_device(a), sch, L=4, TI=True, nspin=(3, 3), estnoise=lambda z, w: W.noisest(z, w)))
+        assert np.array_equal(y2, e)

@@ -87,7 +87,7 @@ def test_glue_binds_every_data_path_entry_point():
         "wl_ctx_create", "wl_ctx_destroy", "wl_ctx_set_option", "wl_strerror", "wl_shard_range",
         "wl_dwt_filter", "wl_dwt_lifting", "wl_dwt_lifting_oop", "wl_wpt_filter", "wl_wpt_lifting", "wl_wpt_filter_full", "wl_wpt_lifting_full",
         "wl_dwtc_filter", "wl_dwtc_lifting_oop", "wl_dwt_filter_batch", "wl_modwt", "wl_imodwt",
-        "wl_threshold", "wl_threshold_biggest", "wl_mad", "wl_circshift", "wl_arrayadd", "wl_denoise_ti_filter",
+        "wl_threshold", "wl_threshold_biggest", "wl_mad", "wl_circshift", "wl_arrayadd", "wl_denoise_ti_filter", "wl_denoise_ti_lifting",
     }
     assert required <= used, sorted(required - used)
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "wl_mad": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _f64p, _vp]),
     "wl_denoise_ti_filter": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_double, _i64p,
                                        C.c_double, _vp]),
+    "wl_denoise_ti_lifting": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, C.c_int, _i32p, _i32p, _i32p, _f64p, C.c_double, C.c_double,
+                                        C.c_int, C.c_int, C.c_double, _i64p, C.c_double, _vp]),
     "wl_circshift": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64p, _i64p, _vp]),
     "wl_arrayadd": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int64, _vp]),
     "wl_rmul": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_double, _vp]),

@@ -264,10 +264,29 @@ int dwt_lifting_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const 
                      int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift,
                      const double *coefs, double norm1, double norm2, int L, int fw)
 {
-    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
     LiftScheme<T> sc;
     int rc = make_scheme<T>(nsteps, is_update, ncoef, shift, coefs, norm1, norm2, fw, sc);
     if (rc) return rc;
+    return wl_lifting_box<T>(ctx, st, b, y, x, sc, L, fw);
+}
+
+}  // namespace
+
+template <typename T>
+int wl_make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift, const double *coefs, double norm1,
+                   double norm2, int fw, wl::LiftScheme<T> &sc)
+{
+    return make_scheme<T>(nsteps, is_update, ncoef, shift, coefs, norm1, norm2, fw, sc);
+}
+template int wl_make_scheme<float>(int, const int32_t *, const int32_t *, const int32_t *, const double *, double, double, int, wl::LiftScheme<float> &);
+template int wl_make_scheme<double>(int, const int32_t *, const int32_t *, const int32_t *, const double *, double, double, int, wl::LiftScheme<double> &);
+
+// the lifting transform of a box with a direction-adjusted scheme (shared with wl_ext.hip: the translation-invariant denoise)
+template <typename T>
+int wl_lifting_box(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const T *x, const LiftScheme<T> &sc, int L, int fw)
+{
+    const int64_t N = b.dims[0] * b.dims[1] * b.dims[2];
+    int rc = WL_OK;
     if (L == 0) {
         if (y != x) {
             Extent3 ext = {{b.dims[0], b.dims[1], b.dims[2]}};
@@ -302,8 +321,8 @@ int dwt_lifting_impl(wl_ctx *ctx, hipStream_t st, const BoxSpec &b, T *y, const 
     ctx->last_kernel = fw ? "k_generic_lift_fwd" : "k_generic_lift_inv";
     return fw ? generic_lifting_fwd<T>(ctx, st, b, y, x, sc, L) : generic_lifting_inv<T>(ctx, st, b, y, x, sc, L);
 }
-
-}  // namespace
+template int wl_lifting_box<float>(wl_ctx *, hipStream_t, const BoxSpec &, float *, const float *, const LiftScheme<float> &, int, int);
+template int wl_lifting_box<double>(wl_ctx *, hipStream_t, const BoxSpec &, double *, const double *, const LiftScheme<double> &, int, int);
 
 // ==========================================================================================
 extern "C" {

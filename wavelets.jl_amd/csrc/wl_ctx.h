@@ -69,3 +69,10 @@ inline int hip_fail(wl_ctx *ctx, hipError_t e)
 // grow the workspace to at least `bytes`: stream-ordered on `st` (no synchronisation) when `ordered`, otherwise with a device
 // synchronisation (wl_ctx_reserve)
 int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st = nullptr, bool ordered = false);
+
+// lifting transform of a box with a direction-adjusted scheme / makescheme (wl_api.hip; used by wl_ext.hip)
+template <typename T>
+int wl_lifting_box(wl_ctx *ctx, hipStream_t st, const wl::BoxSpec &b, T *y, const T *x, const wl::LiftScheme<T> &sc, int L, int fw);
+template <typename T>
+int wl_make_scheme(int nsteps, const int32_t *is_update, const int32_t *ncoef, const int32_t *shift, const double *coefs, double norm1,
+                   double norm2, int fw, wl::LiftScheme<T> &sc);

@@ -1017,6 +1017,92 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
     return WL_OK;
 }
 
+// ---- translation-invariant denoise with a lifting scheme (denoising.jl:36-67 with wt::GLS) --------------------------------
+// The same device-resident sequence as denoise_ti_impl -- sigma from the level-1 transform without a host round trip, the spins
+// shifted / transformed / thresholded / inverted / un-shifted / accumulated B at a time -- with the lifting transforms of the
+// library: a batch of shifted SIGNALS is one batched-lines call (the fused line kernels over all spins), a batch of shifted
+// IMAGES is one 2-D lifting transform per plane (the 2-D lifting kernels are not plane-batched).
+template <typename T>
+int denoise_ti_lifting_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, const int64_t *dims, const LiftScheme<T> &scf,
+                            const LiftScheme<T> &sci, int L, int th, double t_unit, const int64_t *nspin, double sigma_host)
+{
+    const int64_t n0 = dims[0], n1 = (ndims == 2) ? dims[1] : 1, N = n0 * n1;
+    const int64_t nsp0 = nspin[0], nsp1 = (ndims == 2) ? nspin[1] : 1, pns = nsp0 * nsp1;
+    int rc = ensure_aux(ctx);
+    if (rc != WL_OK) return rc;
+    SelState *sel = (SelState *)ctx->aux;
+    const size_t cap = (size_t)opt("WL_TI_WS_CAP_MB", 8192) << 20;
+    // transform workspace: the batched-lines box (1-D) or one plane (2-D), then the shifted copies Z and their coefficients XT
+    auto tws = [&](int64_t B) { return ws_elems(ndims == 1 ? N * B : N, 1); };
+    auto need = [&](int64_t B) { return (tws(B) + (size_t)2 * N * B + (size_t)n0 + 64) * sizeof(T); };
+    int64_t B = pns;
+    while (B > 1 && need(B) > cap) B = (B + 1) / 2;
+    if (B > 65535) B = 65535;
+    rc = wl_ensure_ws(ctx, need(B), st, true);
+    while (rc == WL_ENOMEM && B > 1) { B = (B + 1) / 2; rc = wl_ensure_ws(ctx, need(B), st, true); }
+    if (rc != WL_OK) return rc;
+    T *tw = (T *)ctx->ws;
+    T *Z = tw + tws(B);
+    T *XT = Z + N * B;
+    T *dr = XT + N * B;
+    BoxSpec b1;                                              // one signal / image
+    b1.nd = ndims; b1.nt = ndims;
+    b1.dims[0] = n0; b1.dims[1] = n1; b1.dims[2] = 1;
+    b1.full = dense_strides(b1.dims);
+    // ---- sigma = noisest(x, wt): level-1 transform, MAD of y1[detailrange(y1, 1)] ----
+    if (!(sigma_host >= 0)) {
+        if (n0 < 2 || (n0 % 2) != 0 || (ndims == 2 && (n1 % 2) != 0)) return WL_EINVAL_SIZE;
+        rc = wl_lifting_box<T>(ctx, st, b1, XT, x, scf, 1, 1);
+        if (rc != WL_OK) return rc;
+        const int64_t lo = (int64_t)llround((double)n0 / 2 + 1) - 1, hi = n0;
+        const int64_t nd = hi - lo;
+        hipLaunchKernelGGL((k_copy_range<T>), dim3(ext_blocks(nd, 1, ctx->cu_count)), dim3(EXT_THREADS), 0, st, dr, XT + lo, nd);
+        if (nd <= mad_lds_max<T>()) {
+            rc = mad_small<T>(ctx, st, dr, nd, 1, nullptr);
+            if (rc != WL_OK) return rc;
+        } else {
+            void *mdev = (char *)ctx->aux + 4096;
+            rc = median_impl<T>(ctx, st, dr, nd, nullptr, (T *)mdev);
+            if (rc != WL_OK) return rc;
+            hipLaunchKernelGGL((k_absdev<T>), dim3(ext_blocks(nd, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, dr, nd, (const T *)mdev, vec_ok16(dr));
+            rc = median_impl<T>(ctx, st, dr, nd, nullptr, (T *)nullptr);
+            if (rc != WL_OK) return rc;
+        }
+    }
+    TiGeom g;
+    g.n0 = n0; g.n1 = n1; g.N = N; g.nsp0 = nsp0; g.nsp1 = nsp1;
+    const unsigned gxs = (unsigned)((n0 / 4 + 255) / 256 > 0 ? ((n0 / 4 + 255) / 256 > 64 ? 64 : (n0 / 4 + 255) / 256) : 1);
+    auto transform = [&](T *dst, const T *src, int64_t nb, const LiftScheme<T> &sc, int fw) -> int {
+        if (ndims == 1) {                                    // nb signals = nb lines of one batched call
+            BoxSpec bb;
+            bb.nd = 2; bb.nt = 1;
+            bb.dims[0] = n0; bb.dims[1] = nb; bb.dims[2] = 1;
+            bb.full = dense_strides(bb.dims);
+            return wl_lifting_box<T>(ctx, st, bb, dst, src, sc, L, fw);
+        }
+        for (int64_t p = 0; p < nb; ++p) {
+            int r = wl_lifting_box<T>(ctx, st, b1, dst + p * N, src + p * N, sc, L, fw);
+            if (r != WL_OK) return r;
+        }
+        return WL_OK;
+    };
+    for (int64_t b0 = 0; b0 < pns; b0 += B) {
+        const int64_t nb = (pns - b0 < B) ? (pns - b0) : B;
+        g.b0 = b0;
+        hipLaunchKernelGGL((k_ti_shift<T>), dim3(gxs, (unsigned)((n1 + 7) / 8), (unsigned)nb), dim3(256), 0, st, Z, x, g);
+        rc = transform(XT, Z, nb, scf, 1);                   // (L = 0: a copy, as the reference's dwt is)
+        if (rc != WL_OK) return rc;
+        hipLaunchKernelGGL((k_threshold_dev<T>), dim3(ext_blocks(N * nb, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, XT, N * nb, th, &sel->result,
+                           t_unit, sigma_host, vec_ok16(XT));
+        rc = transform(Z, XT, nb, sci, 0);
+        if (rc != WL_OK) return rc;
+        hipLaunchKernelGGL((k_ti_accumulate<T>), dim3(gxs, (unsigned)n1), dim3(256), 0, st, y, Z, g, nb, b0 == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL((k_rmul<T>), dim3(ext_blocks(N, 4, ctx->cu_count)), dim3(EXT_THREADS), 0, st, y, N, 1.0 / (double)pns, vec_ok16(y));
+    WL_HIP(ctx, hipGetLastError());
+    return WL_OK;
+}
+
 inline int ext_enter(wl_ctx *ctx, int dtype)
 {
     if (!ctx) return WL_EINVAL_ARG;
@@ -1163,6 +1249,43 @@ int wl_denoise_ti_filter(wl_ctx *ctx, int dtype, void *y, const void *x, int ndi
     rc = dtype == WL_F32 ? denoise_ti_impl<float>(ctx, st, (float *)y, (const float *)x, ndims, dims, qmf, flen, L, th, t_unit, nspin, sigma_host)
                          : denoise_ti_impl<double>(ctx, st, (double *)y, (const double *)x, ndims, dims, qmf, flen, L, th, t_unit, nspin, sigma_host);
     if (rc == WL_OK) ctx->last_kernel = "denoise_ti_batch";
+    return rc;
+}
+
+int wl_denoise_ti_lifting(wl_ctx *ctx, int dtype, void *y, const void *x, int ndims, const int64_t *dims,
+                          int nsteps, const int32_t *step_is_update, const int32_t *step_ncoef, const int32_t *step_shift,
+                          const double *coefs_flat, double norm1, double norm2,
+                          int L, int th, double t_unit, const int64_t *nspin, double sigma_host, void *stream)
+{
+    int rc = ext_enter(ctx, dtype);
+    if (rc != WL_OK) return rc;
+    WL_SCOPE(ctx);
+    if (!y || !x || !dims || !nspin) return WL_EINVAL_ARG;
+    if (ndims < 1 || ndims > 2) return WL_EDIMS;
+    if (th < WL_TH_HARD || th > WL_TH_STEIN) return WL_EINVAL_ARG;
+    if (sigma_host != sigma_host || (sigma_host >= 0 && !(sigma_host * t_unit >= 0))) return WL_EINVAL_ARG;
+    for (int d = 0; d < ndims; ++d)
+        if (dims[d] < 1 || nspin[d] < 1) return WL_EDIMS;
+    if (ndims == 2 && dims[0] != dims[1]) return WL_EINVAL_CUBE;
+    if (ndims == 2 && dims[1] > 65535) return WL_EINVAL_SIZE;
+    if (L < 0) return WL_EINVAL_L;
+    for (int d = 0; d < ndims; ++d)
+        if (L >= 62 || (dims[d] % ((int64_t)1 << L)) != 0) return WL_EINVAL_SIZE;
+    if (y == x) return WL_EALIAS;
+    if (!(t_unit >= 0)) return WL_EINVAL_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == WL_F32) {
+        LiftScheme<float> f, i;
+        rc = wl_make_scheme<float>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, 1, f);
+        if (rc == WL_OK) rc = wl_make_scheme<float>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, 0, i);
+        if (rc == WL_OK) rc = denoise_ti_lifting_impl<float>(ctx, st, (float *)y, (const float *)x, ndims, dims, f, i, L, th, t_unit, nspin, sigma_host);
+    } else {
+        LiftScheme<double> f, i;
+        rc = wl_make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, 1, f);
+        if (rc == WL_OK) rc = wl_make_scheme<double>(nsteps, step_is_update, step_ncoef, step_shift, coefs_flat, norm1, norm2, 0, i);
+        if (rc == WL_OK) rc = denoise_ti_lifting_impl<double>(ctx, st, (double *)y, (const double *)x, ndims, dims, f, i, L, th, t_unit, nspin, sigma_host);
+    }
+    if (rc == WL_OK) ctx->last_kernel = "denoise_ti_lifting";
     return rc;
 }
 

@@ -338,4 +338,28 @@ function Threshold.denoise(x::ROCArray{T,N}, wt::OrthoFilter=Threshold.DEFAULT_W
     return y
 end
 
+# ... and for lifting schemes (wl_denoise_ti_lifting): same conditions, same fall-through
+function Threshold.denoise(x::ROCArray{T,N}, wt::GLS;
+                           L::Int=min(Util.maxtransformlevels(x), 6), dnt::S=VisuShrink(size(x, 1)),
+                           estnoise::Function=noisest, TI::Bool=false,
+                           nspin::Union{Int,Tuple}=tuple([8 for i = 1:ndims(x)]...)) where {T<:Union{Float32,Float64},N,S<:DNFT}
+    nspt = nspin isa Int ? (nspin,) : nspin
+    if !(TI && (N == 1 || (N == 2 && length(nspt) == 2)) && get(THCODE, typeof(dnt.th), Cint(9)) <= 3)
+        return invoke(Threshold.denoise, Tuple{AbstractArray,Union{Wavelets.WT.DiscreteWavelet,Nothing}}, x, wt;
+                      L=L, dnt=dnt, estnoise=estnoise, TI=TI, nspin=nspin)
+    end
+    Util.iscube(x) || throw(ArgumentError("array must be square/cube"))
+    sigma = estnoise === noisest ? -1.0 : Float64(estnoise(x, wt))
+    estnoise === noisest || (sigma >= 0 && sigma * dnt.t >= 0) || throw(AssertionError("t >= 0"))
+    y = similar(x)
+    isup, nc, sh, cf = flatten(wt)
+    nsp = N == 1 ? Int64[prod(nspt), 1, 1] : Int64[nspt..., 1]
+    GC.@preserve y x check(ccall((:wl_denoise_ti_lifting, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+                 Cdouble, Cdouble, Cint, Cint, Cdouble, Ptr{Int64}, Cdouble, Ptr{Cvoid}),
+                ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), length(isup), isup, nc, sh, cf, wt.norm1, wt.norm2,
+                L, THCODE[typeof(dnt.th)], Float64(dnt.t), nsp, sigma, stream()))
+    return y
+end
+
 end # module

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from . import util as Util
 from . import wt as WT
-from .transforms import (ArgumentError, DimensionMismatch, HIPError, _check, _context, _dims, _dtype_code, _prep_in,
+from .transforms import (ArgumentError, DimensionMismatch, HIPError, _check, _context, _dims, _dtype_code, _prep_in, _i32p, _f64p,
                          dwt, dwt_oop_, idwt, idwt_, idwt_oop_, is_julia_layout, julia_layout, similar)
 from .wt import GLS, OrthoFilter, wavelet
 
@@ -250,6 +250,22 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
             _check(rc, h)
             return y
         # (one spin and no room for its workspace: the reference's own sequence below, which needs far less)
+    if (TI and isinstance(wt, GLS) and (x.dim() == 1 or (x.dim() == 2 and len(nsp) == 2)) and isinstance(dnt.th, THType)
+            and dnt.th.code is not None and 0 <= dnt.th.code <= 3):
+        # the same device-resident batch for a lifting scheme (wl_denoise_ti_lifting, round 4): shifted signals as one
+        # batched-lines transform, shifted images one 2-D lifting transform per plane; sigma never leaves the device
+        sig = -1.0 if estnoise is noisest else float(estnoise(x, wt))
+        if estnoise is not noisest and not (sig >= 0 and sig * float(dnt.t) >= 0):
+            raise AssertionError("t >= 0")
+        y = similar(x)
+        h, st = _context(x.device)
+        iu, nc, sh, cf = wt.flatten()
+        nsl = [int(np.prod(nsp))] if x.dim() == 1 else list(nsp)
+        nsv = (C.c_int64 * 3)(*(nsl + [1] * (3 - len(nsl))))
+        _check(_lib.load().wl_denoise_ti_lifting(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
+                                                 len(iu), _i32p(iu), _i32p(nc), _i32p(sh), _f64p(cf), wt.norm1, wt.norm2,
+                                                 int(L), dnt.th.code, float(dnt.t), nsv, sig, st), h)
+        return y
     sigma = estnoise(x, wt)
     t = sigma * dnt.t
     if TI:

@@ -832,6 +832,7 @@ struct InvPairArgs {
     int64_t n0, n1;
     int TP;                             // level-l output column pairs per chunk (multiple of 8)
     int nstrips, nchunks;
+    int prio;
     TapsI<float, F> tp;
 };
 
@@ -859,6 +860,10 @@ __global__ void __launch_bounds__(192, MW) k_inv2d_pair(InvPairArgs<F> a)
     const int TPA = (S + SH - 1 + DELTA) / 2 + 1;           // steps of the level-(l+1) wave: ring columns 0 .. S + SH - 1 + DELTA
     const int NBAR = (SH + S + 2 > 2 * TPA) ? (SH + S + 2) : (2 * TPA);
 
+    // wave priorities by role (r04, 8192^2 db4 both levels: none 126.8 us, producer first 125.0, consumers first 123.9-124.2): the
+    // two level-l waves carry the stores and two thirds of the arithmetic; the producer works one step per two barriers
+    if (a.prio == 1 && wv == 0) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 2 && wv != 0) __builtin_amdgcn_s_setprio(2);
     if (wv == 0) {
         // =============================== level l+1 -> ring ===============================
         const int64_t h0a = h0 >> 1, h1a = h1 >> 1;
@@ -1018,6 +1023,7 @@ static hipError_t launch_inv2d_pair_f(hipStream_t st, const Taps<float> &taps, c
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     a.tp = shrink_i<float, F>(taps);
+    a.prio = i_env("WL_INVPAIR_PRIO", 2);
     // four waves per SIMD: the 8-tap instance spills 18 VGPRs for it and is still far ahead of three waves without spills
     // (8192^2 db4, both levels: 126 us against 175) -- like the single-level kernel this one is latency-bound per wave
     constexpr int MW = (F <= 8) ? 4 : 2;

@@ -40,6 +40,7 @@ struct Pair2DArgs {
     int TJ;                           // owned input columns per chunk (multiple of 32)
     int nstrips, nchunks;
     int rev;
+    int prio;                         // 1: the single-wave roles (helper, level-(l+1) wave) run at a raised priority
     // BT instances (the planes of a translation-invariant denoise batch over blockIdx.y): plane strides, the virtual shift of
     // level 1 (plane p reads copy (spin0 + p) % src_mod with its columns rotated by (spin0 + p) / src_mod, as k_fwd2d_lds) and the
     // hard threshold applied to every final coefficient as it is stored (th < 0: none)
@@ -70,8 +71,8 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
 
     // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
     auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
     const uint32_t first = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1u : 0u);
     uint32_t logical = first + (b >> 3);
@@ -105,6 +106,11 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     auto thr = [&](const T v) __attribute__((always_inline)) { return (BT && __builtin_fabsf(v) <= tf) ? 0.f : v; };
     const bool th_ll = BT && (a.ll == nullptr);          // last level of the transform: its approximation is final too
 
+    // The helper and the level-(l+1) wave issue ahead of the main waves: every wave of the workgroup meets at the step barrier,
+    // and a single-wave role that loses the VALU to the two main waves of four co-resident workgroups is what the others wait
+    // for (measured r04, 8192^2: db4 115.1-115.3 -> 112.2-112.4 us, sym5 125.3 -> 123.9; main waves first: +1 %; rotating the
+    // roles over the wave slots by workgroup: neutral or -4 %, the default placement is already the balanced one).
+    if (a.prio && wv >= W) __builtin_amdgcn_s_setprio(2);
     if (wv == W + 1) {
         // =============================== the level-(l+1) wave ===============================
         const int j = (int)(threadIdx.x & 63);
@@ -466,6 +472,7 @@ static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool l
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
+    a.prio = opt("WL_PAIR_PRIO", 1) != 0 ? 1 : 0;
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     if (pb) {

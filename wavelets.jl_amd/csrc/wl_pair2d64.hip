@@ -17,6 +17,7 @@ struct Pair2DArgs64 {
     int TJ;                           // owned input columns per chunk (multiple of 32)
     int nstrips, nchunks;
     int rev;
+    int prio;
     TapsF<double, F> tp;
 };
 
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
     T *const llb = a.ll ? a.ll : a.y;
     const int64_t ldl = a.ll ? a.ldll : a.ldy;
 
+    if (a.prio && wv >= W) __builtin_amdgcn_s_setprio(2);     // (as in k_fwd2d_pair: the single-wave roles issue first)
     if (wv == W + 1) {
         // =============================== the level-(l+1) wave ===============================
         const int j = (int)(threadIdx.x & 63);
@@ -276,6 +278,7 @@ static hipError_t launch_pair64_fw(hipStream_t st, const Taps<double> &taps, boo
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
+    a.prio = opt("WL_PAIR64_PRIO", 0) != 0 ? 1 : 0;       // (Float64: raised helper / level-(l+1) priority measured +1 %: off)
     a.tp = shrink<double, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair64<F, W, 1>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);

@@ -110,3 +110,47 @@ def test_ti_denoise_fused_tiers_against_separate_passes(gpu, W):
             out.append(W.denoise(x, wt, L=L, TI=True, nspin=nspin))
         W.clear_options()
         assert torch.equal(out[0], out[1]), (n, nspin, L)
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_wpt_fast_tiers_against_per_depth_kernels(gpu, W, seed):
+    """round 4: k_wpt_fwd_multi / k_wpt_fwd_tail / k_wpt_inv_tail and the ping-ponged lifting depths against the per-depth tier
+    (WL_WPT_FAST = 0) on random lengths (powers of two and 3 * 2^k), depths, filters, element types and random valid trees"""
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(200 + seed)
+    hits = set()
+    for it in range(70):
+        lg = int(r.integers(6, 19))
+        n = (1 << lg) if r.random() < 0.8 else 3 * (1 << (lg - 2))
+        dt = torch.float32 if r.random() < 0.7 else torch.float64
+        x = torch.randn(n, generator=gen, dtype=dt).cuda()
+        Lmax = W.maxtransformlevels(n)
+        kind = r.random()
+        if kind < 0.55:
+            tree = int(r.integers(1, Lmax + 1))                       # full tree by depth (wl_wpt_*_full)
+        elif kind < 0.8:
+            tree = W.maketree(n, int(r.integers(1, Lmax + 1)), "full")    # the same through a tree vector
+        else:
+            t = np.zeros(2 ** Lmax - 1, dtype=np.uint8)
+            t[0] = 1
+            p = float(r.choice([0.5, 0.8, 0.95]))
+            for i in range(1, len(t)):
+                t[i] = 1 if (t[(i + 1) // 2 - 1] and r.random() < p) else 0
+            tree = t
+        lifting = r.random() < 0.3
+        wt = (W.wavelet(getattr(W.WT, str(r.choice(["cdf97", "db2", "haar"]))), W.WT.Lifting) if lifting
+              else W.wavelet(getattr(W.WT, str(r.choice(["haar", "db2", "db3", "db4", "sym5"])))))
+        out = []
+        for fast in (0, 1):
+            W.set_option("WL_WPT_FAST", fast)
+            y = W.wpt(x, wt, tree)
+            if fast:
+                hits.add(W.last_kernel())
+            xr = W.iwpt(y, wt, tree)
+            if fast:
+                hits.add(W.last_kernel())
+            out.append((y, xr))
+        W.clear_options()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (n, dt, lifting, type(tree), it)
+    assert {"k_wpt_fwd_multi", "k_wpt_fwd_tail", "k_wpt_inv_tail"} <= hits, hits

@@ -746,7 +746,7 @@ def _rocprof_summary(kname_substr, tag="c3"):
 
 
 # levels finished by ONE launch of the kernel that consumes the full-size input (an L = Ldom call is exactly that launch)
-DOMINANT_LEVELS = {"k_fwd2d_stream2": 2, "k_fwd2d_pair": 2, "k_fwd2d_pair64": 2, "k_fwd1d_multi": 4}
+DOMINANT_LEVELS = {"k_fwd2d_stream2": 2, "k_fwd2d_pair": 2, "k_fwd2d_pair64": 2, "k_fwd1d_multi": 4, "k_lift1d_fwd3": 3}
 
 
 def _measure_traffic_live(tag):
@@ -805,7 +805,7 @@ def roofline_leg(W, xs, wt, batched, esize, reps, main_kernel, tag="c3", live_pm
     2*N*sizeof(T): it reads every input sample once and writes N coefficients (8 B/sample
     f32) -- that holds for the single-level kernels and for the fused kernels, which finish several levels in the same pass
     (pair: 3/4 N level-1 details + 1/4 N level-2 coefficients; the level-1 approximation never leaves the chip).
-    A call with L = 1 (L = 2 for the fused pair; L = 4 for the multi-level line kernel) is exactly
+    A call with L = 1 (L = 2 for the fused pair; L = 3 for the fused lifting line kernel; L = 4 for the multi-level line kernel) is exactly
     one launch of that kernel (its first-level template instance, which rocprofv3 --stats reports under its own name).
     `frac` uses HIP events on the launch stream around a train of such launches rotating over the inputs (live, this run);
     `rocprof` repeats the computation from the committed rocprofv3 summary; `traffic` = HBM bytes per launch from the PMC
@@ -838,7 +838,7 @@ def roofline_leg(W, xs, wt, batched, esize, reps, main_kernel, tag="c3", live_pm
                     note = j.get("note", "") + f" (static: read from the committed profiles/{os.path.basename(pmc)}, not measured by this run)"
             except Exception:
                 pass
-    levels = {1: "level 1", 2: "levels 1-2", 4: "levels 1-4"}[Ldom]
+    levels = {1: "level 1", 2: "levels 1-2", 3: "levels 1-3", 4: "levels 1-4"}[Ldom]
     out = {"bound": "hbm", "kernel": f"{kname} (first launch: {levels})",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

@@ -153,4 +153,4 @@ def test_wpt_fast_tiers_against_per_depth_kernels(gpu, W, seed):
             out.append((y, xr))
         W.clear_options()
         assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (n, dt, lifting, type(tree), it)
-    assert {"k_wpt_fwd_multi", "k_wpt_fwd_tail", "k_wpt_inv_tail"} <= hits, hits
+    assert {"k_wpt_fwd_multi", "k_wpt_fwd_tail", "k_wpt_inv_tail", "k_wpt_inv_multi"} <= hits, hits

@@ -1291,10 +1291,10 @@ def test_wpt_fast_paths_bitexact_and_pinned(gpu, W, oracle):
     oracle, and `last_kernel` pins that the fast tier actually ran (transforms_filter.jl:301-359, transforms_lifting.jl:283-319)."""
     cases = [
         # n, dtype, depth (None = maxtransformlevels), filters, expected forward kernel, expected inverse kernel
-        (1 << 18, np.float32, 6, ("db4", "haar"), "k_wpt_fwd_multi", "k_inv1d_stream"),
-        (1 << 18, np.float32, None, ("db4",), "k_wpt_fwd_multi", "k_wpt_inv_tail"),
-        (1 << 16, np.float32, 5, ("sym5",), "k_wpt_fwd_multi", None),
-        (1 << 14, np.float64, None, ("db2", "db4"), "k_wpt_fwd_multi", "k_wpt_inv_tail"),
+        (1 << 18, np.float32, 6, ("db4", "haar"), "k_wpt_fwd_multi", "k_wpt_inv_multi"),
+        (1 << 18, np.float32, None, ("db4",), "k_wpt_fwd_multi", "k_wpt_inv_multi"),
+        (1 << 16, np.float32, 5, ("sym5",), "k_wpt_fwd_multi", "k_wpt_inv_multi"),
+        (1 << 14, np.float64, None, ("db2", "db4"), "k_wpt_fwd_multi", "k_wpt_inv_multi"),
         (1 << 12, np.float32, None, ("db4", "sym5", "haar"), "k_wpt_fwd_tail", "k_wpt_inv_tail"),
         (1 << 11, np.float64, 11, ("db3",), "k_wpt_fwd_tail", "k_wpt_inv_tail"),
         (256, np.float32, 8, ("db4",), "k_wpt_fwd_tail", "k_wpt_inv_tail"),

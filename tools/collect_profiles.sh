@@ -24,11 +24,11 @@ done
 for pmc in FETCH_SIZE WRITE_SIZE; do
   $REPO/tools/rp.sh $O/pmc_$pmc $R "--kernel-trace --pmc $pmc" $B L=2 reps=30 warm=5 check=0
 done
-# ... and of the dominant kernels of C2 / C5 (k_fwd1d_multi, first pass = an L = 4 call) and C4 (k_lift1d_stream, level 1)
+# ... and of the dominant kernels of C2 / C5 (k_fwd1d_multi, first pass = an L = 4 call) and C4 (k_lift1d_fwd3, levels 1-3 = an L = 3 call)
 for pmc in FETCH_SIZE WRITE_SIZE; do
   $REPO/tools/rp.sh $O/pmc_c2_$pmc $R "--kernel-trace --pmc $pmc" $B n0=16777216 n1=1 L=4 reps=30 warm=5 check=0
   $REPO/tools/rp.sh $O/pmc_c5_$pmc $R "--kernel-trace --pmc $pmc" $B dwtc=1 n0=65536 n1=8192 L=4 reps=12 warm=3 check=0
-  $REPO/tools/rp.sh $O/pmc_c4_$pmc $R "--kernel-trace --pmc $pmc" python $REPO/tools/run_case.py lift1d_l1 20
+  $REPO/tools/rp.sh $O/pmc_c4_$pmc $R "--kernel-trace --pmc $pmc" python $REPO/tools/run_case.py lift1d_l3 20
 done
 $REPO/tools/rp.sh $O/pmc_sq $R "--kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $B L=2 reps=30 warm=5 check=0
 $REPO/tools/rp.sh $O/pmc_tcc $R "--kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" $B L=2 reps=30 warm=5 check=0

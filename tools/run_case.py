@@ -80,11 +80,11 @@ elif case == "c1":
     x = torch.rand(1 << 20, generator=g, dtype=torch.float64).cuda()
     y = W.similar(x)
     fn = lambda: W.dwt_oop_(y, x, W.wavelet(W.WT.db2), 20)
-elif case == "lift1d_l1":                    # one launch of the C4 dominant kernel (k_lift1d_stream, level 1)
+elif case == "lift1d_l3":                    # one launch of the C4 dominant kernel (k_lift1d_fwd3: levels 1-3 fused)
     x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
     y = W.similar(x)
     sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
-    fn = lambda: W.dwt_oop_(y, x, sch, 1)
+    fn = lambda: W.dwt_oop_(y, x, sch, 3)
 elif case == "wpt":
     x = torch.randn(1 << 22, generator=g, dtype=torch.float32).cuda()
     y = W.similar(x)

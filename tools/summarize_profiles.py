@@ -83,7 +83,7 @@ def config_pmc(tag, head, short, alg, signals=None, what=""):
 config_pmc("c2", "k_fwd1d_multi<float, 8, 1>", "k_fwd1d_multi", 2 * (1 << 24) * 4, what="first launch of the 1-D db4 dwt of 2^24 f32: levels 1-4")
 config_pmc("c5", "k_fwd1d_multi<float, 8, 1>", "k_fwd1d_multi", 2 * 8192 * (1 << 16) * 4, signals=8192,
            what="first launch of the batched dwt of an 8192 x 2^16 f32 shard: levels 1-4")
-config_pmc("c4", "k_lift1d_stream<float, 0, 1>", "k_lift1d_stream", 2 * (1 << 24) * 4, what="level 1 of the 1-D cdf9/7 lifting dwt of 2^24 f32")
+config_pmc("c4", "k_lift1d_fwd3<float, 0, 1>", "k_lift1d_fwd3", 2 * (1 << 24) * 4, what="first launch of the 1-D cdf9/7 lifting dwt of 2^24 f32: levels 1-3")
 
 pm = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):

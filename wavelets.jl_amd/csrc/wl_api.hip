@@ -711,7 +711,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     }
 
     // ---- filter bank: plan the launches first (the output ping-pongs between y and a work buffer and must end in y) ----
-    struct Step { int kindk; int d; int nd; };          // 0 generic / line kernel (one depth), 1 multi (nd fused depths), 2 tail (nd depths)
+    struct Step { int kindk; int d; int nd; };          // 0 generic / line kernel (one depth), 1 / 3 forward / inverse multi (nd fused depths from depth d), 2 tail (nd depths)
     std::vector<Step> plan;
     const int F = taps->F;
     const int TSw = wpt_tile_samples<T>();
@@ -735,6 +735,11 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             int nd = 0;
             while (nd < run && wpt_tail_ok<T>(F, n, n >> (d - nd), nd + 1)) ++nd;
             if (nd >= 1) { plan.push_back({2, d - nd + 1, nd}); i += nd; continue; }
+            // big segments: up to three depths per pass (k_wpt_inv_multi), the run split evenly over the fewest launches
+            const int stages = (run + 2) / 3;
+            int NL = (run + stages - 1) / stages;
+            while (NL >= 2 && !wpt_inv_multi_ok<T>(F, n, n >> (d - NL + 1), NL)) --NL;
+            if (NL >= 2) { plan.push_back({3, d - NL + 1, NL}); i += NL; continue; }
         }
         plan.push_back({0, d, 1});
         ++i;
@@ -749,9 +754,12 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
         if (sp.kindk == 1) {
             WL_HIP(ctx, wpt_fwd_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd));
             name = "k_wpt_fwd_multi";
+        } else if (sp.kindk == 3) {
+            WL_HIP(ctx, wpt_inv_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd));
+            name = "k_wpt_inv_multi";
         } else if (sp.kindk == 2) {
             WL_HIP(ctx, wpt_tail_launch<T>(st, *taps, fw, cur, out, n, n >> d, sp.nd));
-            if (std::strcmp(name, "k_wpt_fwd_multi") != 0) name = fw ? "k_wpt_fwd_tail" : "k_wpt_inv_tail";
+            if (std::strncmp(name, "k_wpt", 5) != 0) name = fw ? "k_wpt_fwd_tail" : "k_wpt_inv_tail";
         } else {
             const int64_t nj = n >> d, nseg = (int64_t)1 << d;
             Extent3 ext = {{nj, nseg, 1}};

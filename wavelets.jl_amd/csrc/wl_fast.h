@@ -189,6 +189,8 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
 template <typename T> int wpt_tile_samples();
 template <typename T> bool wpt_fwd_multi_ok(int F, int64_t n, int64_t nj, int NL);
 template <typename T> hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL);
+template <typename T> bool wpt_inv_multi_ok(int F, int64_t n, int64_t nj, int NL);
+template <typename T> hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL);
 template <typename T> bool wpt_tail_ok(int F, int64_t n, int64_t nj, int ndepth);
 template <typename T> hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth);
 

@@ -135,6 +135,100 @@ __global__ void __launch_bounds__(256) k_wpt_fwd_multi(WptMultiArgs<T, F> a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// iwpt, NL <= 3 depths per pass over HBM: the mirror of k_wpt_fwd_multi.  A workgroup owns TS samples of a segment of the
+// SHALLOWEST fused depth and stages, from each of the 2^NL leaf bands, its TS / 2^NL samples plus G[NL] on both sides (periodic
+// wrap of the band resolved while staging).  Level t -> t-1: parent pair q of a band (local index 2q, 2q+1) is
+// window_inv(S[q .. q+SH], D[q+SH .. q+2SH]) of its two children -- G[t] = G[t-1] / 2 + SH (rounded up to even, so that every
+// level's range starts at an even sample); halos are recomputed, workgroups are independent; only level 0 goes to memory.
+template <typename T, int F>
+struct WptInvMultiArgs {
+    const T *src; T *dst;
+    int64_t nj;                     // segment length at the shallowest fused depth (a multiple of TS)
+    int NL, TS;
+    int G[4];                       // halo (samples per side) of a band at fused level t
+    int bs[4];                      // band stride in LDS at fused level t
+    int buf_elems;
+    TapsF<T, F> tp;
+};
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256) k_wpt_inv_multi(WptInvMultiArgs<T, F> a)
+{
+    typedef typename VecOf<T, 2>::type T2;
+    constexpr int SH = (F - 2) / 2;
+    constexpr int PPT = 4;                                                // parent pairs per thread and iteration
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int NL = a.NL, TS = a.TS;
+    const int64_t own0 = (int64_t)blockIdx.x * TS;
+    const int64_t root = own0 / a.nj;
+    const int64_t r0 = own0 - root * a.nj;
+    T *bufA = reinterpret_cast<T *>(smem_raw);
+    T *bufB = bufA + a.buf_elems;
+    // ---- stage the leaves: band b, local j <-> element (r0 >> NL) - G[NL] + j of the band (mod its length), pairs of samples ----
+    {
+        const int64_t blen = a.nj >> NL;
+        const int Lt = (TS >> NL) + 2 * a.G[NL];
+        const int hp = Lt >> 1;                                           // pairs per band (Lt is even)
+        const int total = hp << NL;
+        const T *seg = a.src + root * a.nj;
+        const int64_t start = (r0 >> NL) - a.G[NL];
+        for (int it = tid; it < total; it += 256) {
+            const int b = it / hp, jp = it - b * hp;
+            int64_t g = start + 2 * jp;
+            if (g < 0) g += blen;
+            if (g >= blen) g -= blen;
+            const T2 v = *reinterpret_cast<const T2 *>(seg + (int64_t)b * blen + g);
+            *reinterpret_cast<T2 *>(bufA + b * a.bs[NL] + 2 * jp) = v;
+        }
+    }
+    lds_barrier_vm();
+    T *Cin = bufA, *Pout = bufB;
+    for (int t = NL; t >= 1; --t) {
+        const int Lp = (TS >> (t - 1)) + 2 * a.G[t - 1];                  // parent band length (even)
+        const int hp = Lp >> 1;                                           // parent pairs per band
+        const int gpb = (hp + PPT - 1) / PPT;
+        const int nb = 1 << (t - 1);
+        const int total = gpb * nb;
+        const int bsc = a.bs[t], bsp = a.bs[t - 1];
+        const bool last = (t == 1);
+        // parent pair q of a band is pair q + G[t] - G[t-1] / 2 of its children: SH, or SH + 1 where G[t] was rounded up to even
+        const int eps = a.G[t] - a.G[t - 1] / 2 - SH;
+        T *out0 = a.dst + root * a.nj + r0;
+        for (int g = tid; g < total; g += 256) {
+            const int b = g / gpb;
+            const int q0 = (g - b * gpb) * PPT;
+            const T *S = Cin + (2 * b) * bsc + q0 + eps;
+            const T *D = Cin + (2 * b + 1) * bsc + q0 + SH + eps;
+            T sv[PPT + SH], dv[PPT + SH];
+#pragma unroll
+            for (int i = 0; i < PPT + SH; ++i) { sv[i] = S[i]; dv[i] = D[i]; }
+            T xo[2 * PPT];
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+                for (int i = 0; i <= SH; ++i) { sw[i] = sv[p + i]; dw[i] = dv[p + i]; }
+                window_inv<T, F>(sw, dw, a.tp, xo[2 * p], xo[2 * p + 1]);
+            }
+            if (!last) {
+#pragma unroll
+                for (int p = 0; p < PPT; ++p)
+                    *reinterpret_cast<T2 *>(Pout + b * bsp + 2 * (q0 + p)) = T2{xo[2 * p], xo[2 * p + 1]};     // (past hp: the band's padding)
+            } else if (q0 + PPT <= hp) {
+                vstore16<T, 2 * PPT>(out0 + 2 * q0, xo);
+            } else {
+#pragma unroll
+                for (int p = 0; p < PPT; ++p)
+                    if (q0 + p < hp) *reinterpret_cast<T2 *>(out0 + 2 * (q0 + p)) = T2{xo[2 * p], xo[2 * p + 1]};
+            }
+        }
+        lds_barrier();
+        T *tmp = Cin; Cin = Pout; Pout = tmp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <typename T, int F>
 struct WptTailArgs {
     const T *src; T *dst;
@@ -302,6 +396,60 @@ hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *sr
     }
 }
 
+template <typename T>
+static void wpt_inv_halos(int F, int NL, int (&G)[4])
+{
+    const int SH = (F - 2) / 2;
+    G[0] = 0;
+    for (int t = 1; t <= 3; ++t) G[t] = (t <= NL) ? ((G[t - 1] / 2 + SH + 1) & ~1) : 0;
+}
+
+// NL fused depths whose SHALLOWEST segment length is nj
+template <typename T>
+bool wpt_inv_multi_ok(int F, int64_t n, int64_t nj, int NL)
+{
+    if (!wpt_fwd_multi_ok<T>(F, n, nj, NL)) return false;
+    int G[4];
+    wpt_inv_halos<T>(F, NL, G);
+    return (int64_t)G[NL] < (nj >> NL) && ((nj >> NL) % 2) == 0;
+}
+
+template <typename T, int F>
+static hipError_t launch_wpt_inv_multi_f(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    WptInvMultiArgs<T, F> a;
+    a.src = src; a.dst = dst; a.nj = nj; a.NL = NL; a.TS = wpt_tile_samples<T>();
+    wpt_inv_halos<T>(F, NL, a.G);
+    int maxlen = 0;
+    for (int t = 0; t <= 3; ++t) a.bs[t] = 0;
+    for (int t = 0; t <= NL; ++t) {
+        // a band of level t + what the last thread group of the level above it reads / writes past the end
+        const int len = (a.TS >> t) + 2 * a.G[t] + 2 * 4 + F + VEC;
+        a.bs[t] = (len + VEC - 1) / VEC * VEC;
+        const int tot = a.bs[t] << t;
+        if (tot > maxlen) maxlen = tot;
+    }
+    a.buf_elems = (maxlen + 15) & ~15;
+    a.tp = shrink<T, F>(taps);
+    const size_t shmem = 2 * (size_t)a.buf_elems * sizeof(T);
+    hipLaunchKernelGGL((k_wpt_inv_multi<T, F>), dim3((unsigned)(n / a.TS)), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+{
+    switch (taps.F) {
+    case 2: return launch_wpt_inv_multi_f<T, 2>(st, taps, src, dst, n, nj, NL);
+    case 4: return launch_wpt_inv_multi_f<T, 4>(st, taps, src, dst, n, nj, NL);
+    case 6: return launch_wpt_inv_multi_f<T, 6>(st, taps, src, dst, n, nj, NL);
+    case 8: return launch_wpt_inv_multi_f<T, 8>(st, taps, src, dst, n, nj, NL);
+    case 10: return launch_wpt_inv_multi_f<T, 10>(st, taps, src, dst, n, nj, NL);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 // tail: segments of nj = 2^k <= chunk samples, ndepth depths (the last one splits / merges segments of nj >> (ndepth - 1) >= 2)
 template <typename T>
 bool wpt_tail_ok(int F, int64_t n, int64_t nj, int ndepth)
@@ -349,6 +497,10 @@ template bool wpt_fwd_multi_ok<float>(int, int64_t, int64_t, int);
 template bool wpt_fwd_multi_ok<double>(int, int64_t, int64_t, int);
 template hipError_t wpt_fwd_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int);
 template hipError_t wpt_fwd_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int);
+template bool wpt_inv_multi_ok<float>(int, int64_t, int64_t, int);
+template bool wpt_inv_multi_ok<double>(int, int64_t, int64_t, int);
+template hipError_t wpt_inv_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int);
+template hipError_t wpt_inv_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int);
 template bool wpt_tail_ok<float>(int, int64_t, int64_t, int);
 template bool wpt_tail_ok<double>(int, int64_t, int64_t, int);
 template hipError_t wpt_tail_launch<float>(hipStream_t, const Taps<float> &, int, const float *, float *, int64_t, int64_t, int);

@@ -206,7 +206,9 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 assert W.last_kernel() == kfw or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
-                assert W.last_kernel() == kexp or not big, (fname, shape, L, W.last_kernel())
+                # inverse, Float32, 12..20 taps, output rows a multiple of 256: one pass per level as well (wl_inv2d_long.hip, round 4)
+                kinv = "k_inv2d_lds_long" if (dtype == np.float32 and flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 512) else kexp
+                assert W.last_kernel() == kinv or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
         xm = rng_array((4096, 5), dtype, flen)
         assert np.array_equal(host(W, W.dwtc(dev(W, xm), wt, 4)), oracle.dwtc_filter(xm, wt.qmf, 4))
@@ -356,6 +358,38 @@ def test_long_filter_single_pass_2d_kernel(gpu, W, oracle, wmain, tj):
     wt = W.wavelet(W.WT.db8)
     y = host(W, W.dwt(dev(W, x), wt, 2))
     assert W.last_kernel() != "k_fwd2d_lds_long" and np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2))
+
+
+@pytest.mark.parametrize("tp", [8, 20, 64])
+@pytest.mark.parametrize("wmain", [1, 2, 4])
+def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, wmain, tp):
+    """k_inv2d_lds_long (wl_inv2d_long.hip, round 4): 12..20 taps, ONE pass per 2-D inverse level (LDS exchange of the raw
+    columns incl. the helper wave's halo pairs, (SH+1)-slot rings, exit-guarded steps: chunk lengths that are not a multiple of
+    the ring), strips of 256 W output rows, every filter length, odd / even depths, non-square blocks, a single strip (the halo
+    wraps onto the strip itself), short last chunks, every request distance D (columns requested 1 ... 4 steps ahead, rings
+    rounded up to a multiple of D) -- bit for bit against the oracle; the two-pass tier gives the same bits."""
+    W.set_option("WL_INVLONG_W", wmain)
+    W.set_option("WL_INVLONG_TP", tp)
+    W.set_option("WL_INVLONG_D", {8: 1, 20: 2, 64: 4}[tp])
+    W.set_option("WL_INVLONG_WAVES_PER_CU", 0)
+    W.set_option("WL_INVLONG2D_MIN_ROWS", 256)
+    shapes = (((512, 512), (1, 2, 3)), ((1024, 2048), (1, 2)), ((2048, 256), (1, 3)), ((256, 96), (1,)), ((768, 130), (1,)), ((1280, 1056), (1, 2)))
+    for shape, Ls in shapes:
+        x = rng_array(shape, np.float32, sum(shape) + wmain + tp)
+        for fname in ("db6", "db7", "db8", "db9", "db10", "sym6", "sym8", "coif4", "coif6", "beyl"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                xr = host(W, W.idwt(dev(W, x), wt, L))
+                assert W.last_kernel() == "k_inv2d_lds_long", (shape, fname, L, W.last_kernel())
+                xe = oracle.dwt_filter(x, wt.qmf, L, fw=False)
+                if not np.array_equal(xr, xe):
+                    bad = np.argwhere(xr != xe)
+                    raise AssertionError((shape, fname, L, wmain, tp, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist()))
+    W.set_option("WL_INVLONG2D", 0)
+    x = rng_array((512, 512), np.float32, 4)
+    wt = W.wavelet(W.WT.db8)
+    xr = host(W, W.idwt(dev(W, x), wt, 2))
+    assert W.last_kernel() != "k_inv2d_lds_long" and np.array_equal(xr, oracle.dwt_filter(x, wt.qmf, 2, fw=False))
 
 
 @pytest.mark.parametrize("tj", [32, 128])

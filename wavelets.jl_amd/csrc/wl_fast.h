@@ -185,6 +185,11 @@ template <typename T>
 bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
                       T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
 
+// one fused 2-D inverse level for 12..20 taps, Float32 (wl_inv2d_long.hip); ll = deeper reconstruction or nullptr
+bool inv2d_long_ok(int F, int64_t n0, int64_t n1);
+hipError_t inv2d_long_launch(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                             float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count);
+
 // ---- fully split depths of the packet transform (wl_wpt.hip) ----
 template <typename T> int wpt_tile_samples();
 template <typename T> bool wpt_fwd_multi_ok(int F, int64_t n, int64_t nj, int NL);

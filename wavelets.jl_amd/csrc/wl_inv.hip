@@ -1086,7 +1086,12 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             const int64_t blk = two_d ? nq[0] * nq[1] : nq[0];
             const bool fits = two_d ? (((nq[0] | 1) * nq[1]) <= inv_tail_cap<T>() + 256 && nq[1] <= 256)
                                     : (2 * nq[0] <= 2 * (int64_t)inv_tail_cap<T>());
-            const int64_t vl_cap = (vlong_filter_ok(taps.F) && i_env("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40);
+            // 12 ... 20 taps on power-of-two blocks of <= 4096 elements / lines: the LDS-resident tail is instantiated for them (as in
+            // the forward direction); other long-filter shapes leave the tail at 64 / 16 samples, the chip-wide kernels take the rest
+            const bool long_tail = F >= 12 && i_env("WL_LONG_TAIL", 1) != 0 && i_env("WL_TAIL2", 1) != 0 &&
+                                   (two_d ? tail2_inv_ok<T>(F, 2, nq[0], nq[1], L - q + 1, y, 0) : tail2_inv_ok<T>(F, 1, nq[0], 1, L - q + 1, y, b.full.s[1]));
+            const int64_t vl_cap = long_tail ? (int64_t)4096
+                                   : ((vlong_filter_ok(taps.F) && i_env("WL_NO_LONGF", 0) == 0) ? (two_d ? 64 : 16) : ((int64_t)1 << 40));
             if (blk <= (int64_t)i_env("WL_INVTAIL_MAX", 4096) && blk <= vl_cap && blk <= inv_tail_cap<T>() && fits && nq[0] < (1 << 20)) l_lo = q; else break;
         }
         if (l_lo <= L) {
@@ -1262,6 +1267,16 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e);
             WL_TRYI(e);
             if (done) dominant = "k_inv2d_stream";
+        }
+        // ---- 12..20 taps, Float32, output rows a multiple of 256: the whole 2-D level in one pass (wl_inv2d_long.hip) ----
+        if constexpr (sizeof(T) == 4) {
+            if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 512) && b.full.s[0] == 1 &&
+                inv2d_long_ok(F, n[0], n[1]) && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
+                (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
+                WL_TRYI(inv2d_long_launch(st, taps, x, b.full.s[1], llsrc, llsrc ? llsrc_st.s[1] : 0, res, res_st.s[1], n[0], n[1], cu_count));
+                dominant = "k_inv2d_lds_long";
+                done = true;
+            }
         }
         // ---- long filters (12..24 taps) ----
         if (!done && path == 0 && long_filter_ok(F) && i_env("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1) {

@@ -1,0 +1,246 @@
+// wl_inv2d_long.hip -- ONE fused 2-D INVERSE level per pass over HBM for the 12 ... 20-tap filters (db6 ... db10, sym6 ... sym10,
+// coif4, coif6, beyl), Float32: the mirror of k_fwd2d_lds_long (wl_fwd2d_long.hip).  Up to round 3 these filters took two line
+// launches + one axis launch per inverse level through an N-element intermediate (2 x the traffic, 3 launches).
+//
+//   k_inv2d_lds_long<F, W, D>
+//
+// Reference order (transforms_filter.jl:173-186): dim-1 reconstruction of every column, then dim-2 reconstruction of every row.
+// A workgroup of W waves (default 1) owns 256 W OUTPUT rows (= 128 W coefficient pairs along dim 1: two pairs per lane, exact
+// tiling, no overlap) and marches along the output column pairs p of a chunk, as k_inv2d_stream does:
+//   * per step it takes the raw coefficient column p of the left half and column p + SH of the right half (the lane's two
+//     scaling and two detail coefficients of each: four 8-byte loads, requested D steps ahead),
+//   * publishes them in LDS -- the reach of a 20-tap filter is 9 pairs on either side, beyond any DPP exchange -- together with
+//     the SH scaling pairs before the strip and the SH detail pairs after it (periodic wrap), which 2 SH lanes of wave 0 load,
+//   * after the step's only barrier reads its windows back (scaling pairs r-SH .. r+1, detail pairs r .. r+1+SH) and
+//     reconstructs the two columns along dim 1 (window_inv, wl_dev.h) into two register rings of R >= SH + 1 slots,
+//   * combines ring columns p-SH .. p / p .. p+SH into output columns 2p, 2p+1 (window_inv again) and stores 16 bytes per column.
+// The LDS buffers alternate with the step parity, so one barrier per step is enough.  The loop body is unrolled over the ring
+// (R steps, R a multiple of D so that request slots are compile-time); a step past the chunk is an EXIT (see k_fwd2d_lds_long).
+// Loads and waits are the compiler's here.
+// What bounds it (measured r04, profiles/r04_inv_long.md): VALU issue.  A step is ~500 f32 multiplies / adds per lane (2 F per
+// sample and pass, no FMA by the arithmetic contract) + ~110 other VALU; it takes ~2300 cycles on a SIMD whether one or two
+// waves share it, with or without v_pk_* packing, with requests 1 ... 4 steps ahead: 8192^2 db8 = 164 us = 3.3 TB/s, above the
+// two-pass tier's 226 us (same arithmetic, twice the traffic) and well below the copy ceiling -- the arithmetic is the limit.
+// A first draft used a helper wave for the halo (as k_fwd2d_lds_long): it held a wave slot with the main waves' 130 ... 210 VGPRs,
+// i.e. half of the two-waves-per-SIMD occupancy, for two loads per step.
+// Arithmetic: the closed form of filtup! in the reference's summation order (wl_internal.h) -- bit-identical to the two-pass tier.
+#include "wl_fast.h"
+#include "wl_dev.h"
+
+namespace wl {
+
+template <int F>
+struct InvLongArgs {
+    const float *x; int64_t ldx;        // coefficient array
+    const float *ll; int64_t ldl;       // deeper reconstruction = approximation quadrant, h0 x h1 (nullptr: it is in x)
+    float *dst; int64_t ldd;            // n0 x n1 result
+    int64_t n0, n1;
+    int TP;                             // output column pairs per chunk
+    int nstrips, nchunks;
+    TapsF<float, F> tp;
+};
+
+template <int F, int W, int D>
+__global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
+{
+    typedef float T;
+    typedef float T2 __attribute__((ext_vector_type(2)));
+    typedef float T4 __attribute__((ext_vector_type(4)));
+    constexpr int SH = (F - 2) / 2, SHP = (SH + 1) & ~1;      // reach in pairs; the same rounded up to even (8-byte aligned LDS rows)
+    constexpr int R = ((SH + 1 + D - 1) / D) * D;             // ring depth = unroll: >= SH + 1, a multiple of the request distance D
+    constexpr int NP = 128 * W;                               // coefficient pairs of the strip
+    constexpr int LA = NP + SHP + 4;                          // one LDS array: positions [0, NP + SHP) (+ pad)
+    __shared__ __attribute__((aligned(16))) T lds[2][4][LA];  // [step parity][Ls, Ld, Rs, Rd]
+
+    const int wv = (W > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const uint32_t logical = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    const int strip = (int)(logical % (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+    const int64_t h0 = a.n0 >> 1, h1 = a.n1 >> 1;
+    const int64_t p0 = (int64_t)chunk * a.TP;
+    const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
+    const int S = (int)(pend - p0);
+    const int64_t r0 = (int64_t)strip * NP;
+    const bool from_ll = (a.ll != nullptr);
+    const int64_t ls_ld = from_ll ? a.ldl : a.ldx;
+    // the raw columns of step t (t from -SH: wraps below zero; the requests past the chunk wrap above and are never used)
+    auto col_s = [&](const int t) __attribute__((always_inline)) { int64_t j = p0 + t; if (j < 0) j += h1; if (j >= h1) j -= h1; return j; };
+    auto col_d = [&](const int t) __attribute__((always_inline)) { int64_t j = p0 + t + SH; if (j >= h1) j -= h1; return j; };
+
+    // ================= lane Lm = 64 wv + lane owns pairs r0 + 2 Lm, r0 + 2 Lm + 1 =================
+    const int Lm = 64 * wv + lane;
+    const int64_t rr = r0 + 2 * Lm;
+    const T *ls_base = (from_ll ? a.ll : a.x) + rr;           // left half, scaling rows
+    const T *ld_base = a.x + h0 + rr;                         // left half, detail rows
+    const T *rs_base = a.x + h1 * a.ldx + rr;                 // right half, scaling rows
+    const T *rd_base = rs_base + h0;                          // right half, detail rows
+    const int ws = SHP + 2 * Lm;                              // LDS positions: scaling arrays hold pair r0 - SHP + i at i, detail arrays r0 + i
+    const int wd = 2 * Lm;
+    // the halo of the exchange (periodic wrap) rides on wave 0: lane h < SH takes scaling pair r0 - SH + h of both halves,
+    // lane SH <= h < 2 SH detail pair r0 + NP + (h - SH).  (Up to round-4 draft 1 a helper wave did this: it cost a wave slot with
+    // the main waves' register allocation, i.e. half of the two-waves-per-SIMD occupancy.)
+    const bool halo_wave = (wv == 0);
+    const bool hd = lane >= SH;
+    const bool hl = lane < 2 * SH;
+    int64_t hr = 0;
+    if (hl) { hr = hd ? (r0 + NP + (lane - SH)) : (r0 - SH + lane); if (hr < 0) hr += h0; if (hr >= h0) hr -= h0; }
+    const T *hlb = hd ? (a.x + h0 + hr) : ((from_ll ? a.ll : a.x) + hr);
+    const int64_t hl_ld = hd ? a.ldx : ls_ld;
+    const T *hrb = a.x + h1 * a.ldx + (hd ? h0 : 0) + hr;
+    const int hw = hd ? (NP + lane - SH) : (SHP - SH + lane);
+    const int hal = hd ? 1 : 0;
+
+    T2 raw[D][4];                                             // requests in flight: D steps ahead
+    T hv[D][2];
+    auto load_raw = [&](const int t, const int s) __attribute__((always_inline)) {
+        const int64_t js = col_s(t), jd = col_d(t);
+        raw[s][0] = *reinterpret_cast<const T2 *>(ls_base + js * ls_ld);
+        raw[s][1] = *reinterpret_cast<const T2 *>(ld_base + js * a.ldx);
+        raw[s][2] = *reinterpret_cast<const T2 *>(rs_base + jd * a.ldx);
+        raw[s][3] = *reinterpret_cast<const T2 *>(rd_base + jd * a.ldx);
+        if (halo_wave) {
+            if (hl) { hv[s][0] = hlb[js * hl_ld]; hv[s][1] = hrb[jd * a.ldx]; }
+        }
+    };
+
+    T iS[R][4], iD[R][4];                                     // dim-1-reconstructed columns: left half / right half
+    T *out = a.dst + 2 * (r0 + 2 * Lm);                       // the lane's four output rows
+    // one column of the exchange -> the lane's four dim-1-reconstructed samples
+    auto recon = [&](const T *sa, const T *da, T (&o)[4]) __attribute__((always_inline)) {
+        // scaling pairs r - SH .. r + 1 at positions ws - SH .. ws + 1 (ws - SHP is even: read from there), detail pairs r .. r + 1 + SH
+        T sv[SHP + 2], dv[SH + 3];
+#pragma unroll
+        for (int i = 0; i < (SHP + 2) / 2; ++i) {
+            const T2 v = *reinterpret_cast<const T2 *>(sa + ws - SHP + 2 * i);
+            sv[2 * i] = v.x; sv[2 * i + 1] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < (SH + 3) / 2; ++i) {
+            const T2 v = *reinterpret_cast<const T2 *>(da + wd + 2 * i);
+            dv[2 * i] = v.x; dv[2 * i + 1] = v.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sw[i] = sv[SHP - SH + p + i]; dw[i] = dv[p + i]; }
+            window_inv<T, F>(sw, dw, a.tp, o[2 * p], o[2 * p + 1]);
+        }
+    };
+    // t: step (from -SH: the first SH steps only fill the rings), s: request slot, u: ring slot of this step's columns
+    auto step = [&](const int t, const int s, const int u, const bool combine) __attribute__((always_inline)) {
+        T(*buf)[LA] = lds[t & 1];
+        *reinterpret_cast<T2 *>(&buf[0][ws]) = raw[s][0];
+        *reinterpret_cast<T2 *>(&buf[1][wd]) = raw[s][1];
+        *reinterpret_cast<T2 *>(&buf[2][ws]) = raw[s][2];
+        *reinterpret_cast<T2 *>(&buf[3][wd]) = raw[s][3];
+        if (halo_wave) {
+            if (hl) { buf[hal][hw] = hv[s][0]; buf[2 + hal][hw] = hv[s][1]; }
+        }
+        load_raw(t + D, s);
+        lds_barrier();
+        // (never taken: a block boundary between the request / publish half and the reconstruction half of a step -- without it the
+        //  compiler schedules the unrolled steps as one region, 256 VGPRs + scratch for F >= 16; with it 125 ... 209, no scratch)
+        if (__builtin_expect(a.nchunks < 0, 0)) return;
+        recon(buf[0], buf[1], iS[u]);
+        recon(buf[2], buf[3], iD[u]);
+        if (!combine) return;
+        T xe[4], xo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            T sw[SH + 1], dw[SH + 1];
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
+            window_inv<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+        }
+        const int64_t p = p0 + t;
+        *reinterpret_cast<T4 *>(out + (2 * p) * a.ldd) = T4{xe[0], xe[1], xe[2], xe[3]};
+        *reinterpret_cast<T4 *>(out + (2 * p + 1) * a.ldd) = T4{xo[0], xo[1], xo[2], xo[3]};
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_raw(s - SH, s);
+    // prologue: steps -SH .. -1 -> ring slots R - SH .. R - 1, request slots c % D (step t uses request slot (t + SH) % D; R % D == 0)
+#pragma unroll
+    for (int c = 0; c < SH; ++c) step(c - SH, c % D, c - SH + R, false);
+    for (int t0 = 0; t0 < S; t0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (t0 + u >= S) return;                          // (workgroup-uniform: every wave takes the same barriers)
+            step(t0 + u, (u + SH) % D, u, true);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+bool inv2d_long_ok(int F, int64_t n0, int64_t n1)
+{
+    if (F < 12 || F > 20 || (F & 1)) return false;
+    if (n0 >= ((int64_t)1 << 30) || n1 >= ((int64_t)1 << 30)) return false;
+    // exact tiling: strips of 256 output rows per main wave; the reach (SH pairs) must not wrap twice
+    const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
+    return n0 >= 256 && (n0 % 256) == 0 && (n1 % 2) == 0 && h1 >= (F - 2) / 2 + 5 && h0 >= (F - 2) / 2;   // (+ 4: requests up to 4 steps ahead wrap once)
+}
+
+template <int F, int W, int D>
+static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                                     float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    InvLongArgs<F> a;
+    a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
+    const int64_t h1 = n1 >> 1;
+    a.nstrips = (int)(n0 / (256 * W));
+    // a chunk pays SH prologue steps: long chunks where the array is large enough to fill the chip (8 waves per CU: two per SIMD
+    // at 130 ... 210 VGPRs) with them, shorter ones below (measured r04: 8192^2 TP 64, 4096^2 TP 16, 2048^2 TP 8)
+    int TP = (int)opt("WL_INVLONG_TP", 64);
+    if (TP < 8) TP = 64;
+    const int64_t want = (int64_t)cu_count * opt("WL_INVLONG_WAVES_PER_CU", 8);
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * W < want) TP >>= 1;
+    a.TP = TP;
+    a.nchunks = (int)((h1 + TP - 1) / TP);
+    a.tp = shrink<float, F>(taps);
+    hipLaunchKernelGGL((k_inv2d_lds_long<F, W, D>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64 * W), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int F, int W>
+static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                                     float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    // request distance in steps: a step is ~0.3 us of arithmetic, a loaded HBM round trip 1 - 2 us
+    const int D = (int)opt("WL_INVLONG_D", 3);
+    if (D <= 1) return launch_inv_long_fwd<F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    if (D == 2) return launch_inv_long_fwd<F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    if (D == 3) return launch_inv_long_fwd<F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    return launch_inv_long_fwd<F, W, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+}
+
+template <int F>
+static hipError_t launch_inv_long_f(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                                    float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    int W = (int)opt("WL_INVLONG_W", 0);
+    if (W != 1 && W != 2 && W != 4) W = 1;                    // (one wave per workgroup: the step's barrier is free; W = 2, 4 measured equal or slower)
+    while (W > 1 && (n0 % (256 * W)) != 0) W >>= 1;
+    if (W == 4) return launch_inv_long_fw<F, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    if (W == 2) return launch_inv_long_fw<F, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    return launch_inv_long_fw<F, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+}
+
+hipError_t inv2d_long_launch(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
+                             float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+{
+    switch (taps.F) {
+    case 12: return launch_inv_long_f<12>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 14: return launch_inv_long_f<14>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 16: return launch_inv_long_f<16>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 18: return launch_inv_long_f<18>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 20: return launch_inv_long_f<20>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace wl

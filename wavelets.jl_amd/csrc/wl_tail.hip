@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
 template <typename T>
 bool tail2_ok(int F, int nt, int64_t m0, int64_t m1, int nlev, int fmax)
 {
-    // fmax = 10: the inverse tail and the default; 20: the forward tail is also instantiated for 12..20 taps (wl_fwd2d_long.hip's
+    // fmax = 10: the default; 20: the forward and (round 4) the inverse tail are also instantiated for 12..20 taps (wl_fwd2d_long.hip's
     // filters: one workgroup finishes a 64 x 64 block instead of two chip-wide launches per level down to 16 x 16)
     if (F < 2 || F > fmax || F > 20 || (F & 1)) return false;
     auto pow2 = [](int64_t v) { return v >= 2 && (v & (v - 1)) == 0; };
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(512) k_tail2_inv(Tail2InvArgs<T, F> a)
 template <typename T>
 bool tail2_inv_ok(int F, int nt, int64_t n0, int64_t n1, int nlev, const T *out, int64_t out_item)
 {
-    if (!tail2_ok<T>(F, nt, n0, n1, nlev, 10)) return false;
+    if (!tail2_ok<T>(F, nt, n0, n1, nlev, 20)) return false;       // (12 ... 20 taps since round 4, as the forward tail)
     // the last level of a line is stored as 8-byte pairs
     if (nt == 1 && ((reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) != 0 || (out_item % 2) != 0)) return false;
     return true;
@@ -376,6 +376,11 @@ hipError_t launch_tail2_inv(hipStream_t st, const Taps<T> &taps, const T *x, int
     case 6: return launch_tail2_inv_f<T, 6>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
     case 8: return launch_tail2_inv_f<T, 8>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
     case 10: return launch_tail2_inv_f<T, 10>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 12: return launch_tail2_inv_f<T, 12>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 14: return launch_tail2_inv_f<T, 14>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 16: return launch_tail2_inv_f<T, 16>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 18: return launch_tail2_inv_f<T, 18>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
+    case 20: return launch_tail2_inv_f<T, 20>(st, taps, x, ldx, x_item, out, ldo, out_item, nitems, n0, n1, nt, nlev);
     default: return hipErrorInvalidValue;
     }
 }

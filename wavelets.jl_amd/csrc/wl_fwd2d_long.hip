@@ -228,7 +228,7 @@ static hipError_t launch_long_f(hipStream_t st, const Taps<float> &taps, bool lv
     if (TJ < 16) TJ = 16;
     TJ &= ~1;
     auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };
-    while (TJ > 16 && nwgs(TJ) < (int64_t)cu_count * opt("WL_LONG_WG_PER_CU", 2)) TJ = (TJ / 2) & ~1;
+    while (TJ > 16 && nwgs(TJ) < (int64_t)cu_count * opt("WL_LONG_WG_PER_CU", 1)) TJ = (TJ / 2) & ~1;
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;

@@ -206,8 +206,8 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 assert W.last_kernel() == kfw or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
-                # inverse, Float32, 12..20 taps, output rows a multiple of 256: one pass per level as well (wl_inv2d_long.hip, round 4)
-                kinv = "k_inv2d_lds_long" if (dtype == np.float32 and flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 512) else kexp
+                # inverse, 12..20 taps, output rows a multiple of 256 (>= 512): one pass per level as well, both element types (wl_inv2d_long.hip, round 4)
+                kinv = "k_inv2d_lds_long" if (flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 512) else kexp
                 assert W.last_kernel() == kinv or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
         xm = rng_array((4096, 5), dtype, flen)
@@ -360,23 +360,29 @@ def test_long_filter_single_pass_2d_kernel(gpu, W, oracle, wmain, tj):
     assert W.last_kernel() != "k_fwd2d_lds_long" and np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2))
 
 
-@pytest.mark.parametrize("tp", [8, 20, 64])
-@pytest.mark.parametrize("wmain", [1, 2, 4])
-def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, wmain, tp):
-    """k_inv2d_lds_long (wl_inv2d_long.hip, round 4): 12..20 taps, ONE pass per 2-D inverse level (LDS exchange of the raw
-    columns incl. the helper wave's halo pairs, (SH+1)-slot rings, exit-guarded steps: chunk lengths that are not a multiple of
-    the ring), strips of 256 W output rows, every filter length, odd / even depths, non-square blocks, a single strip (the halo
-    wraps onto the strip itself), short last chunks, every request distance D (columns requested 1 ... 4 steps ahead, rings
-    rounded up to a multiple of D) -- bit for bit against the oracle; the two-pass tier gives the same bits."""
+@pytest.mark.parametrize("dtype,wmain,tp", [(np.float32, 1, 8), (np.float32, 1, 20), (np.float32, 1, 64), (np.float32, 2, 8), (np.float32, 2, 20),
+                                            (np.float32, 2, 64), (np.float32, 4, 8), (np.float32, 4, 20), (np.float32, 4, 64),
+                                            (np.float64, 1, 8), (np.float64, 1, 20), (np.float64, 2, 64), (np.float64, 4, 20)])
+def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, dtype, wmain, tp):
+    """k_inv2d_lds_long (wl_inv2d_long.hip, round 4): ONE pass per 2-D inverse level -- 12..20 taps in Float32, 8..20 taps in
+    Float64, and (enabled here) 8 / 10 taps in Float32 -- LDS exchange of the raw columns incl. the halo pairs that ride on
+    wave 0, rings rounded up to a multiple of the request distance D, exit-guarded steps (chunk lengths that are not a multiple
+    of the ring), strips of 256 W output rows, every filter length, odd / even depths, non-square blocks, a single strip (the
+    halo wraps onto the strip itself), short last chunks, D = 1 ... 4 -- bit for bit against the oracle; the other tiers give the
+    same bits."""
     W.set_option("WL_INVLONG_W", wmain)
     W.set_option("WL_INVLONG_TP", tp)
     W.set_option("WL_INVLONG_D", {8: 1, 20: 2, 64: 4}[tp])
     W.set_option("WL_INVLONG_WAVES_PER_CU", 0)
     W.set_option("WL_INVLONG2D_MIN_ROWS", 256)
+    W.set_option("WL_INVLONG_FMIN", 8)
+    W.set_option("WL_INVLONG_SHORT_MIN", 0)
+    W.set_option("WL_INV_PAIR", 0)
+    W.set_option("WL_TILE_INV", 0)
     shapes = (((512, 512), (1, 2, 3)), ((1024, 2048), (1, 2)), ((2048, 256), (1, 3)), ((256, 96), (1,)), ((768, 130), (1,)), ((1280, 1056), (1, 2)))
     for shape, Ls in shapes:
-        x = rng_array(shape, np.float32, sum(shape) + wmain + tp)
-        for fname in ("db6", "db7", "db8", "db9", "db10", "sym6", "sym8", "coif4", "coif6", "beyl"):
+        x = rng_array(shape, dtype, sum(shape) + wmain + tp)
+        for fname in ("db4", "sym5", "db6", "db7", "db8", "db9", "db10", "sym6", "sym8", "coif4", "coif6", "beyl"):
             wt = W.wavelet(getattr(W.WT, fname))
             for L in Ls:
                 xr = host(W, W.idwt(dev(W, x), wt, L))
@@ -386,10 +392,11 @@ def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, wmain, tp):
                     bad = np.argwhere(xr != xe)
                     raise AssertionError((shape, fname, L, wmain, tp, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist()))
     W.set_option("WL_INVLONG2D", 0)
-    x = rng_array((512, 512), np.float32, 4)
-    wt = W.wavelet(W.WT.db8)
-    xr = host(W, W.idwt(dev(W, x), wt, 2))
-    assert W.last_kernel() != "k_inv2d_lds_long" and np.array_equal(xr, oracle.dwt_filter(x, wt.qmf, 2, fw=False))
+    x = rng_array((512, 512), dtype, 4)
+    for fname in ("db8", "sym5"):
+        wt = W.wavelet(getattr(W.WT, fname))
+        xr = host(W, W.idwt(dev(W, x), wt, 2))
+        assert W.last_kernel() != "k_inv2d_lds_long" and np.array_equal(xr, oracle.dwt_filter(x, wt.qmf, 2, fw=False))
 
 
 @pytest.mark.parametrize("tj", [32, 128])
@@ -1398,6 +1405,30 @@ def test_batch_of_images_bitexact(gpu, W, oracle):
         for i in range(nb):
             e = oracle.dwt_filter(oracle.dwt_filter(xs[i], wt.qmf, L), wt.qmf, L, fw=False)
             assert np.array_equal(xr[:, :, i].cpu().numpy(), e), (n0, n1, L, fname, i)
+
+
+def test_batched_planes_lds_exchange_inverse(gpu, W, oracle):
+    """k_inv2d_lds_long over blockIdx.y (round 4): batches of images (wl_dwt_filter_batch inverse) and the planes of a 3-D level --
+    10 taps in Float32, 8 ... 20 taps in Float64, 12 ... 20 in Float32; the first planes of a 3-D level take their approximation
+    quadrant from the deeper reconstruction, the others from the coefficient array; bit for bit against the oracle."""
+    import torch
+    W.set_option("WL_INVLONG2D_MIN_ROWS", 256)
+    W.set_option("WL_INVLONG_SHORT_MIN", 0)
+    for (n0, n1, nb, L, fname, dtype) in ((512, 512, 5, 3, "sym5", np.float32), (1024, 256, 3, 2, "db8", np.float32), (256, 96, 7, 1, "db10", np.float32),
+                                           (512, 256, 4, 2, "db4", np.float64), (256, 512, 3, 2, "db6", np.float64), (768, 64, 2, 1, "coif6", np.float64)):
+        wt = W.wavelet(getattr(W.WT, fname))
+        ys = [rng_array((n0, n1), dtype, 300 + i) for i in range(nb)]
+        yb = torch.stack([W.to_device(a).t().contiguous() for a in ys]).permute(2, 1, 0)      # n0 x n1 x B, column-major
+        xr = W.idwt_batch(yb, wt, L)
+        assert W.last_kernel() == "k_inv2d_lds_long", (n0, n1, fname, W.last_kernel())
+        for i in range(nb):
+            assert np.array_equal(xr[:, :, i].cpu().numpy(), oracle.dwt_filter(ys[i], wt.qmf, L, fw=False)), (n0, n1, L, fname, i)
+    # 3-D: the dim-1 / dim-2 reconstruction of every plane in one launch, then the axis-3 pass
+    for (shape, L, fname, dtype) in (((512, 256, 32), 2, "sym5", np.float32), ((256, 256, 64), 1, "db4", np.float64)):
+        wt = W.wavelet(getattr(W.WT, fname))
+        y = rng_array(shape, dtype, 17)
+        xr = host(W, W.idwt(dev(W, y), wt, L))
+        assert np.array_equal(xr, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (shape, fname)
 
 
 # ---- BASELINE.json full sizes: size-independent properties -------------------------------------------

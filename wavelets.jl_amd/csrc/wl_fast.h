@@ -170,7 +170,7 @@ bool fwd2d_planes(hipStream_t st, const Taps<T> &taps, const T *src, T *y, int64
                   int64_t nplanes, int nll, int cu_count, hipError_t *err);
 template <typename T>
 bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
-                  int64_t nplanes, int nll, int cu_count, hipError_t *err);
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel = nullptr);
 
 // 3-D lifting transform of a cube (2^k <= 512 per side) through the axis-streaming and short-line kernels.
 template <typename T>
@@ -185,10 +185,13 @@ template <typename T>
 bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
                       T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
 
-// one fused 2-D inverse level for 12..20 taps, Float32 (wl_inv2d_long.hip); ll = deeper reconstruction or nullptr
-bool inv2d_long_ok(int F, int64_t n0, int64_t n1);
-hipError_t inv2d_long_launch(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
-                             float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count);
+// one fused 2-D inverse level through an LDS exchange, 8..20 taps (wl_inv2d_long.hip: which filter lengths per element type); ll = deeper reconstruction or nullptr
+bool inv2d_long_ok(int F, int64_t n0, int64_t n1, int esize);
+// (a batch of independent blocks: nplanes over blockIdx.y, element strides, the first nll planes take their approximation from ll)
+struct InvLongBatch { int64_t nplanes, bs_x, bs_ll, bs_dst; int nll; };
+template <typename T>
+hipError_t inv2d_long_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                             T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt = InvLongBatch{1, 0, 0, 0, 1});
 
 // ---- fully split depths of the packet transform (wl_wpt.hip) ----
 template <typename T> int wpt_tile_samples();

@@ -1146,11 +1146,26 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         T *res = (l == 1) ? y : (pp ? w.B : w.A);
         Strides3 res_st = (l == 1) ? b.full : box_st;
         bool done = false;
+        // the LDS-exchange level kernel (wl_inv2d_long.hip): Float32, output rows a multiple of 256
+        auto try_lds_long = [&]() -> hipError_t {
+            if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 512) && b.full.s[0] == 1 &&
+                inv2d_long_ok(F, n[0], n[1], (int)sizeof(T)) && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
+                (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
+                hipError_t e = inv2d_long_launch<T>(st, taps, x, b.full.s[1], llsrc, llsrc ? llsrc_st.s[1] : 0, res, res_st.s[1], n[0], n[1], cu_count);
+                if (e != hipSuccess) return e;
+                dominant = "k_inv2d_lds_long";
+                done = true;
+            }
+            return hipSuccess;
+        };
+        // 8 / 10 taps: ahead of the streaming kernels where it is enabled for them (WL_INVLONG_FMIN / _FMIN64) and the block is large
+        if (F <= 10 && n[0] * n[1] >= (int64_t)i_env("WL_INVLONG_SHORT_MIN", 1 << 22) &&
+            !(sizeof(T) == 4 && F <= 8 && l >= 2 && (l % 2) == 0)) WL_TRYI(try_lds_long());
 
         // ---- big 2-D blocks: levels l and l-1 in one launch, the level-l reconstruction handed over through an LDS column ring ----
         if constexpr (sizeof(T) == 4) {
             // (l even: the pairs end at level 1, so the two biggest levels share a launch)
-            if (fastF && two_d && l >= 2 && (l % 2) == 0 && i_env("WL_INV_PAIR", 1) != 0 && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) &&
+            if (!done && fastF && two_d && l >= 2 && (l % 2) == 0 && i_env("WL_INV_PAIR", 1) != 0 && b.full.s[0] == 1 && (b.full.s[1] % VEC) == 0 && i_al16(x) &&
                 (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
                 int64_t n1[3];
                 level_box(b, l - 1, n1);                    // output extents of the shallower level
@@ -1167,7 +1182,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             }
         }
         // ---- small 2-D blocks: two levels (l and l-1) per launch, LDS tiles (wl_tile.hip) ----
-        if (fastF && two_d && path == 0 && l >= 2 && i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
+        if (!done && fastF && two_d && path == 0 && l >= 2 && i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
             int64_t n1[3];
             level_box(b, l - 1, n1);                        // output extents of the shallower level
             if (inv2d_tile2_ok<T>(F, n1[0], n1[1]) && n1[0] <= i_env("WL_TILE_INV_MAX", 1024) && n1[1] <= i_env("WL_TILE_INV_MAX", 1024)) {
@@ -1262,22 +1277,15 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         }
         // ---- batch of independent 2-D blocks (box n0 x n1 x B, first two axes transformed): the fused inverse level
         //      kernel with the planes over blockIdx.y ----
-        if (!done && fastF && b.nd == 3 && b.nt == 2 && b.full.s[0] == 1 && (l == 1 || res_st.s[1] == n[0])) {
+        if (!done && path == 0 && (fastF || (F >= 12 && F <= 20)) && b.nd == 3 && b.nt == 2 && b.full.s[0] == 1 && (l == 1 || res_st.s[1] == n[0])) {
             hipError_t e = hipSuccess;
-            done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e);
+            const char *kn = nullptr;
+            done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e, &kn);
             WL_TRYI(e);
-            if (done) dominant = "k_inv2d_stream";
+            if (done) dominant = kn;
         }
         // ---- 12..20 taps, Float32, output rows a multiple of 256: the whole 2-D level in one pass (wl_inv2d_long.hip) ----
-        if constexpr (sizeof(T) == 4) {
-            if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 512) && b.full.s[0] == 1 &&
-                inv2d_long_ok(F, n[0], n[1]) && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
-                (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
-                WL_TRYI(inv2d_long_launch(st, taps, x, b.full.s[1], llsrc, llsrc ? llsrc_st.s[1] : 0, res, res_st.s[1], n[0], n[1], cu_count));
-                dominant = "k_inv2d_lds_long";
-                done = true;
-            }
-        }
+        if (!done && F >= 12) WL_TRYI(try_lds_long());
         // ---- long filters (12..24 taps) ----
         if (!done && path == 0 && long_filter_ok(F) && i_env("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1) {
             hipError_t e = hipSuccess;
@@ -1372,14 +1380,24 @@ template bool fast_lines_inv_level<double>(hipStream_t, const Taps<double> &, co
 // -> plane p of dst (dense n0 x n1).
 template <typename T>
 bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
-                  int64_t nplanes, int nll, int cu_count, hipError_t *err)
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel)
 {
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
-    if ((F % 2) != 0 || F > 10 || n0 < 256 || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 ||
+    if ((F % 2) != 0 || F > 20 || n0 < 256 || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 ||
         !i_al16(x) || !i_al16(dst) || (ll && !i_al16(ll)) || nplanes > 65535)
         return false;
+    // the LDS-exchange level kernel (wl_inv2d_long.hip) where it is enabled for this filter length and the batch is large
+    if (i_env("WL_INVLONG2D", 1) != 0 && inv2d_long_ok(F, n0, n1, (int)sizeof(T)) && n0 >= i_env("WL_INVLONG2D_MIN_ROWS", 512) &&
+        (F >= 12 || n0 * n1 * nplanes >= (int64_t)i_env("WL_INVLONG_SHORT_MIN", 1 << 22))) {
+        const InvLongBatch bt = {nplanes, x2, (n0 >> 1) * (n1 >> 1), n0 * n1, ll ? nll : 0};
+        *err = inv2d_long_launch<T>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, bt);
+        if (kernel) *kernel = "k_inv2d_lds_long";
+        return true;
+    }
+    if (F > 10) return false;
+    if (kernel) *kernel = "k_inv2d_stream";
     bool ok = false;
     WL_DISPATCH_FI(F, *err = launch_inv2d<T, FF, 2>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, nplanes, x2,
                                                      (n0 >> 1) * (n1 >> 1), n0 * n1, nll);
@@ -1387,9 +1405,9 @@ bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, i
     return ok;
 }
 template bool inv2d_planes<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *, int64_t,
-                                  int64_t, int64_t, int, int, hipError_t *);
+                                  int64_t, int64_t, int, int, hipError_t *, const char **);
 template bool inv2d_planes<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *, int64_t,
-                                   int64_t, int64_t, int, int, hipError_t *);
+                                   int64_t, int64_t, int, int, hipError_t *, const char **);
 
 template int filter_inv_levels<float>(void *, bool, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);

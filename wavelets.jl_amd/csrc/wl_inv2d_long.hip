@@ -1,8 +1,15 @@
-// wl_inv2d_long.hip -- ONE fused 2-D INVERSE level per pass over HBM for the 12 ... 20-tap filters (db6 ... db10, sym6 ... sym10,
-// coif4, coif6, beyl), Float32: the mirror of k_fwd2d_lds_long (wl_fwd2d_long.hip).  Up to round 3 these filters took two line
-// launches + one axis launch per inverse level through an N-element intermediate (2 x the traffic, 3 launches).
+// wl_inv2d_long.hip -- ONE fused 2-D INVERSE level per pass over HBM through an LDS exchange: the mirror of k_fwd2d_lds_long
+// (wl_fwd2d_long.hip).  Written in round 4 for the 12 ... 20-tap filters (db6 ... db10, sym6 ... sym10, coif4, coif6, beyl), which
+// up to round 3 took two line launches + one axis launch per inverse level through an N-element intermediate (2 x the traffic,
+// 3 launches).  Also used where it measured ahead of the DPP-halo streaming kernel (k_inv2d_stream, wl_inv.hip):
+//   Float32  12 ... 20 taps: levels of >= 512 output rows;  10 taps (sym5, the default wavelet of denoise): blocks / batches of >= 2^22
+//            samples (8192^2 level 130 -> 117 us, 64 x 2048^2 batch 532 -> 436 us);  8 taps: not used (112 against 114 us, and the
+//            fused pair of k_inv2d_pair is ahead of both)
+//   Float64  8 ... 20 taps (8192^2 idwt L = 13: db4 331 -> 316 us, sym5 390 -> 355, db6 711 -> 376, db8 733 -> 437, db10 781 -> 631;
+//            14 taps and more run one wave per SIMD with the ring's overflow in AGPRs)
+// Batches (planes of a 3-D level, images of wl_dwt_filter_batch, the spins of the TI denoise) ride on blockIdx.y.
 //
-//   k_inv2d_lds_long<F, W, D>
+//   k_inv2d_lds_long<T, F, W, D>
 //
 // Reference order (transforms_filter.jl:173-186): dim-1 reconstruction of every column, then dim-2 reconstruction of every row.
 // A workgroup of W waves (default 1) owns 256 W OUTPUT rows (= 128 W coefficient pairs along dim 1: two pairs per lane, exact
@@ -29,23 +36,39 @@
 
 namespace wl {
 
-template <int F>
+template <typename T, int F>
 struct InvLongArgs {
-    const float *x; int64_t ldx;        // coefficient array
-    const float *ll; int64_t ldl;       // deeper reconstruction = approximation quadrant, h0 x h1 (nullptr: it is in x)
-    float *dst; int64_t ldd;            // n0 x n1 result
+    const T *x; int64_t ldx;            // coefficient array
+    const T *ll; int64_t ldl;           // deeper reconstruction = approximation quadrant, h0 x h1 (nullptr: it is in x)
+    T *dst; int64_t ldd;                // n0 x n1 result
     int64_t n0, n1;
     int TP;                             // output column pairs per chunk
     int nstrips, nchunks;
-    TapsF<float, F> tp;
+    // batch of independent blocks over blockIdx.y (planes of a 3-D level, images of a batch): element strides; only the first nll
+    // planes take their approximation quadrant from ll
+    int64_t bs_x, bs_ll, bs_dst; int nll;
+    TapsF<T, F> tp;
 };
 
-template <int F, int W, int D>
-__global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
+// four consecutive samples: 16 bytes per store (one for Float32, two for Float64)
+template <typename T>
+__device__ __forceinline__ void store4(T *p, const T (&v)[4])
 {
-    typedef float T;
-    typedef float T2 __attribute__((ext_vector_type(2)));
-    typedef float T4 __attribute__((ext_vector_type(4)));
+    constexpr int C = (int)(16 / sizeof(T));
+    typedef T V __attribute__((ext_vector_type(C)));
+#pragma unroll
+    for (int c = 0; c < 4 / C; ++c) {
+        V t;
+#pragma unroll
+        for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
+template <typename T, int F, int W, int D>
+__global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k_inv2d_lds_long(InvLongArgs<T, F> a)
+{
+    typedef T T2 __attribute__((ext_vector_type(2)));
     constexpr int SH = (F - 2) / 2, SHP = (SH + 1) & ~1;      // reach in pairs; the same rounded up to even (8-byte aligned LDS rows)
     constexpr int R = ((SH + 1 + D - 1) / D) * D;             // ring depth = unroll: >= SH + 1, a multiple of the request distance D
     constexpr int NP = 128 * W;                               // coefficient pairs of the strip
@@ -64,8 +87,10 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
     const int64_t pend = (p0 + a.TP < h1) ? (p0 + a.TP) : h1;
     const int S = (int)(pend - p0);
     const int64_t r0 = (int64_t)strip * NP;
-    const bool from_ll = (a.ll != nullptr);
+    const bool from_ll = (a.ll != nullptr) && ((int)blockIdx.y < a.nll);
     const int64_t ls_ld = from_ll ? a.ldl : a.ldx;
+    const T *const xb = a.x + (int64_t)blockIdx.y * a.bs_x;
+    const T *const llb = from_ll ? (a.ll + (int64_t)blockIdx.y * a.bs_ll) : xb;
     // the raw columns of step t (t from -SH: wraps below zero; the requests past the chunk wrap above and are never used)
     auto col_s = [&](const int t) __attribute__((always_inline)) { int64_t j = p0 + t; if (j < 0) j += h1; if (j >= h1) j -= h1; return j; };
     auto col_d = [&](const int t) __attribute__((always_inline)) { int64_t j = p0 + t + SH; if (j >= h1) j -= h1; return j; };
@@ -73,9 +98,9 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
     // ================= lane Lm = 64 wv + lane owns pairs r0 + 2 Lm, r0 + 2 Lm + 1 =================
     const int Lm = 64 * wv + lane;
     const int64_t rr = r0 + 2 * Lm;
-    const T *ls_base = (from_ll ? a.ll : a.x) + rr;           // left half, scaling rows
-    const T *ld_base = a.x + h0 + rr;                         // left half, detail rows
-    const T *rs_base = a.x + h1 * a.ldx + rr;                 // right half, scaling rows
+    const T *ls_base = llb + rr;                              // left half, scaling rows
+    const T *ld_base = xb + h0 + rr;                          // left half, detail rows
+    const T *rs_base = xb + h1 * a.ldx + rr;                  // right half, scaling rows
     const T *rd_base = rs_base + h0;                          // right half, detail rows
     const int ws = SHP + 2 * Lm;                              // LDS positions: scaling arrays hold pair r0 - SHP + i at i, detail arrays r0 + i
     const int wd = 2 * Lm;
@@ -87,9 +112,9 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
     const bool hl = lane < 2 * SH;
     int64_t hr = 0;
     if (hl) { hr = hd ? (r0 + NP + (lane - SH)) : (r0 - SH + lane); if (hr < 0) hr += h0; if (hr >= h0) hr -= h0; }
-    const T *hlb = hd ? (a.x + h0 + hr) : ((from_ll ? a.ll : a.x) + hr);
+    const T *hlb = hd ? (xb + h0 + hr) : (llb + hr);
     const int64_t hl_ld = hd ? a.ldx : ls_ld;
-    const T *hrb = a.x + h1 * a.ldx + (hd ? h0 : 0) + hr;
+    const T *hrb = xb + h1 * a.ldx + (hd ? h0 : 0) + hr;
     const int hw = hd ? (NP + lane - SH) : (SHP - SH + lane);
     const int hal = hd ? 1 : 0;
 
@@ -107,7 +132,7 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
     };
 
     T iS[R][4], iD[R][4];                                     // dim-1-reconstructed columns: left half / right half
-    T *out = a.dst + 2 * (r0 + 2 * Lm);                       // the lane's four output rows
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + 2 * (r0 + 2 * Lm);      // the lane's four output rows
     // one column of the exchange -> the lane's four dim-1-reconstructed samples
     auto recon = [&](const T *sa, const T *da, T (&o)[4]) __attribute__((always_inline)) {
         // scaling pairs r - SH .. r + 1 at positions ws - SH .. ws + 1 (ws - SHP is even: read from there), detail pairs r .. r + 1 + SH
@@ -157,8 +182,8 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
             window_inv<T, F>(sw, dw, a.tp, xe[q], xo[q]);
         }
         const int64_t p = p0 + t;
-        *reinterpret_cast<T4 *>(out + (2 * p) * a.ldd) = T4{xe[0], xe[1], xe[2], xe[3]};
-        *reinterpret_cast<T4 *>(out + (2 * p + 1) * a.ldd) = T4{xo[0], xo[1], xo[2], xo[3]};
+        store4<T>(out + (2 * p) * a.ldd, xe);
+        store4<T>(out + (2 * p + 1) * a.ldd, xo);
     };
 
 #pragma unroll
@@ -176,21 +201,24 @@ __global__ void __launch_bounds__(64 * W, 2) k_inv2d_lds_long(InvLongArgs<F> a)
 }
 
 // ------------------------------------------------------------------------------------------
-bool inv2d_long_ok(int F, int64_t n0, int64_t n1)
+bool inv2d_long_ok(int F, int64_t n0, int64_t n1, int esize)
 {
-    if (F < 12 || F > 20 || (F & 1)) return false;
+    if (F < 8 || F > 20 || (F & 1)) return false;
+    if (esize == 4 && F < (int)opt("WL_INVLONG_FMIN", 10)) return false;
+    if (esize == 8 && (F < (int)opt("WL_INVLONG_FMIN64", 8) || F > (int)opt("WL_INVLONG_FMAX64", 20))) return false;
     if (n0 >= ((int64_t)1 << 30) || n1 >= ((int64_t)1 << 30)) return false;
     // exact tiling: strips of 256 output rows per main wave; the reach (SH pairs) must not wrap twice
     const int64_t h0 = n0 >> 1, h1 = n1 >> 1;
     return n0 >= 256 && (n0 % 256) == 0 && (n1 % 2) == 0 && h1 >= (F - 2) / 2 + 5 && h0 >= (F - 2) / 2;   // (+ 4: requests up to 4 steps ahead wrap once)
 }
 
-template <int F, int W, int D>
-static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
-                                     float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+template <typename T, int F, int W, int D>
+static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                                      T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
-    InvLongArgs<F> a;
+    InvLongArgs<T, F> a;
     a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
+    a.bs_x = bt.bs_x; a.bs_ll = bt.bs_ll; a.bs_dst = bt.bs_dst; a.nll = bt.nll;
     const int64_t h1 = n1 >> 1;
     a.nstrips = (int)(n0 / (256 * W));
     // a chunk pays SH prologue steps: long chunks where the array is large enough to fill the chip (8 waves per CU: two per SIMD
@@ -198,49 +226,57 @@ static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<float> &taps, c
     int TP = (int)opt("WL_INVLONG_TP", 64);
     if (TP < 8) TP = 64;
     const int64_t want = (int64_t)cu_count * opt("WL_INVLONG_WAVES_PER_CU", 8);
-    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * W < want) TP >>= 1;
+    while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * W * bt.nplanes < want) TP >>= 1;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
-    a.tp = shrink<float, F>(taps);
-    hipLaunchKernelGGL((k_inv2d_lds_long<F, W, D>), dim3((unsigned)(a.nstrips * a.nchunks)), dim3(64 * W), 0, st, a);
+    a.tp = shrink<T, F>(taps);
+    hipLaunchKernelGGL((k_inv2d_lds_long<T, F, W, D>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)bt.nplanes), dim3(64 * W), 0, st, a);
     return hipGetLastError();
 }
 
-template <int F, int W>
-static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
-                                     float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+template <typename T, int F, int W>
+static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                                     T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     // request distance in steps: a step is ~0.3 us of arithmetic, a loaded HBM round trip 1 - 2 us
-    const int D = (int)opt("WL_INVLONG_D", 3);
-    if (D <= 1) return launch_inv_long_fwd<F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    if (D == 2) return launch_inv_long_fwd<F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    if (D == 3) return launch_inv_long_fwd<F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    return launch_inv_long_fwd<F, W, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    const int D = (int)opt("WL_INVLONG_D", F <= 10 ? 2 : 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
+    if (D <= 1) return launch_inv_long_fwd<T, F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    if (D == 2) return launch_inv_long_fwd<T, F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    if (D == 3) return launch_inv_long_fwd<T, F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    return launch_inv_long_fwd<T, F, W, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
 }
 
-template <int F>
-static hipError_t launch_inv_long_f(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
-                                    float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+template <typename T, int F>
+static hipError_t launch_inv_long_f(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                                    T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     int W = (int)opt("WL_INVLONG_W", 0);
     if (W != 1 && W != 2 && W != 4) W = 1;                    // (one wave per workgroup: the step's barrier is free; W = 2, 4 measured equal or slower)
     while (W > 1 && (n0 % (256 * W)) != 0) W >>= 1;
-    if (W == 4) return launch_inv_long_fw<F, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    if (W == 2) return launch_inv_long_fw<F, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    return launch_inv_long_fw<F, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    if (W == 4) return launch_inv_long_fw<T, F, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    if (W == 2) return launch_inv_long_fw<T, F, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    return launch_inv_long_fw<T, F, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
 }
 
-hipError_t inv2d_long_launch(hipStream_t st, const Taps<float> &taps, const float *x, int64_t ldx, const float *ll, int64_t ldl,
-                             float *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count)
+template <typename T>
+hipError_t inv2d_long_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
+                             T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     switch (taps.F) {
-    case 12: return launch_inv_long_f<12>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    case 14: return launch_inv_long_f<14>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    case 16: return launch_inv_long_f<16>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    case 18: return launch_inv_long_f<18>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
-    case 20: return launch_inv_long_f<20>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count);
+    case 8: return launch_inv_long_f<T, 8>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 10: return launch_inv_long_f<T, 10>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 12: return launch_inv_long_f<T, 12>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 14: return launch_inv_long_f<T, 14>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 16: return launch_inv_long_f<T, 16>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 18: return launch_inv_long_f<T, 18>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    case 20: return launch_inv_long_f<T, 20>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     default: return hipErrorInvalidValue;
     }
 }
+
+template hipError_t inv2d_long_launch<float>(hipStream_t, const Taps<float> &, const float *, int64_t, const float *, int64_t, float *, int64_t,
+                                             int64_t, int64_t, int, const InvLongBatch &);
+template hipError_t inv2d_long_launch<double>(hipStream_t, const Taps<double> &, const double *, int64_t, const double *, int64_t, double *, int64_t,
+                                              int64_t, int64_t, int, const InvLongBatch &);
 
 }  // namespace wl

@@ -220,6 +220,37 @@ def test_denoise_pipeline_bitexact(gpu, W, oracle, dtype):
         assert np.array_equal(yz, ez) and np.array_equal(np.signbit(yz), np.signbit(ez)), Lz
 
 
+def test_ti_fused_thresholds_all_kinds(gpu, W, oracle):
+    """The level kernels of the translation-invariant batch threshold the coefficients they store (round 4: every kind, not just
+    hard): a Float32 cut per coefficient, threshold_one in Float64 for what survives the cut of soft / semisoft / Stein.  Both
+    level kernels (k_fwd2d_lds per level; k_fwd2d_pair, two levels per launch), thresholds from "nothing survives" to "everything
+    survives" (incl. t = 0: no cut at all), the pair as the last launch (its approximation is final), against the oracle and
+    against the separate threshold pass."""
+    rng = np.random.default_rng(11)
+    b = (doppler(512)[:, None] * doppler(512)[None, :] + 0.05 * rng.standard_normal((512, 512))).astype(np.float32)
+    bd = W.to_device(b)
+    kinds = (W.SoftTH(), W.SemiSoftTH(), W.SteinTH(), W.HardTH())
+    for pair in (0, 1):
+        for th in kinds:
+            for wname, L, nspin, t, sigma in (("db4", 4, (2, 2), 2.0, None), ("sym5", 3, (3, 2), 0.4, None), ("db2", 2, (2, 1), 1.0, None),
+                                              ("db4", 2, (1, 2), 3.0, 0.05), ("sym5", 5, (2, 2), 0.0 if not isinstance(th, W.SteinTH) else 1e-3, 1.0)):
+                wt = W.wavelet(getattr(W.WT, wname))
+                dnt = W.VisuShrink(th, t)
+                kw = dict(L=L, dnt=dnt, TI=True, nspin=nspin)
+                if sigma is not None:
+                    kw["estnoise"] = (lambda s: (lambda a, w: s))(sigma)
+                e = _oracle_denoise(oracle, W, b, wt, L, dnt, True, nspin, sigma=sigma)
+                W.clear_options()
+                if pair:
+                    W.set_option("WL_PAIR_BATCH_MIN", 0)
+                y = host(W, W.denoise(bd, wt, **kw))
+                assert W.last_kernel() == "denoise_ti_batch"
+                assert np.array_equal(y, e, equal_nan=True), (pair, type(th).__name__, wname, L, t, int((y != e).sum()))
+                W.set_option("WL_TI_FUSE_SOFT", 0)
+                assert np.array_equal(host(W, W.denoise(bd, wt, **kw)), e, equal_nan=True), (pair, type(th).__name__, wname, "separate pass")
+    W.clear_options()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_denoise_ti_lifting_batch_bitexact(gpu, W, oracle, dtype):
     """wl_denoise_ti_lifting (round 4): the translation-invariant branch of denoise for lifting schemes as one device-resident

@@ -84,7 +84,12 @@ int main(int argc, char **argv)
         for (int d = 0; d < nd; ++d) L = std::min(L, wl_maxtransformlevels(dims[d]));
     }
     const int fw = atoi(kv["fw"].c_str()), reps = atoi(kv["reps"].c_str()), warm = atoi(kv["warm"].c_str());
-    auto it = kTaps.find(kv["filt"]);
+    // filt=cdf97lift: the cdf9/7 lifting scheme (wt_main.jl:451-480 table order) through wl_dwt_lifting_oop
+    const bool lifting = kv["filt"] == "cdf97lift";
+    static const int32_t ls_upd[4] = {1, 0, 1, 0}, ls_nc[4] = {2, 2, 2, 2}, ls_sh[4] = {0, 1, 0, 1};
+    static const double ls_c[8] = {1.5861343420604, 1.5861343420604, 0.05298011857291494, 0.05298011857291494,
+                                   -0.882911075531393, -0.882911075531393, -0.44350685204384654, -0.44350685204384654};
+    auto it = kTaps.find(lifting ? std::string("db4") : kv["filt"]);
     if (it == kTaps.end()) { fprintf(stderr, "unknown filter\n"); return 1; }
     const std::vector<double> &qmf = it->second;
     const size_t N = (size_t)dims[0] * dims[1] * dims[2];
@@ -116,12 +121,13 @@ int main(int argc, char **argv)
     if (dtype == WL_F32) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float *)x, N, 42u);
     else hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, (double *)x, N, 42u);
     CK(hipMemset(y, 0, N * es));
-    rc = wl_ctx_reserve(ctx, wl_workspace_bytes(dtype, nd, dims, L));
+    rc = wl_ctx_reserve(ctx, lifting ? wl_workspace_bytes_full(dtype, nd, dims, L) : wl_workspace_bytes(dtype, nd, dims, L));
     if (rc) { fprintf(stderr, "reserve: %s\n", wl_strerror(rc)); return 2; }
     CK(hipDeviceSynchronize());
     const bool batched = kv.count("dwtc") && atoi(kv["dwtc"].c_str()) != 0;      // dwtc=1: n1 signals of length n0 (columns)
     if (batched && atoi(kv["L"].c_str()) == 0) L = wl_maxtransformlevels(dims[0]);
     auto call = [&]() {
+        if (lifting) return wl_dwt_lifting_oop(ctx, dtype, y, x, nd, dims, 4, ls_upd, ls_nc, ls_sh, ls_c, 1.1496043988603355, 0.8698644516247099, L, fw, nullptr);
         if (batched) return wl_dwtc_filter(ctx, dtype, y, x, dims[0], dims[1], dims[0], qmf.data(), (int)qmf.size(), L, fw, nullptr);
         return wl_dwt_filter(ctx, dtype, y, x, nd, dims, qmf.data(), (int)qmf.size(), L, fw, nullptr);
     };

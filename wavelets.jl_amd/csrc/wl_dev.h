@@ -163,6 +163,48 @@ __device__ __forceinline__ T threshold_one(T xr, int th, C t)
     return out;
 }
 
+// ---- threshold! fused into the stores of a Float32 level kernel (the translation-invariant batch) ----
+// The reference computes `x[i] op t` in Float64 (t = sigma * dnt.t is a Float64).  Every kind zeroes the small coefficients, and
+// "small" has a Float32 cut: a compare and a select per coefficient decide most of them without leaving single precision.
+//   hard:            |x| <= t            <=>  |x| <= the largest Float32 <= t           (the cut is the whole threshold)
+//   soft, semisoft:  |x| - t < 0         <=>  |x| <= the largest Float32 <  t           (semisoft: then x <= |x| < t <= 2t holds too)
+//   Stein:           1 - t^2 / x^2 < 0   <==  |x| <= the largest Float32 <= 0.999 t     (a sufficient cut: the quotient's roundings are
+//                                                                                       1e-16 relative; x = 0 gives -Inf < 0 as well)
+// Coefficients above the cut of the last three kinds take threshold_one in Float64 -- inside a wave-uniform branch that a wave
+// whose coefficients were all cut (most waves of a denoising problem) skips.  t <= 0 disables the cut (tf < 0): soft with t = 0
+// keeps -0.0, Stein with t = 0 produces the reference's NaN at x = 0.
+struct ThCut {
+    float tf;       // |x| <= tf: zero
+    double t;
+    int th;         // wl_thtype; < 0: none
+};
+__device__ __forceinline__ ThCut th_make_cut(int th, double t)
+{
+    ThCut c;
+    c.th = th; c.t = t; c.tf = -1.f;
+    if (th < 0 || !(t > 0)) {
+        if (th == WL_TH_HARD && t == 0) c.tf = 0.f;                  // (hard: |x| <= 0 zeroes -0.0)
+        return c;
+    }
+    const double lim = (th == WL_TH_STEIN) ? 0.999 * t : t;
+    float f = (float)lim;
+    const bool strict = (th == WL_TH_SOFT || th == WL_TH_SEMISOFT);
+    if ((double)f > lim || (strict && (double)f == lim)) f = (f > 0.f) ? __uint_as_float(__float_as_uint(f) - 1u) : -1.f;
+    if (th != WL_TH_HARD && f > 3.4028234663852886e38f) f = 3.4028234663852886e38f;      // (t = Inf: an infinite x still takes the exact path -> NaN)
+    c.tf = f;
+    return c;
+}
+__device__ __forceinline__ float th_cut(const ThCut &c, float v) { return (__builtin_fabsf(v) <= c.tf) ? 0.f : v; }
+// after th_cut on a group of coefficients: `above` = this lane still holds a coefficient above the cut
+__device__ __forceinline__ bool th_needs_exact(const ThCut &c, bool above)
+{
+    return c.th > WL_TH_HARD && __builtin_amdgcn_ballot_w64(above) != 0;
+}
+__device__ __forceinline__ float th_exact(const ThCut &c, float v)
+{
+    return (__builtin_fabsf(v) <= c.tf) ? v : threshold_one<float, double>(v, c.th, c.t);     // (cut values are already 0)
+}
+
 // ---- hand-placed vector-memory loads / waits of the 2-D marching kernels (wl_fwd2d.hip, wl_pair2d.hip) ----
 __device__ __forceinline__ void wg_lds_sync(bool multi)
 {

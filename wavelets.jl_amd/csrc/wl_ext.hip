@@ -976,7 +976,9 @@ int denoise_ti_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int ndims, co
             // plane p of this group = copy (b0 + p) % nsp0 of ZR with its columns rotated by (b0 + p) / nsp0
             tl_srcview.mod = (int)nsp0; tl_srcview.spin0 = b0; tl_srcview.used = 0; tl_srcview.corner0 = n0; tl_srcview.corner1 = n1;
             // ... and that launch thresholds the level-1 details as it stores them (3/4 of all coefficients)
-            const bool fuse_th = opt("WL_TI_FUSE_TH", 1) != 0 && th == WL_TH_HARD;      // (one Float32 compare; the other kinds compute in Float64)
+            // (hard: one Float32 compare; soft / semisoft / Stein: the same cut, Float64 only for the survivors -- ThCut, wl_dev.h)
+            const bool fuse_th = opt("WL_TI_FUSE_TH", 1) != 0 && th >= WL_TH_HARD && th <= WL_TH_STEIN &&
+                                 (th == WL_TH_HARD || opt("WL_TI_FUSE_SOFT", 1) != 0);
             tl_srcview.th = fuse_th ? th : -1; tl_srcview.t_unit = t_unit; tl_srcview.sigma_host = sigma_host; tl_srcview.mad_dev = &sel->result;
             rc = filter_fwd_levels<T>(tw, true, ctx->cu_count, ctx->path, st, bb, XT, ZR, taps, L, &ctx->last_kernel, &ctx->last_hip);
             shifted = tl_srcview.used != 0;

@@ -180,15 +180,11 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     T *const llb = to_ll ? (a.ll + (int64_t)blockIdx.y * a.bs_ll) : yb;
     const int64_t ldl = to_ll ? a.ldll : a.ldy;
     const int64_t kbase = j0 >> 1;                     // multiple of 8
-    // TH (hard threshold only): |x| <= t with t = sigma * dnt.t in Float64 (the reference compares the promoted values) is
-    // |x| <= tf for the largest Float32 tf <= t -- one compare and one select per coefficient.  (The general threshold_one in
-    // Float64 made this kernel, which is VALU-bound with 10 taps, slower than the separate pass it was meant to save.)
-    float tf = 0.f;
-    if constexpr (TH != 0) {
-        const double tthr = ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit;
-        tf = (float)tthr;
-        if ((double)tf > tthr) tf = __uint_as_float(__float_as_uint(tf) - 1u);        // (tthr >= 0: the next float towards zero)
-    }
+    // TH: threshold!(xt, th, sigma * dnt.t) at the stores -- a Float32 cut per coefficient, Float64 only for what survives the cut
+    // of soft / semisoft / Stein, in a wave-uniform branch (ThCut, wl_dev.h).  (Round 3 applied the general threshold_one in
+    // Float64 to every coefficient: this kernel, VALU-bound with 10 taps, became slower than the separate pass it was to save.)
+    ThCut cut = th_make_cut(-1, 0.0);
+    if constexpr (TH != 0) cut = th_make_cut(a.th, ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit);
 
     auto step = [&](const int t, const int u, const bool prefetch) __attribute__((always_inline)) {
         if (prefetch) {                                    // (compile-time)
@@ -250,12 +246,19 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
         }
         if constexpr (TH != 0) {
             // the three detail components of every row (sd, ds, dd) are final coefficients: threshold!(xt, th, sigma * t)
+            bool above = false;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                P[q].y = (__builtin_fabsf(P[q].y) <= tf) ? 0.f : P[q].y;
-                Q[q].x = (__builtin_fabsf(Q[q].x) <= tf) ? 0.f : Q[q].x;
-                Q[q].y = (__builtin_fabsf(Q[q].y) <= tf) ? 0.f : Q[q].y;
-                if (!to_ll) P[q].x = (__builtin_fabsf(P[q].x) <= tf) ? 0.f : P[q].x;     // (last level: the approximation is final too)
+                P[q].y = th_cut(cut, P[q].y); Q[q].x = th_cut(cut, Q[q].x); Q[q].y = th_cut(cut, Q[q].y);
+                if (!to_ll) P[q].x = th_cut(cut, P[q].x);                 // (last level: the approximation is final too)
+                above = above || P[q].y != 0.f || Q[q].x != 0.f || Q[q].y != 0.f || (!to_ll && P[q].x != 0.f);
+            }
+            if (th_needs_exact(cut, above || cut.tf < 0.f)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    P[q].y = th_exact(cut, P[q].y); Q[q].x = th_exact(cut, Q[q].x); Q[q].y = th_exact(cut, Q[q].y);
+                    if (!to_ll) P[q].x = th_exact(cut, P[q].x);
+                }
             }
         }
         const int64_t k = kbase + t;

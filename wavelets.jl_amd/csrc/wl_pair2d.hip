@@ -96,14 +96,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         crot = spin / a.src_mod;
     }
     const T *const srcp = a.src + (BT ? splane * a.bs_src : 0);
-    // hard threshold (BT): |x| <= t in Float64 <=> |x| <= the largest Float32 <= t (see k_fwd2d_lds); tf < 0: nothing is zeroed
-    float tf = -1.f;
-    if (BT && a.th >= 0) {
-        const double tthr = ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit;
-        tf = (float)tthr;
-        if ((double)tf > tthr) tf = __uint_as_float(__float_as_uint(tf) - 1u);
-    }
-    auto thr = [&](const T v) __attribute__((always_inline)) { return (BT && __builtin_fabsf(v) <= tf) ? 0.f : v; };
+    // threshold! at the stores (BT): a Float32 cut, Float64 only for the survivors of soft / semisoft / Stein (ThCut, wl_dev.h)
+    ThCut cut = th_make_cut(-1, 0.0);
+    if (BT && a.th >= 0) cut = th_make_cut(a.th, ((a.sigma_host >= 0) ? a.sigma_host : (*a.mad_dev / 0.6745)) * a.t_unit);
     const bool th_ll = BT && (a.ll == nullptr);          // last level of the transform: its approximation is final too
 
     // The helper and the level-(l+1) wave issue ahead of the main waves: every wave of the workgroup meets at the step barrier,
@@ -171,10 +166,19 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                 if (kd2 >= nxj2) kd2 -= nxj2;
                 T *const ck = yb + k2 * a.ldy, *const ckd = yb + (nxj2 + kd2) * a.ldy, *const cl = llb + k2 * ldl;   // (uniform)
                 if constexpr (BT != 0) {
+                    bool above = false;
 #pragma unroll
                     for (int q = 0; q < HS; ++q) {
-                        if (th_ll) P[q].x = thr(P[q].x);
-                        P[q].y = thr(P[q].y); Q[q].x = thr(Q[q].x); Q[q].y = thr(Q[q].y);
+                        if (th_ll) P[q].x = th_cut(cut, P[q].x);
+                        P[q].y = th_cut(cut, P[q].y); Q[q].x = th_cut(cut, Q[q].x); Q[q].y = th_cut(cut, Q[q].y);
+                        above = above || (th_ll && P[q].x != 0.f) || P[q].y != 0.f || Q[q].x != 0.f || Q[q].y != 0.f;
+                    }
+                    if (th_needs_exact(cut, above || cut.tf < 0.f)) {
+#pragma unroll
+                        for (int q = 0; q < HS; ++q) {
+                            if (th_ll) P[q].x = th_exact(cut, P[q].x);
+                            P[q].y = th_exact(cut, P[q].y); Q[q].x = th_exact(cut, Q[q].x); Q[q].y = th_exact(cut, Q[q].y);
+                        }
                     }
                 }
                 if constexpr (HS == 4) {
@@ -404,8 +408,16 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         }
         *reinterpret_cast<T2 *>(slot) = T2{P[0].x, P[1].x};             // approximation column kbase + t -> ring
         if constexpr (BT != 0) {
+            bool above = false;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { P[q].y = thr(P[q].y); Q[q].x = thr(Q[q].x); Q[q].y = thr(Q[q].y); }
+            for (int q = 0; q < 2; ++q) {
+                P[q].y = th_cut(cut, P[q].y); Q[q].x = th_cut(cut, Q[q].x); Q[q].y = th_cut(cut, Q[q].y);
+                above = above || P[q].y != 0.f || Q[q].x != 0.f || Q[q].y != 0.f;
+            }
+            if (th_needs_exact(cut, above || cut.tf < 0.f)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { P[q].y = th_exact(cut, P[q].y); Q[q].x = th_exact(cut, Q[q].x); Q[q].y = th_exact(cut, Q[q].y); }
+            }
         }
         const int64_t k = kbase + t;
         int64_t kd = k + SH;

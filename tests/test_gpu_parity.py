@@ -1023,6 +1023,38 @@ def test_lifting_register_tail_2d(gpu, W, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_lds_tail_3d(gpu, W, oracle, dtype):
+    """k_tail_lift3d (round 4: every remaining level of a power-of-two cube of <= 32^3 Float32 / 16^3 Float64 in one workgroup's
+    LDS, a thread per line, planes -> rows -> columns and back): every cube from 8 to 64, every depth, the three scheme shapes,
+    forward and inverse, in place, as the end of a larger transform -- bit for bit against the oracle and against the per-axis
+    launches it replaces."""
+    for sname in ("cdf97", "db2", "haar"):
+        sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+        for n in (8, 16, 32, 64):
+            x = rng_array((n, n, n), dtype, n + len(sname))
+            for L in range(1, W.maxtransformlevels(n) + 1):
+                ye = oracle.dwt_lifting(x, sch, L)
+                assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L)
+                t = dev(W, x)
+                W.dwt_(t, sch, L)
+                assert np.array_equal(host(W, t), ye), (sname, n, L, "in place")
+                xe = oracle.dwt_lifting(ye, sch, L, fw=False)
+                assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "inv")
+                t = dev(W, ye)
+                W.idwt_(t, sch, L)
+                assert np.array_equal(host(W, t), xe), (sname, n, L, "inv in place")
+                with W.options(WL_LIFT_TAIL3D=0):
+                    assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), (sname, n, L, "per-axis launches")
+                    assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), xe), (sname, n, L, "per-axis launches inv")
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    x = rng_array((128, 128, 128), dtype, 9)
+    for L in (7, 4):
+        ye = oracle.dwt_lifting(x, sch, L)
+        assert np.array_equal(host(W, W.dwt(dev(W, x), sch, L)), ye), L
+        assert np.array_equal(host(W, W.idwt(dev(W, ye), sch, L)), oracle.dwt_lifting(ye, sch, L, fw=False)), (L, "inv")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_lifting_any_even_size_tile_kernel(gpu, W, oracle, dtype):
     """k_lift2d_gtile (one 2-D lifting level of ANY even size per launch: one wave per 64 x 64 tile, a lane holds a tile row /
     column in registers, halo = the scheme's dependency cone, in-bounds / boundary summation forms selected by the global

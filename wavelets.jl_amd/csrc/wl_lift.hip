@@ -1131,6 +1131,193 @@ static hipError_t launch_tail_lift2d_reg(int id, hipStream_t st, const LiftSchem
 }
 
 // --------------------------------------------------------------------------------------------------
+// LDS tail for 3-D lifting (round 4): every remaining level of a power-of-two cube of <= MM^3 (32^3 Float32 = 132 KiB of LDS,
+// 16^3 Float64) in ONE workgroup.  As in the 2-D register tail a thread owns a whole line of the current pass and keeps it in
+// registers (s[H], d[H]: compile-time indices, the periodic wrap and the reference's two summation forms decided per element
+// at compile time); the cube lives in LDS between the passes (leading dimensions MM + 1 and (MM + 1) MM: the three line
+// directions all read / write conflict-free), M^2 lines per pass = one line per thread of the 1024.  Pass order of the
+// reference (transforms_lifting.jl:228-268): forward planes (dim 3), rows (dim 2), columns (dim 1); inverse columns, rows, planes.
+// Replaces three launches per level (k_lift_axis_stream x 2 + k_lift_short_lines) on the levels that hold 0.2 % of the data:
+// 256^3 cdf9/7, 8 levels: 22 launches -> 8.
+__device__ __forceinline__ void tail3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <typename T>
+struct LiftTail3Args {
+    const T *src; int64_t s1, s2;   // fw: the level's input cube;  inv: the coefficient array (its m0^3 corner)
+    T *y; int64_t y1, y2;           // fw: the coefficient array;   inv: the m0^3 result
+    int m0, nlev;
+    T c[LIFT_FAST_STEPS][WL_MAX_NCOEF];
+    T norm1, norm2;
+};
+
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail3_fwd_level(T *P, const LiftTail3Args<T> &a, bool last, int tid, int nthr)
+{
+    constexpr int H = M / 2, L1 = MM + 1, L2 = (MM + 1) * MM;
+    const int u = tid % M, v = tid / M;                      // the two coordinates a line does not run along
+    const bool act = tid < M * M;
+    // ---- planes: lines along dim 3 at (i, j) = (u, v) ----
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u + v * L1;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = q[(2 * k) * L2]; d[k] = q[(2 * k + 1) * L2]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[k * L2] = s[k] * a.norm1; q[(H + k) * L2] = d[k] * a.norm2; }
+    }
+    tail3_barrier();
+    // ---- rows: lines along dim 2 at (i, k) = (u, v) ----
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u + v * L2;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = q[(2 * k) * L1]; d[k] = q[(2 * k + 1) * L1]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[k * L1] = s[k] * a.norm1; q[(H + k) * L1] = d[k] * a.norm2; }
+    }
+    tail3_barrier();
+    // ---- columns: lines along dim 1 at (j, k) = (u, v) ----
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u * L1 + v * L2;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = q[2 * k]; d[k] = q[2 * k + 1]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[k] = s[k] * a.norm1; q[H + k] = d[k] * a.norm2; }
+    }
+    tail3_barrier();
+    // the seven detail octants are final (the approximation octant too after the last level): lanes along dim 1
+    for (int idx = tid; idx < M * M * M; idx += nthr) {
+        const int i = idx % M, j = (idx / M) % M, k = idx / (M * M);
+        if (last || i >= H || j >= H || k >= H) a.y[i + (int64_t)j * a.y1 + (int64_t)k * a.y2] = P[i + j * L1 + k * L2];
+    }
+}
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail3_fwd_from(T *P, const LiftTail3Args<T> &a, int m0, int nlev, int tid, int nthr)
+{
+    if (m0 == M) {
+        tail3_fwd_level<T, ID, M, MM>(P, a, nlev == 1, tid, nthr);
+        if constexpr (M >= 4) {
+            if (nlev > 1) tail3_fwd_from<T, ID, M / 2, MM>(P, a, M / 2, nlev - 1, tid, nthr);
+        }
+    } else {
+        if constexpr (M >= 4) tail3_fwd_from<T, ID, M / 2, MM>(P, a, m0, nlev, tid, nthr);
+    }
+}
+// one inverse level with output M^3 in P (normalize -> steps -> merge per line; columns, rows, planes)
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail3_inv_level(T *P, const LiftTail3Args<T> &a, int tid)
+{
+    constexpr int H = M / 2, L1 = MM + 1, L2 = (MM + 1) * MM;
+    const int u = tid % M, v = tid / M;
+    const bool act = tid < M * M;
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u * L1 + v * L2;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * q[k]; d[k] = a.norm2 * q[H + k]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[2 * k] = s[k]; q[2 * k + 1] = d[k]; }
+    }
+    tail3_barrier();
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u + v * L2;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * q[k * L1]; d[k] = a.norm2 * q[(H + k) * L1]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[(2 * k) * L1] = s[k]; q[(2 * k + 1) * L1] = d[k]; }
+    }
+    tail3_barrier();
+    if (act) {
+        T s[H], d[H];
+        T *q = P + u + v * L1;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * q[k * L2]; d[k] = a.norm2 * q[(H + k) * L2]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[(2 * k) * L2] = s[k]; q[(2 * k + 1) * L2] = d[k]; }
+    }
+    tail3_barrier();
+}
+// levels with outputs m0 >> (nlev-1), ..., m0 (smallest first)
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail3_inv_upto(T *P, const LiftTail3Args<T> &a, int m0, int nlev, int tid)
+{
+    if constexpr (M >= 4) tail3_inv_upto<T, ID, M / 2, MM>(P, a, m0, nlev, tid);
+    if (M <= m0 && M >= (m0 >> (nlev - 1))) tail3_inv_level<T, ID, M, MM>(P, a, tid);
+}
+
+template <typename T, int ID, int FW, int MM>
+__global__ void __launch_bounds__(1024) k_tail_lift3d(LiftTail3Args<T> a)
+{
+    constexpr int L1 = MM + 1, L2 = (MM + 1) * MM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int m0 = a.m0, lg = 31 - __clz(m0);
+    for (int idx = tid; idx < m0 * m0 * m0; idx += nthr) {
+        const int i = idx & (m0 - 1), j = (idx >> lg) & (m0 - 1), k = idx >> (2 * lg);
+        P[i + j * L1 + k * L2] = a.src[i + (int64_t)j * a.s1 + (int64_t)k * a.s2];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (FW) {
+        tail3_fwd_from<T, ID, MM, MM>(P, a, m0, a.nlev, tid, nthr);
+    } else {
+        tail3_inv_upto<T, ID, MM, MM>(P, a, m0, a.nlev, tid);
+        for (int idx = tid; idx < m0 * m0 * m0; idx += nthr) {
+            const int i = idx & (m0 - 1), j = (idx >> lg) & (m0 - 1), k = idx >> (2 * lg);
+            a.y[i + (int64_t)j * a.y1 + (int64_t)k * a.y2] = P[i + j * L1 + k * L2];
+        }
+    }
+}
+template <typename T> constexpr int tail3_max() { return sizeof(T) == 4 ? 32 : 16; }
+template <typename T>
+static bool tail_lift3d_ok(int id, int64_t n) { return id >= 0 && id <= 5 && n >= 2 && n <= tail3_max<T>() && (n & (n - 1)) == 0; }
+template <typename T, int ID, int FW>
+static hipError_t launch_tail_lift3d_id(hipStream_t st, const LiftTail3Args<T> &a)
+{
+    constexpr int MM = tail3_max<T>();
+    const size_t shmem = (size_t)(MM + 1) * MM * MM * sizeof(T);
+    static thread_local int attr_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool done = false;
+    for (int i = 0; i < 8; ++i) done = done || attr_dev[i] == dev;
+    if (!done && shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift3d<T, ID, FW, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        for (int i = 0; i < 8; ++i) if (attr_dev[i] < 0) { attr_dev[i] = dev; break; }
+    }
+    const int lines = a.m0 * a.m0;
+    const int threads = lines >= 1024 ? 1024 : (lines >= 256 ? 256 : 64);
+    hipLaunchKernelGGL((k_tail_lift3d<T, ID, FW, MM>), dim3(1), dim3(threads), shmem, st, a);
+    return hipGetLastError();
+}
+template <typename T, int FW>
+static hipError_t launch_tail_lift3d(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t s1, int64_t s2, T *y, int64_t y1,
+                                     int64_t y2, int m0, int nlev)
+{
+    LiftTail3Args<T> a;
+    a.src = src; a.s1 = s1; a.s2 = s2; a.y = y; a.y1 = y1; a.y2 = y2; a.m0 = m0; a.nlev = nlev;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    if (FW) {
+        if (id == 0) return launch_tail_lift3d_id<T, 0, 1>(st, a);
+        if (id == 2) return launch_tail_lift3d_id<T, 2, 1>(st, a);
+        return launch_tail_lift3d_id<T, 4, 1>(st, a);
+    }
+    if (id == 1) return launch_tail_lift3d_id<T, 1, 0>(st, a);
+    if (id == 3) return launch_tail_lift3d_id<T, 3, 0>(st, a);
+    return launch_tail_lift3d_id<T, 5, 0>(st, a);
+}
+
+// --------------------------------------------------------------------------------------------------
 // One 2-D lifting level of a block of ANY even size in one launch (known scheme shapes): the levels the streaming / register
 // kernels decline (sizes that are not multiples of 8, small non-power-of-two blocks: 1000 x 1000 and its 500, 250 levels)
 // ran as twelve one-thread-per-element launches per level.  One WAVE per tile: 64 x 64 samples of the block incl. a halo of
@@ -2798,6 +2985,11 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             const bool last = (l == L);
             T *llbuf = pp ? w.B : w.A;
+            // every remaining level inside one workgroup's LDS (k_tail_lift3d)
+            if ((id == 0 || id == 2 || id == 4) && tail_lift3d_ok<T>(id, n) && l_env("WL_LIFT_TAIL3D", 1) != 0) {
+                WL_E((launch_tail_lift3d<T, 1>(id, st, sc, cur, c1, c2, y, y1, y2, (int)n, L - l + 1)));
+                break;
+            }
             // planes (dim 3): the cube is an (n*n) x n matrix when its first two dims are dense
             if (c1 == n) {
                 ax.src = cur; ax.lds = c2; ax.bs_src = 0; ax.dst = w.T0; ax.ldd = n * n; ax.bs_dst = 0; ax.R = n * n; ax.C = n;
@@ -2833,7 +3025,18 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
     } else {
         const T *llsrc = nullptr;
         int pp = 0;
-        for (int l = L; l >= 1; --l) {
+        int l_top = L;
+        // the deepest levels (outputs of <= 32^3 Float32 / 16^3 Float64) inside one workgroup's LDS (k_tail_lift3d)
+        if ((id == 1 || id == 3 || id == 5) && l_env("WL_LIFT_TAIL3D", 1) != 0 && tail_lift3d_ok<T>(id, n0 >> (L - 1))) {
+            int lt = L;
+            while (lt > 1 && tail_lift3d_ok<T>(id, n0 >> (lt - 2))) --lt;
+            const int64_t m0 = n0 >> (lt - 1);
+            T *out = (lt == 1) ? y : (pp ? w.B : w.A);
+            WL_E((launch_tail_lift3d<T, 0>(id, st, sc, x, y1, y2, out, (lt == 1) ? y1 : m0, (lt == 1) ? y2 : m0 * m0, (int)m0, L - lt + 1)));
+            llsrc = out; pp ^= 1;
+            l_top = lt - 1;
+        }
+        for (int l = l_top; l >= 1; --l) {
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             bool planes = false;

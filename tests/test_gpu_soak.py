@@ -91,6 +91,16 @@ def test_soak_inv2d_pair(gpu, W):
     _soak_shape(torch, W, (8192, 8192), torch.float32, "db4", 2, "k_inv2d_pair", inverse=True, nlaunch=3000)
 
 
+@pytest.mark.parametrize("wname,dtype,nlaunch", [("sym8", "float32", 2000), ("sym5", "float32", 3000), ("db4", "float64", 1500)])
+def test_soak_inv2d_lds_long(gpu, W, wname, dtype, nlaunch):
+    """k_inv2d_lds_long (round 4; compiler-placed loads requested 2-3 steps ahead, LDS exchange with alternating buffers and one
+    barrier per step): one 8192^2 level of 16 / 10 taps, 4096^2 in Float64"""
+    import torch
+    dt = getattr(torch, dtype)
+    shape = (8192, 8192) if dtype == "float32" else (4096, 4096)
+    _soak_shape(torch, W, shape, dt, wname, 1, "k_inv2d_lds_long", inverse=True, nlaunch=nlaunch)
+
+
 def test_soak_ti_denoise_batch(gpu, W):
     """the plane-batched (BT) instances of the pair / level kernels: a translation-invariant denoise of 2048^2, 4 x 4 spins"""
     import torch

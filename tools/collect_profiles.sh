@@ -17,7 +17,7 @@ done
 for c in c3 c2 c4 c5; do
   $REPO/tools/rp.sh $O/stats_$c $R "--kernel-trace --stats" python $REPO/bench.py --workload $c --no-cpu --no-secondary --no-c5 --no-pipelined --steps 50 --warmup 3
 done
-for k in idwt2d lift2d lift2d_inv dwt3d modwt denoise dwt2d_f64 dwt2d_db8 wpt batch2d; do
+for k in idwt2d idwt2d_sym8 idwt2d_sym5 idwt2d_f64 lift2d lift2d_inv lift3d dwt3d modwt denoise dwt2d_f64 dwt2d_db8 wpt batch2d; do
   $REPO/tools/rp.sh $O/stats_$k $R "--kernel-trace --stats" python $REPO/tools/run_case.py $k 20
 done
 # PMC: the first launch of the headline transform (an L = 2 call = exactly that kernel: levels 1-2 fused), torch-free harness

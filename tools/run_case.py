@@ -34,6 +34,16 @@ elif case == "dwt2d_db8":
     y = W.similar(x)
     db8 = W.wavelet(W.WT.db8)
     fn = lambda: W.dwt_oop_(y, x, db8, 13)
+elif case in ("idwt2d_sym8", "idwt2d_sym5"):      # k_inv2d_lds_long: 16 taps / 10 taps (the default wavelet of denoise)
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    wt = W.wavelet(W.WT.sym8 if case.endswith("sym8") else W.WT.sym5)
+    fn = lambda: W.idwt_oop_(y, x, wt, 13)
+elif case == "lift3d":
+    x = torch.randn(256, 256, 256, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
+    y = W.similar(x)
+    sch = W.wavelet(W.WT.cdf97, W.WT.Lifting)
+    fn = lambda: W.dwt_oop_(y, x, sch, 8)
 elif case == "idwt2d_f64":
     x = torch.randn(8192, 8192, generator=g, dtype=torch.float64).cuda().t()
     y = W.similar(x)

@@ -21,7 +21,8 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
-for k in ("c2", "c3", "c4", "c5", "idwt2d", "lift2d", "lift2d_inv", "dwt3d", "modwt", "denoise", "dwt2d_f64", "dwt2d_db8", "wpt", "batch2d"):
+for k in ("c2", "c3", "c4", "c5", "idwt2d", "idwt2d_sym8", "idwt2d_sym5", "idwt2d_f64", "lift2d", "lift2d_inv", "lift3d", "dwt3d", "modwt", "denoise",
+          "dwt2d_f64", "dwt2d_db8", "wpt", "batch2d"):
     p = find(f"stats_{k}", "*kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(DST, f"{R}_{k}_kernel_stats.csv"))

@@ -189,39 +189,25 @@ cdf97 = CDF(9, 7)
 
 # ---- Daubechies filters (wt_main.jl:271-361) -----------------------------------------------
 def daubechies(N: int) -> np.ndarray:
-    """Scaling filter of the Daubechies wavelet with N vanishing moments (2N taps, unit
-    2-norm).  Same construction as the reference: the N-1 roots y_i of the truncated
-    binomial series sum_n C(N-1+n, n) y^n, mapped to z + 1/z = 2 - 4y, keep |z| <= 1, and
-    expand (1+z)^N prod_i (z - z_i)."""
-    assert N > 0
-    C = np.array([comb(N - 1 + n, n) for n in range(N - 1, -1, -1)], dtype=np.float64)  # highest power first
-    if N > 1:
-        A = np.zeros((N - 1, N - 1))
-        A[0, :] = -C[1:] / C[0]
-        for i in range(1, N - 1):
-            A[i, i - 1] = 1.0
-        Y = np.linalg.eigvals(A).astype(np.complex128)
+    """Scaling filter of the Daubechies wavelet with N vanishing moments (2N taps, unit 2-norm), by spectral factorisation --
+    the construction the reference uses (wt_main.jl:271-361), so that the taps agree with it to rounding:
+    |H(w)|^2 = cos^2N(w/2) P(sin^2(w/2)) with P(y) = sum_{n<N} C(N-1+n, n) y^n; every root y of P gives a reciprocal pair of
+    zeros z, 1/z through z + 1/z = 2 - 4y; the minimum-phase filter keeps the zeros inside the unit circle next to the N-fold
+    zero at z = -1."""
+    if N < 1:
+        raise AssertionError("N > 0")
+    eps = np.finfo(np.float64).eps
+    if N == 1:
+        inside = np.empty(0, dtype=np.complex128)
     else:
-        Y = np.zeros(0, dtype=np.complex128)
-    Z = np.zeros(2 * N - 2, dtype=np.complex128)
-    for i in range(N - 1):
-        Yi = Y[i]
-        d = 2 * np.sqrt(Yi * Yi - Yi)
-        y2 = 1 - 2 * Yi
-        Z[i] = y2 + d
-        Z[i + N - 1] = y2 - d
-    R = [-1.0 + 0j] * N + [z for z in Z if abs(z) <= 1 + np.finfo(float).eps]
-    # Vieta: coefficients of prod (z - r_k), highest power first
-    Cc = np.zeros(len(R) + 1, dtype=np.complex128)
-    Cc[0] = 1
-    for k in range(len(R)):
-        Ci = Cc[0]
-        for i in range(k + 1):
-            Cig = Cc[i + 1]
-            Cc[i + 1] = Cig - R[k] * Ci
-            Ci = Cig
-    HH = Cc * (1 / np.linalg.norm(Cc))
-    return np.real(HH).astype(np.float64)
+        series = [comb(N - 1 + n, n) for n in range(N)]                  # P, ascending powers of y
+        y = np.roots(np.array(series[::-1], dtype=np.float64)).astype(np.complex128)
+        centre, radius = 1 - 2 * y, 2 * np.sqrt(y * y - y)              # z = centre +- radius solves z + 1/z = 2 - 4y
+        pairs = np.concatenate([centre + radius, centre - radius])
+        inside = pairs[np.abs(pairs) <= 1 + eps]
+    zeros = np.concatenate([np.full(N, -1.0 + 0j), inside])
+    h = np.real(np.poly(zeros))                                          # monic polynomial with these zeros, highest power first
+    return (h / np.linalg.norm(h)).astype(np.float64)
 
 
 # ---- OrthoFilter (wt_main.jl:139-163) --------------------------------------------------------

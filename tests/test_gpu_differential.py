@@ -154,3 +154,70 @@ def test_wpt_fast_tiers_against_per_depth_kernels(gpu, W, seed):
         W.clear_options()
         assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), (n, dt, lifting, type(tree), it)
     assert {"k_wpt_fwd_multi", "k_wpt_fwd_tail", "k_wpt_inv_tail", "k_wpt_inv_multi"} <= hits, hits
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_inverse_lds_exchange_level_against_the_tiers_it_replaces(gpu, W, seed):
+    """k_inv2d_lds_long (wl_inv2d_long.hip) against the two-pass long-filter tier / the DPP streaming kernel: random row counts
+    (multiples of 256), column counts (any even number that fits the reach), depths, strip widths, chunk lengths, request
+    distances, both element types, single images and batches of planes."""
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(300 + seed)
+    hit = 0
+    names = ["db4", "sym5", "db6", "sym7", "db8", "coif4", "db9", "coif6", "db10", "beyl"]
+    for it in range(48):
+        n0 = 256 * int(r.integers(1, 9))
+        n1 = 2 * int(r.integers(16, 600))
+        dt = torch.float32 if r.random() < 0.65 else torch.float64
+        wt = W.wavelet(getattr(W.WT, str(r.choice(names))))
+        nb = int(r.choice([0, 0, 2, 5]))                      # 0: a single image
+        if n0 * n1 * max(nb, 1) > (1 << 22):
+            n1 = 2 * int(r.integers(16, 64))
+        if nb:
+            x = torch.randn(nb, n1, n0, generator=gen, dtype=dt).cuda().permute(2, 1, 0)
+        else:
+            x = _rnd(torch, gen, (n0, n1), dt)
+        Lmax = min(W.maxtransformlevels(x[:, :, 0] if nb else x), 4)
+        if Lmax < 1:
+            continue
+        L = int(r.integers(1, Lmax + 1))
+        out = []
+        for on in (0, 1):
+            W.clear_options()
+            W.set_option("WL_INVLONG2D", on)
+            W.set_option("WL_INVLONG2D_MIN_ROWS", 256)
+            W.set_option("WL_INVLONG_SHORT_MIN", 0)
+            W.set_option("WL_INVLONG_FMIN", 8)
+            W.set_option("WL_INV_PAIR", 0)
+            W.set_option("WL_TILE_INV", 0)
+            W.set_option("WL_INVLONG_W", int(r.choice([0, 1, 2, 4])))
+            W.set_option("WL_INVLONG_TP", int(r.choice([8, 12, 16, 24, 40, 64, 128])))
+            W.set_option("WL_INVLONG_D", int(r.choice([1, 2, 3, 4])))
+            W.set_option("WL_INVLONG_WAVES_PER_CU", int(r.choice([0, 8])))
+            out.append(W.idwt_batch(x, wt, L) if nb else W.idwt(x, wt, L))
+            hit += int(on and W.last_kernel() == "k_inv2d_lds_long")
+        W.clear_options()
+        assert torch.equal(out[0], out[1]), (n0, n1, nb, L, str(dt), wt.name)
+    assert hit >= 15            # (the comparison must not be vacuous)
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_lifting_3d_lds_tail_against_per_axis_launches(gpu, W, seed):
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(400 + seed)
+    for it in range(40):
+        n = int(r.choice([8, 16, 32, 64, 128]))
+        dt = torch.float32 if r.random() < 0.6 else torch.float64
+        sch = W.wavelet(getattr(W.WT, str(r.choice(["cdf97", "db2", "haar"]))), W.WT.Lifting)
+        x = torch.randn(n, n, n, generator=gen, dtype=dt).cuda().permute(2, 1, 0)
+        L = int(r.integers(1, W.maxtransformlevels(x) + 1))
+        ys, xs = [], []
+        for on in (0, 1):
+            W.set_option("WL_LIFT_TAIL3D", on)
+            y = W.dwt(x, sch, L)
+            ys.append(y)
+            xs.append(W.idwt(y, sch, L))
+        W.clear_options()
+        assert torch.equal(ys[0], ys[1]) and torch.equal(xs[0], xs[1]), (n, L, str(dt), sch.name)

@@ -773,6 +773,24 @@ def test_randomized_shapes_near_dispatch_thresholds(gpu, W, oracle):
         assert np.array_equal(host(W, W.idwtc(dev(W, ye), wt, L)), oracle.dwtc_filter(ye, wt.qmf, L, fw=False))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_multi_level_line_kernel_every_depth_per_launch(gpu, W, oracle, dtype):
+    """k_fwd1d_multi: 1 ... 8 levels per launch (round 4 raised the cap for lines of a few MiB from 6 to 8: the halo
+    (F-2)(2^NL - 1) then exceeds the tile), every filter length of the fast family, tile lengths from 1 KiB up, lines from 2^13
+    to 2^20 -- bit for bit against the oracle."""
+    for n, Ls in ((1 << 13, (1, 5, 13)), (1 << 16, (8, 16)), (1 << 18, (3, 18)), (1 << 20, (8, 20)), (3 << 14, (6, 14))):
+        x = rng_array((n,), dtype, n % 1000 + 3)
+        for fname in ("haar", "db2", "db3", "db4", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                for per, ts in ((8, 0), (7, 0), (5, 2048), (3, 1024), (1, 0), (8, 256)):
+                    with W.options(WL_NL_SMALL_MAX=per, WL_NLMAX=per, WL_TS=ts):
+                        y = host(W, W.dwt(dev(W, x), wt, L))
+                        assert W.last_kernel() in ("k_fwd1d_multi", "k_tail2_fwd", "k_tail_fwd"), W.last_kernel()
+                        assert np.array_equal(y, ye), (n, fname, L, per, ts, int((y != ye).sum()))
+
+
 # ---- lifting ----------------------------------------------------------------------------------------
 LSHAPES = [(2,), (4,), (8,), (40,), (1024,), (1 << 15,), (2, 2), (8, 8), (32, 32), (96, 96), (256, 256), (512, 512), (1024, 1024), (576, 576),
            (4, 4, 4), (8, 8, 8), (16, 16, 16), (24, 24, 24), (32, 32, 32), (64, 64, 64)]

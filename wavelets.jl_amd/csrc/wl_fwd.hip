@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256) k_fwd1d_stream(Fwd1DArgs<T, F> a)
 
 
 // ==========================================================================================
-// 1-D multi-level tile kernel: NL (<= 6) consecutive levels of a line in ONE pass over HBM.
+// 1-D multi-level tile kernel: NL (<= 8; 4 on lines that do not fit L2) consecutive levels of a line in ONE pass over HBM.
 // A workgroup owns TS input samples, loads them plus a halo of H0 = (F-2)(2^NL - 1) samples on
 // each side into LDS (periodic wrap resolved while staging), then runs the levels LDS -> LDS:
 // at level t the local array covers the owned range widened by H_t = (F-2)(2^(NL-t) - 1), so pair i
@@ -534,7 +534,7 @@ struct Multi1DArgs {
 
 // the NL levels of one staged tile, LDS -> LDS (bufA holds the tile + halo); ends with a barrier after the last level
 template <typename T, int F>
-__device__ __forceinline__ void multi1d_levels(const Multi1DArgs<T, F> &a, const int (&H)[8], const int64_t own0, const int own_len,
+__device__ __forceinline__ void multi1d_levels(const Multi1DArgs<T, F> &a, const int (&H)[10], const int64_t own0, const int own_len,
                                                T *bufA, T *bufB, T *y)
 {
     constexpr int VEC = 16 / sizeof(T);
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
     const int tid = threadIdx.x;
     const int64_t n = a.n;
     const int NL = a.NL;
-    int H[8];
+    int H[10];
     H[NL] = 0;
     for (int t = NL; t >= 1; --t) H[t - 1] = 2 * H[t] + (F - 2);
     const int64_t own0 = (int64_t)blockIdx.x * a.TS;
@@ -1435,7 +1435,7 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             (nlines == 1 || ((cur_st.s[1] % VEC) == 0 && (b.full.s[1] % VEC) == 0))) {
             int NL = L - l + 1;
             // big stages are bandwidth-bound: 4 levels keep the halo (F-2)(2^NL - 1) small; small stages are launch-latency
-            // bound: up to 6 levels per launch saves whole launches (1-D db2 2^20 f64: 23.8 -> 17.3 us)
+            // bound: up to 8 levels per launch saves whole launches (1-D db2 2^20 f64: 23.8 -> 17.3 us with 6, 15.9 with 8)
             int nl_auto = 4;
             if (n[0] * nlines < ((int64_t)1 << 22)) {
                 // levels left before the one-workgroup tail can take the line: split them evenly over the fewest launches
@@ -1445,7 +1445,12 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 int r = lg_n - lg_cap;
                 if (r > L - l + 1) r = L - l + 1;
                 if (r < 1) r = 1;
-                const int stages = (r + 5) / 6;
+                // (up to 8 levels per launch: the halo (F-2)(2^NL - 1) is then a multiple of the tile, but these lines are a few MiB
+                //  in L2 and a launch saved is ~1 us net -- r04: 2^20 db4 19.0 -> 18.0 us, L = 8: 12.4 -> 11.3)
+                int per = env_int("WL_NL_SMALL_MAX", 8);
+                if (per < 1) per = 1;
+                if (per > 8) per = 8;
+                const int stages = (r + per - 1) / per;
                 nl_auto = (r + stages - 1) / stages;
             }
             const int nlmax = env_int("WL_NLMAX", nl_auto);

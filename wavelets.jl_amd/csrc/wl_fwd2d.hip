@@ -40,6 +40,7 @@ struct Lds2DArgs {
     int nload;                        // lanes that load input rows (npl + halo lanes, <= blockDim)
     int rev;
     int helper;                       // 1: the workgroup's last wave only supplies halo rows (exact tiling)
+    int prio;                         // 1: the helper wave issues ahead of the main waves (s_setprio; see wl_pair2d.hip)
     int64_t bs_src, bs_y, bs_ll; int nll;    // batch of independent blocks over blockIdx.y (planes of a 3-D level)
     int src_mod; int64_t spin0;       // > 0: plane p reads copy (spin0 + p) % src_mod with its columns rotated by (spin0 + p) / src_mod (SrcView)
     int th; double t_unit, sigma_host; const double *mad_dev;     // TH instances: threshold the details at the store (SrcView)
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds(Lds2DArgs<F> a)
     const bool loader = lp < a.nload;
     // exact tiling: the last wave is the halo helper (wave-uniform, kept in an SGPR)
     const bool helper = a.helper && (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == (nthreads >> 6) - 1);
+    if (a.prio && helper) __builtin_amdgcn_s_setprio(2);
     const bool own = (lp < a.npl) && (gi < msi);
     const int ko = gi >> 1;
     int kod = ko + 4;  if (kod >= hmi) kod -= hmi;                           // first d row of this lane
@@ -336,6 +338,7 @@ static hipError_t launch_lds_f(hipStream_t st, const Taps<float> &taps, bool lvl
     a.bs_src = bs_src; a.bs_y = bs_y; a.bs_ll = bs_ll; a.nll = nll; a.src_mod = src_mod; a.spin0 = spin0;
     const Shape2D sh = pick_shape(ms, (int)opt("WL_LDS_MODE", 0), (int)opt("WL_LDS_W", 4));
     a.npl = sh.npl; a.nload = sh.nload; a.nstrips = sh.nstrips; a.helper = sh.helper;
+    a.prio = opt("WL_LDS_PRIO", 1) != 0 ? 1 : 0;
     int TJ = (int)opt("WL_TJ", 128);
     if (TJ < 16 || (TJ % 16) != 0) TJ = 128;              // (a test knob must not be able to divide by zero)
     auto nwaves = [&](int tj) { return (int64_t)a.nstrips * sh.nw * ((ns + tj - 1) / tj) * nbatch; };

@@ -1131,6 +1131,148 @@ static hipError_t launch_tail_lift2d_reg(int id, hipStream_t st, const LiftSchem
 }
 
 // --------------------------------------------------------------------------------------------------
+// LDS tail for 2-D lifting, a thread per line, several waves (round 4): every remaining level of a power-of-two block of
+// <= 128 x 128 (Float32; 64 x 64 Float64) in one workgroup.  Same scheme as the register tail above -- a thread holds a whole
+// row / column in registers, straight-line steps with compile-time wrap and summation forms -- but the block is staged, and
+// its details stored, by 256 threads, and a 128-sample line is two waves' worth of threads: the 128 x 128 level no longer
+// needs a tile launch of its own (8192^2 cdf9/7: 128^2 tile 9.7 us + 64^2 register tail 13.5 us -> one launch).
+__device__ __forceinline__ void tail2l_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail2l_fwd_level(T *P, const LiftTailRegArgs<T> &a, bool last, int tid, int nthr)
+{
+    constexpr int H = M / 2, LD = MM + 1;
+    if (tid < M) {                                   // rows (dim 2): the line of row tid runs along the columns
+        T s[H], d[H];
+        T *q = P + tid;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = q[(2 * k) * LD]; d[k] = q[(2 * k + 1) * LD]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[k * LD] = s[k] * a.norm1; q[(H + k) * LD] = d[k] * a.norm2; }
+    }
+    tail2l_barrier();
+    if (tid < M) {                                   // columns (dim 1)
+        T s[H], d[H];
+        T *q = P + tid * LD;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = q[2 * k]; d[k] = q[2 * k + 1]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[k] = s[k] * a.norm1; q[H + k] = d[k] * a.norm2; }
+    }
+    tail2l_barrier();
+    for (int idx = tid; idx < M * M; idx += nthr) {
+        const int i = idx % M, j = idx / M;
+        if (last || i >= H || j >= H) a.y[i + (int64_t)j * a.ldy] = P[i + j * LD];
+    }
+}
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail2l_fwd_from(T *P, const LiftTailRegArgs<T> &a, int m0, int nlev, int tid, int nthr)
+{
+    if (m0 == M) {
+        tail2l_fwd_level<T, ID, M, MM>(P, a, nlev == 1, tid, nthr);
+        if constexpr (M >= 4) {
+            if (nlev > 1) tail2l_fwd_from<T, ID, M / 2, MM>(P, a, M / 2, nlev - 1, tid, nthr);
+        }
+    } else {
+        if constexpr (M >= 4) tail2l_fwd_from<T, ID, M / 2, MM>(P, a, m0, nlev, tid, nthr);
+    }
+}
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail2l_inv_level(T *P, const LiftTailRegArgs<T> &a, int tid)
+{
+    constexpr int H = M / 2, LD = MM + 1;
+    if (tid < M) {                                   // columns (dim 1) first
+        T s[H], d[H];
+        T *q = P + tid * LD;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * q[k]; d[k] = a.norm2 * q[H + k]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[2 * k] = s[k]; q[2 * k + 1] = d[k]; }
+    }
+    tail2l_barrier();
+    if (tid < M) {                                   // rows (dim 2)
+        T s[H], d[H];
+        T *q = P + tid;
+#pragma unroll
+        for (int k = 0; k < H; ++k) { s[k] = a.norm1 * q[k * LD]; d[k] = a.norm2 * q[(H + k) * LD]; }
+        reg_line_steps<T, ID, H>(s, d, a.c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) { q[(2 * k) * LD] = s[k]; q[(2 * k + 1) * LD] = d[k]; }
+    }
+    tail2l_barrier();
+}
+template <typename T, int ID, int M, int MM>
+__device__ __forceinline__ void tail2l_inv_upto(T *P, const LiftTailRegArgs<T> &a, int m0, int nlev, int tid)
+{
+    if constexpr (M >= 4) tail2l_inv_upto<T, ID, M / 2, MM>(P, a, m0, nlev, tid);
+    if (M <= m0 && M >= (m0 >> (nlev - 1))) tail2l_inv_level<T, ID, M, MM>(P, a, tid);
+}
+template <typename T, int ID, int FW, int MM>
+__global__ void __launch_bounds__(256) k_tail_lift2d_lds(LiftTailRegArgs<T> a)
+{
+    constexpr int LD = MM + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int m0 = a.m0, lg = 31 - __clz(m0);
+    for (int idx = tid; idx < m0 * m0; idx += nthr) {
+        const int i = idx & (m0 - 1), j = idx >> lg;
+        P[i + j * LD] = a.src[i + (int64_t)j * a.lds];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (FW) {
+        tail2l_fwd_from<T, ID, MM, MM>(P, a, m0, a.nlev, tid, nthr);
+    } else {
+        tail2l_inv_upto<T, ID, MM, MM>(P, a, m0, a.nlev, tid);
+        for (int idx = tid; idx < m0 * m0; idx += nthr) {
+            const int i = idx & (m0 - 1), j = idx >> lg;
+            a.y[i + (int64_t)j * a.ldy] = P[i + j * LD];
+        }
+    }
+}
+template <typename T> constexpr int tail2l_max() { return sizeof(T) == 4 ? 128 : 64; }
+template <typename T>
+static bool tail_lift2d_lds_ok(int id, int64_t n) { return id >= 0 && id <= 5 && n >= 2 && n <= tail2l_max<T>() && (n & (n - 1)) == 0; }
+template <typename T, int ID, int FW>
+static hipError_t launch_tail_lift2d_lds_id(hipStream_t st, const LiftTailRegArgs<T> &a)
+{
+    constexpr int MM = tail2l_max<T>();
+    const size_t shmem = (size_t)(MM + 1) * MM * sizeof(T);
+    static thread_local int attr_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool done = false;
+    for (int i = 0; i < 8; ++i) done = done || attr_dev[i] == dev;
+    if (!done && shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_lift2d_lds<T, ID, FW, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        for (int i = 0; i < 8; ++i) if (attr_dev[i] < 0) { attr_dev[i] = dev; break; }
+    }
+    hipLaunchKernelGGL((k_tail_lift2d_lds<T, ID, FW, MM>), dim3(1), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+template <typename T, int FW>
+static hipError_t launch_tail_lift2d_lds(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy,
+                                         int n0, int nlev)
+{
+    LiftTailRegArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.m0 = n0; a.nlev = nlev;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    if (FW) {
+        if (id == 0) return launch_tail_lift2d_lds_id<T, 0, 1>(st, a);
+        if (id == 2) return launch_tail_lift2d_lds_id<T, 2, 1>(st, a);
+        return launch_tail_lift2d_lds_id<T, 4, 1>(st, a);
+    }
+    if (id == 1) return launch_tail_lift2d_lds_id<T, 1, 0>(st, a);
+    if (id == 3) return launch_tail_lift2d_lds_id<T, 3, 0>(st, a);
+    return launch_tail_lift2d_lds_id<T, 5, 0>(st, a);
+}
+
+// --------------------------------------------------------------------------------------------------
 // LDS tail for 3-D lifting (round 4): every remaining level of a power-of-two cube of <= MM^3 (32^3 Float32 = 132 KiB of LDS,
 // 16^3 Float64) in ONE workgroup.  As in the 2-D register tail a thread owns a whole line of the current pass and keeps it in
 // registers (s[H], d[H]: compile-time indices, the periodic wrap and the reference's two summation forms decided per element
@@ -2784,7 +2926,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     Strides3 full = {{1, ldy, ldy * n0}};
     auto lines_ok = [](int64_t n) { return n >= 512 && (n % 64) == 0; };
     auto fused_ok = [](int64_t n) { return n >= 128 && (n % 8) == 0; };     // k_lift2d_*: a lane's 4 rows wrap at most once
-    bool any_fast = false, fused = false, gtile = false, tiled = false;
+    bool any_fast = false, fused = false, gtile = false, tiled = false, ldstail = false;
 
     if (fw) {
         const T *cur = x;
@@ -2796,6 +2938,15 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             T *llbuf = pp ? w.B : w.A;
             T *lld = last ? y : llbuf;
             const int64_t ldd = last ? ldy : h;
+            // every remaining level of a block <= 128 x 128 (Float32) in one workgroup's LDS, a thread per line (k_tail_lift2d_lds)
+            // (measured r04, cdf9/7 forward: 64^2 all levels 11.2 us against 13.5 in the one-wave register tail; 128^2 24.4 against
+            //  23.3 for a tile launch + the register tail -- a 128-sample line per thread keeps two waves busy, the tile kernel 16)
+            if ((id == 0 || id == 2 || id == 4) && tail_lift2d_lds_ok<T>(id, n) && n >= l_env("WL_LIFT_LDSTAIL2D_FMIN", 64) &&
+                n <= l_env("WL_LIFT_LDSTAIL2D_FMAX", 64) && l_env("WL_NO_LIFT_TAIL2D", 0) == 0 && l_env("WL_LIFT_LDSTAIL2D", 1) != 0) {
+                WL_E((launch_tail_lift2d_lds<T, 1>(id, st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
+                any_fast = true; ldstail = (l == 1);          // (names the call only when the tail is the whole transform)
+                break;
+            }
             if (n <= 64 && l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {        // every remaining level inside one workgroup / one wave
                 if ((id == 0 || id == 2 || id == 4) && tail_lift2d_reg_ok<T>(id, (int)n) && l_env("WL_LIFT_REGTAIL2D", 1) != 0)
                     WL_E((launch_tail_lift2d_reg<T, 1>(id, st, sc, cur, cur_ls, y, ldy, (int)n, L - l + 1)));
@@ -2873,11 +3024,19 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
         if (l_env("WL_NO_LIFT_TAIL2D", 0) == 0) {
             int l_lo = L + 1;                       // shallowest level whose output still fits the LDS tail
             while (l_lo > 1 && (n0 >> (l_lo - 2)) <= 64) --l_lo;
+            // ... or, a thread per line in several waves, 128 x 128 (Float32): k_tail_lift2d_lds (inverse 128^2 all levels: 19.1 us
+            //     against 20.9 for the register tail + a tile launch)
+            const bool lds128 = (id == 1 || id == 3 || id == 5) && l_env("WL_LIFT_LDSTAIL2D", 1) != 0 && l_lo >= 2 && l_lo <= L + 1 &&
+                                tail_lift2d_lds_ok<T>(id, n0 >> (l_lo - 2)) && (n0 >> (l_lo - 2)) >= l_env("WL_LIFT_LDSTAIL2D_MIN", 128);
+            if (lds128) --l_lo;
             if (l_lo <= L) {
                 const int64_t n = n0 >> (l_lo - 1);
                 T *out = (l_lo == 1) ? y : (pp ? w.B : w.A);
                 const int64_t ldo = (l_lo == 1) ? ldy : n;
-                if ((id == 1 || id == 3 || id == 5) && tail_lift2d_reg_ok<T>(id, (int)n) && l_env("WL_LIFT_REGTAIL2D", 1) != 0)
+                if (lds128) {
+                    WL_E((launch_tail_lift2d_lds<T, 0>(id, st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
+                    ldstail = (l_lo == 1);
+                } else if ((id == 1 || id == 3 || id == 5) && tail_lift2d_reg_ok<T>(id, (int)n) && l_env("WL_LIFT_REGTAIL2D", 1) != 0)
                     WL_E((launch_tail_lift2d_reg<T, 0>(id, st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
                 else
                     WL_E((launch_tail_lift2d<T, 0>(st, sc, x, ldy, out, ldo, (int)n, L - l_lo + 1)));
@@ -2949,7 +3108,7 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
     }
     *handled = 1;
     if (kernel_name)
-        *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : (tiled ? "k_lift2d_tile" : (gtile ? "k_lift2d_gtile" : "k_lift_axis_stream+lines")))
+        *kernel_name = any_fast ? (fused ? (fw ? "k_lift2d_fwd" : "k_lift2d_inv") : (tiled ? "k_lift2d_tile" : (gtile ? "k_lift2d_gtile" : (ldstail ? "k_tail_lift2d_lds" : "k_lift_axis_stream+lines"))))
                                 : (fw ? "k_generic_lift_fwd" : "k_generic_lift_inv");
     return WL_OK;
 }

@@ -1146,7 +1146,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         T *res = (l == 1) ? y : (pp ? w.B : w.A);
         Strides3 res_st = (l == 1) ? b.full : box_st;
         bool done = false;
-        // the LDS-exchange level kernel (wl_inv2d_long.hip): Float32, output rows a multiple of 256
+        // the LDS-exchange level kernel (wl_inv2d_long.hip: which filter lengths per element type), output rows a multiple of 256
         auto try_lds_long = [&]() -> hipError_t {
             if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 512) && b.full.s[0] == 1 &&
                 inv2d_long_ok(F, n[0], n[1], (int)sizeof(T)) && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
@@ -1284,7 +1284,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             WL_TRYI(e);
             if (done) dominant = kn;
         }
-        // ---- 12..20 taps, Float32, output rows a multiple of 256: the whole 2-D level in one pass (wl_inv2d_long.hip) ----
+        // ---- 12..20 taps, output rows a multiple of 256: the whole 2-D level in one pass (wl_inv2d_long.hip) ----
         if (!done && F >= 12) WL_TRYI(try_lds_long());
         // ---- long filters (12..24 taps) ----
         if (!done && path == 0 && long_filter_ok(F) && i_env("WL_NO_LONGF", 0) == 0 && b.full.s[0] == 1) {

@@ -30,6 +30,7 @@ struct LdsLongArgs {
     int nstrips, nchunks;
     int npl;                          // owned lanes per workgroup (64 W)
     int rev;
+    int prio;                         // wave priorities by role (s_setprio): 1 helper first, 2 main waves first; 0 = none (default)
     TapsF<float, F> tp;
 };
 
@@ -76,6 +77,8 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
     if (row >= msi) row -= msi;
     const bool loader = lp < a.npl + HL;
     const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == (nthreads >> 6) - 1;
+    if (a.prio == 1 && helper) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 2 && !helper) __builtin_amdgcn_s_setprio(2);
     const int ko = gi >> 1;
     int kod = ko + DSH;  if (kod >= hmi) kod -= hmi;  // first d row of this lane
     const bool odd = (lp & 1) != 0;
@@ -232,6 +235,9 @@ static hipError_t launch_long_f(hipStream_t st, const Taps<float> &taps, bool lv
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
+    // (measured r04, 8192^2 level: helper first db8 175 -> 192 us, db10 200 -> 253 -- it shares a SIMD with a main wave and starves
+    //  it; main waves first: neutral.  Unlike the pair kernels, whose helper carries a quarter of a main wave's work.)
+    a.prio = (int)opt("WL_LONG_PRIO", 0);
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     const int nthreads = 64 * (W + 1);

@@ -215,9 +215,9 @@ template <int F>
 static hipError_t launch_long_f(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count)
 {
-    // ring slots: 20 for 12 / 14 taps, 24 above -- fewer VGPRs for the shorter filters (20 slots keep them under
-    // 170 VGPRs = 3 waves per SIMD); the unrolled body covers R / 2 steps, any chunk length (guarded steps)
-    constexpr int R = (F <= 14) ? 20 : 24;
+    // ring slots: 20 up to 16 taps, 24 above -- fewer VGPRs for the shorter filters (20 slots keep them under
+    // 170 VGPRs = 3 waves per SIMD; 16 taps then request two steps ahead instead of four: 175 -> 173 us); the unrolled body covers R / 2 steps, any chunk length (guarded steps)
+    constexpr int R = (F <= 16) ? 20 : 24;
     typedef LongGeom<F> G;
     LdsLongArgs<F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
@@ -227,7 +227,8 @@ static hipError_t launch_long_f(hipStream_t st, const Taps<float> &taps, bool lv
     while (W > 1 && (ms % (256 * W)) != 0) W >>= 1;
     a.npl = 64 * W;
     a.nstrips = (int)(ms / (256 * W));
-    int TJ = (int)opt("WL_LONG_TJ", 128);
+    // (a chunk's ring fill -- R - 2 columns -- is pure overhead: 256 columns where one workgroup per CU remains; r04: db8 175 -> 169 us)
+    int TJ = (int)opt("WL_LONG_TJ", 256);
     if (TJ < 16) TJ = 16;
     TJ &= ~1;
     auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj); };

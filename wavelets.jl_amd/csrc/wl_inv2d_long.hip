@@ -50,6 +50,39 @@ struct InvLongArgs {
     TapsF<T, F> tp;
 };
 
+// window_inv (wl_dev.h) with the detail taps taken from the scaling taps: g[m] = (-1)^m h[m] EXACTLY (make_taps, wl_internal.h), so
+// g[2q] = h[2q] and g[2q + 1] = -h[2q + 1]: the negation is a source modifier of the multiply, and only F instead of 2 F tap values
+// occupy SGPRs (the 16-tap instance reloaded 78 spilled SGPRs per step through v_readlane_b32: 13 % of its VALU instructions)
+template <typename T, int F>
+__device__ __forceinline__ void window_inv_h(const T (&sw)[(F - 2) / 2 + 1], const T (&dw)[(F - 2) / 2 + 1], const TapsF<T, F> &tp, T &xe, T &xo)
+{
+    constexpr int SH = (F - 2) / 2;
+    T Se = tp.h[F - 2] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Se = Se + tp.h[F - 2 - 2 * q] * sw[q];
+    T De = (-tp.h[1]) * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) De = De + (-tp.h[1 + 2 * q]) * dw[q];
+    xe = Se + De;
+    T So = tp.h[F - 1] * sw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) So = So + tp.h[F - 1 - 2 * q] * sw[q];
+    T Do = tp.h[0] * dw[0];
+#pragma unroll
+    for (int q = 1; q <= SH; ++q) Do = Do + tp.h[2 * q] * dw[q];
+    xo = So + Do;
+}
+
+#ifndef WL_INVLONG_HTAPS_MIN
+#define WL_INVLONG_HTAPS_MIN 12          // (10 taps and fewer: nothing spills, and the separate tap table measured 1-3 % ahead)
+#endif
+template <typename T, int F>
+__device__ __forceinline__ void window_inv_sel(const T (&sw)[(F - 2) / 2 + 1], const T (&dw)[(F - 2) / 2 + 1], const TapsF<T, F> &tp, T &xe, T &xo)
+{
+    if constexpr (F >= WL_INVLONG_HTAPS_MIN) window_inv_h<T, F>(sw, dw, tp, xe, xo);
+    else window_inv<T, F>(sw, dw, tp, xe, xo);
+}
+
 // four consecutive samples: 16 bytes per store (one for Float32, two for Float64)
 template <typename T>
 __device__ __forceinline__ void store4(T *p, const T (&v)[4])
@@ -152,7 +185,7 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
             T sw[SH + 1], dw[SH + 1];
 #pragma unroll
             for (int i = 0; i <= SH; ++i) { sw[i] = sv[SHP - SH + p + i]; dw[i] = dv[p + i]; }
-            window_inv<T, F>(sw, dw, a.tp, o[2 * p], o[2 * p + 1]);
+            window_inv_sel<T, F>(sw, dw, a.tp, o[2 * p], o[2 * p + 1]);
         }
     };
     // t: step (from -SH: the first SH steps only fill the rings), s: request slot, u: ring slot of this step's columns
@@ -179,7 +212,7 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
             T sw[SH + 1], dw[SH + 1];
 #pragma unroll
             for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
-            window_inv<T, F>(sw, dw, a.tp, xe[q], xo[q]);
+            window_inv_sel<T, F>(sw, dw, a.tp, xe[q], xo[q]);
         }
         const int64_t p = p0 + t;
         store4<T>(out + (2 * p) * a.ldd, xe);

@@ -272,11 +272,13 @@ static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<T> &taps, const 
                                      T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     // request distance in steps: a step is ~0.3 us of arithmetic, a loaded HBM round trip 1 - 2 us
-    const int D = (int)opt("WL_INVLONG_D", F <= 10 ? 2 : 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
+    int D = (int)opt("WL_INVLONG_D", F <= 10 ? 2 : 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
+    if (sizeof(T) == 8 && D > 3) D = 3;                       // (Float64 with 4 columns in flight spills at 10 / 12 taps)
     if (D <= 1) return launch_inv_long_fwd<T, F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     if (D == 2) return launch_inv_long_fwd<T, F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     if (D == 3) return launch_inv_long_fwd<T, F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
-    return launch_inv_long_fwd<T, F, W, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    if constexpr (sizeof(T) == 4) return launch_inv_long_fwd<T, F, W, 4>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    else return launch_inv_long_fwd<T, F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
 }
 
 template <typename T, int F>

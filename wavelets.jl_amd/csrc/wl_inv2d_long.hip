@@ -98,7 +98,7 @@ __device__ __forceinline__ void store4(T *p, const T (&v)[4])
     }
 }
 
-template <typename T, int F, int W, int D>
+template <typename T, int F, int W, int D, int ROLL = 0>
 __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k_inv2d_lds_long(InvLongArgs<T, F> a)
 {
     typedef T T2 __attribute__((ext_vector_type(2)));
@@ -219,6 +219,22 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
         store4<T>(out + (2 * p + 1) * a.ldd, xo);
     };
 
+    if constexpr (ROLL != 0) {
+        // rolled form (D = 1, R = SH + 1): ONE step's code in a real loop, the rings shifted by register moves instead of being
+        // addressed by an unrolled slot index -- 1/R of the instruction footprint for 2 R x 4 moves per step
+        static_assert(D == 1, "the rolled form requests one step ahead");
+        load_raw(-SH, 0);
+#pragma unroll 1
+        for (int t = -SH; t < S; ++t) {
+#pragma unroll
+            for (int i = 0; i + 1 < R; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { iS[i][q] = iS[i + 1][q]; iD[i][q] = iD[i + 1][q]; }
+            }
+            step(t, 0, R - 1, t >= 0);
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < D; ++s) load_raw(s - SH, s);
     // prologue: steps -SH .. -1 -> ring slots R - SH .. R - 1, request slots c % D (step t uses request slot (t + SH) % D; R % D == 0)
@@ -245,7 +261,7 @@ bool inv2d_long_ok(int F, int64_t n0, int64_t n1, int esize)
     return n0 >= 256 && (n0 % 256) == 0 && (n1 % 2) == 0 && h1 >= (F - 2) / 2 + 5 && h0 >= (F - 2) / 2;   // (+ 4: requests up to 4 steps ahead wrap once)
 }
 
-template <typename T, int F, int W, int D>
+template <typename T, int F, int W, int D, int ROLL = 0>
 static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
                                       T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
@@ -258,12 +274,15 @@ static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const
     // at 130 ... 210 VGPRs) with them, shorter ones below (measured r04: 8192^2 TP 64, 4096^2 TP 16, 2048^2 TP 8)
     int TP = (int)opt("WL_INVLONG_TP", 64);
     if (TP < 8) TP = 64;
+    // (10 taps, Float32, 125 VGPRs = four waves per SIMD possible: 8192^2 level 119.5 us with 64-pair chunks, 115.3 with 32, 137-151
+    //  with 128 (one wave per SIMD) -- but a 16-waves-per-CU target halves the chunks of the smaller levels too and the whole
+    //  transform loses: 187 against 182 us.  Kept at 8.)
     const int64_t want = (int64_t)cu_count * opt("WL_INVLONG_WAVES_PER_CU", 8);
     while (TP > 8 && (int64_t)a.nstrips * ((h1 + TP - 1) / TP) * W * bt.nplanes < want) TP >>= 1;
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     a.tp = shrink<T, F>(taps);
-    hipLaunchKernelGGL((k_inv2d_lds_long<T, F, W, D>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)bt.nplanes), dim3(64 * W), 0, st, a);
+    hipLaunchKernelGGL((k_inv2d_lds_long<T, F, W, D, ROLL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)bt.nplanes), dim3(64 * W), 0, st, a);
     return hipGetLastError();
 }
 
@@ -272,8 +291,11 @@ static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<T> &taps, const 
                                      T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     // request distance in steps: a step is ~0.3 us of arithmetic, a loaded HBM round trip 1 - 2 us
-    int D = (int)opt("WL_INVLONG_D", F <= 10 ? 2 : 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
-    if (sizeof(T) == 8 && D > 3) D = 3;                       // (Float64 with 4 columns in flight spills at 10 / 12 taps)
+    int D = (int)opt("WL_INVLONG_D", 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
+    if (sizeof(T) == 8 && D > 3) D = 3;
+    if constexpr (sizeof(T) == 4 && W == 1) {                   // (experiment knob: the rolled form, Float32, one wave per workgroup)
+        if (opt("WL_INVLONG_ROLL", 0) != 0) return launch_inv_long_fwd<T, F, W, 1, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+    }                       // (Float64 with 4 columns in flight spills at 10 / 12 taps)
     if (D <= 1) return launch_inv_long_fwd<T, F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     if (D == 2) return launch_inv_long_fwd<T, F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     if (D == 3) return launch_inv_long_fwd<T, F, W, 3>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);

@@ -291,7 +291,7 @@ static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<T> &taps, const 
                                      T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
     // request distance in steps: a step is ~0.3 us of arithmetic, a loaded HBM round trip 1 - 2 us
-    int D = (int)opt("WL_INVLONG_D", 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 against 463)
+    int D = (int)opt("WL_INVLONG_D", F <= 10 ? 2 : 3);       // (measured r04: db8 164 us with 3 against 167 with 2; sym5 batches 436 with 2 against 463 with 3)
     if (sizeof(T) == 8 && D > 3) D = 3;
     if constexpr (sizeof(T) == 4 && W == 1) {                   // (experiment knob: the rolled form, Float32, one wave per workgroup)
         if (opt("WL_INVLONG_ROLL", 0) != 0) return launch_inv_long_fwd<T, F, W, 1, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);

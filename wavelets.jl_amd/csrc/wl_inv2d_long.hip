@@ -24,10 +24,13 @@
 // The LDS buffers alternate with the step parity, so one barrier per step is enough.  The loop body is unrolled over the ring
 // (R steps, R a multiple of D so that request slots are compile-time); a step past the chunk is an EXIT (see k_fwd2d_lds_long).
 // Loads and waits are the compiler's here.
-// What bounds it (measured r04, profiles/r04_inv_long.md): VALU issue.  A step is ~500 f32 multiplies / adds per lane (2 F per
-// sample and pass, no FMA by the arithmetic contract) + ~110 other VALU; it takes ~2300 cycles on a SIMD whether one or two
-// waves share it, with or without v_pk_* packing, with requests 1 ... 4 steps ahead: 8192^2 db8 = 164 us = 3.3 TB/s, above the
-// two-pass tier's 226 us (same arithmetic, twice the traffic) and well below the copy ceiling -- the arithmetic is the limit.
+// What bounds it (measured r04, profiles/r04_inv_long.md): a step is ~500 f32 multiplies / adds per lane (2 F per sample and pass,
+// no FMA by the arithmetic contract) + ~100 other VALU instructions = 1370 cycles of VALU pipe time at the 2.3-cycle rate two or
+// more waves reach together (one wave alone issues every 4.6 cycles); measured 2500 cycles per wave-step and SIMD with the two
+// waves that 150 ... 230 VGPRs allow: the exchange round trip of one wave is covered by one other wave only.  8192^2 db8 = 150 us
+// = 3.6 TB/s, well above the two-pass tier (226 us, twice the traffic), below the copy ceiling.  Packed arithmetic is neutral (a
+// packed instruction costs two scalar ones on a shared pipe), a rolled loop (1/9 of the code) is slower, longer request
+// distances are neutral; four waves per SIMD (10 taps, shorter chunks) gain 4-10 %.
 // A first draft used a helper wave for the halo (as k_fwd2d_lds_long): it held a wave slot with the main waves' 130 ... 210 VGPRs,
 // i.e. half of the two-waves-per-SIMD occupancy, for two loads per step.
 // Arithmetic: the closed form of filtup! in the reference's summation order (wl_internal.h) -- bit-identical to the two-pass tier.

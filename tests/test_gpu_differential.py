@@ -194,6 +194,7 @@ def test_inverse_lds_exchange_level_against_the_tiers_it_replaces(gpu, W, seed):
             W.set_option("WL_INVLONG_W", int(r.choice([0, 1, 2, 4])))
             W.set_option("WL_INVLONG_TP", int(r.choice([8, 12, 16, 24, 40, 64, 128])))
             W.set_option("WL_INVLONG_D", int(r.choice([1, 2, 3, 4])))
+            W.set_option("WL_INVLONG_PPL", int(r.choice([0, 1, 2])))
             W.set_option("WL_INVLONG_WAVES_PER_CU", int(r.choice([0, 8])))
             out.append(W.idwt_batch(x, wt, L) if nb else W.idwt(x, wt, L))
             hit += int(on and W.last_kernel() == "k_inv2d_lds_long")

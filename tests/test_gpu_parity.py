@@ -373,6 +373,7 @@ def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, dtype, wmain,
     W.set_option("WL_INVLONG_W", wmain)
     W.set_option("WL_INVLONG_TP", tp)
     W.set_option("WL_INVLONG_D", {8: 1, 20: 2, 64: 4}[tp])
+    W.set_option("WL_INVLONG_PPL", {8: 2, 20: 1, 64: 0}[tp])       # pairs per lane: forced 2, forced 1 (Float32, W = 1), by size
     W.set_option("WL_INVLONG_WAVES_PER_CU", 0)
     W.set_option("WL_INVLONG2D_MIN_ROWS", 256)
     W.set_option("WL_INVLONG_FMIN", 8)

@@ -101,13 +101,16 @@ __device__ __forceinline__ void store4(T *p, const T (&v)[4])
     }
 }
 
-template <typename T, int F, int W, int D, int ROLL = 0>
+// PPL: coefficient pairs per lane (2: strips of 256 W rows, 8-byte loads and 16-byte stores; 1: strips of 128 W rows with half
+// the ring registers -- four waves per SIMD for the 12 ... 20-tap instances -- at 4-byte loads and 8-byte stores)
+template <typename T, int F, int W, int D, int ROLL = 0, int PPL = 2>
 __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k_inv2d_lds_long(InvLongArgs<T, F> a)
 {
     typedef T T2 __attribute__((ext_vector_type(2)));
+    static_assert(PPL == 1 || PPL == 2, "one or two pairs per lane");
     constexpr int SH = (F - 2) / 2, SHP = (SH + 1) & ~1;      // reach in pairs; the same rounded up to even (8-byte aligned LDS rows)
     constexpr int R = ((SH + 1 + D - 1) / D) * D;             // ring depth = unroll: >= SH + 1, a multiple of the request distance D
-    constexpr int NP = 128 * W;                               // coefficient pairs of the strip
+    constexpr int NP = 64 * PPL * W;                          // coefficient pairs of the strip
     constexpr int LA = NP + SHP + 4;                          // one LDS array: positions [0, NP + SHP) (+ pad)
     __shared__ __attribute__((aligned(16))) T lds[2][4][LA];  // [step parity][Ls, Ld, Rs, Rd]
 
@@ -133,13 +136,13 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
 
     // ================= lane Lm = 64 wv + lane owns pairs r0 + 2 Lm, r0 + 2 Lm + 1 =================
     const int Lm = 64 * wv + lane;
-    const int64_t rr = r0 + 2 * Lm;
+    const int64_t rr = r0 + PPL * Lm;
     const T *ls_base = llb + rr;                              // left half, scaling rows
     const T *ld_base = xb + h0 + rr;                          // left half, detail rows
     const T *rs_base = xb + h1 * a.ldx + rr;                  // right half, scaling rows
     const T *rd_base = rs_base + h0;                          // right half, detail rows
-    const int ws = SHP + 2 * Lm;                              // LDS positions: scaling arrays hold pair r0 - SHP + i at i, detail arrays r0 + i
-    const int wd = 2 * Lm;
+    const int ws = SHP + PPL * Lm;                            // LDS positions: scaling arrays hold pair r0 - SHP + i at i, detail arrays r0 + i
+    const int wd = PPL * Lm;
     // the halo of the exchange (periodic wrap) rides on wave 0: lane h < SH takes scaling pair r0 - SH + h of both halves,
     // lane SH <= h < 2 SH detail pair r0 + NP + (h - SH).  (Up to round-4 draft 1 a helper wave did this: it cost a wave slot with
     // the main waves' register allocation, i.e. half of the two-waves-per-SIMD occupancy.)
@@ -154,37 +157,50 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
     const int hw = hd ? (NP + lane - SH) : (SHP - SH + lane);
     const int hal = hd ? 1 : 0;
 
-    T2 raw[D][4];                                             // requests in flight: D steps ahead
+    T raw[D][4][PPL];                                         // requests in flight: D steps ahead
+    auto ldp = [&](const T *q, T (&v)[PPL]) __attribute__((always_inline)) {
+        if constexpr (PPL == 2) { const T2 t2 = *reinterpret_cast<const T2 *>(q); v[0] = t2.x; v[1] = t2.y; }
+        else v[0] = *q;
+    };
+    auto stp = [&](T *q, const T (&v)[PPL]) __attribute__((always_inline)) {
+        if constexpr (PPL == 2) *reinterpret_cast<T2 *>(q) = T2{v[0], v[1]};
+        else *q = v[0];
+    };
     T hv[D][2];
     auto load_raw = [&](const int t, const int s) __attribute__((always_inline)) {
         const int64_t js = col_s(t), jd = col_d(t);
-        raw[s][0] = *reinterpret_cast<const T2 *>(ls_base + js * ls_ld);
-        raw[s][1] = *reinterpret_cast<const T2 *>(ld_base + js * a.ldx);
-        raw[s][2] = *reinterpret_cast<const T2 *>(rs_base + jd * a.ldx);
-        raw[s][3] = *reinterpret_cast<const T2 *>(rd_base + jd * a.ldx);
+        ldp(ls_base + js * ls_ld, raw[s][0]);
+        ldp(ld_base + js * a.ldx, raw[s][1]);
+        ldp(rs_base + jd * a.ldx, raw[s][2]);
+        ldp(rd_base + jd * a.ldx, raw[s][3]);
         if (halo_wave) {
             if (hl) { hv[s][0] = hlb[js * hl_ld]; hv[s][1] = hrb[jd * a.ldx]; }
         }
     };
 
-    T iS[R][4], iD[R][4];                                     // dim-1-reconstructed columns: left half / right half
-    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + 2 * (r0 + 2 * Lm);      // the lane's four output rows
-    // one column of the exchange -> the lane's four dim-1-reconstructed samples
-    auto recon = [&](const T *sa, const T *da, T (&o)[4]) __attribute__((always_inline)) {
-        // scaling pairs r - SH .. r + 1 at positions ws - SH .. ws + 1 (ws - SHP is even: read from there), detail pairs r .. r + 1 + SH
+    T iS[R][2 * PPL], iD[R][2 * PPL];                         // dim-1-reconstructed columns: left half / right half
+    T *out = a.dst + (int64_t)blockIdx.y * a.bs_dst + 2 * (r0 + PPL * Lm);    // the lane's 2 PPL output rows
+    // one column of the exchange -> the lane's 2 PPL dim-1-reconstructed samples
+    auto recon = [&](const T *sa, const T *da, T (&o)[2 * PPL]) __attribute__((always_inline)) {
+        // scaling pairs r - SH .. r + PPL - 1 at positions ws - SH .. (PPL = 2: ws - SHP is even, 8-byte reads from there), detail pairs r .. r + PPL - 1 + SH
         T sv[SHP + 2], dv[SH + 3];
+        if constexpr (PPL == 2) {
 #pragma unroll
-        for (int i = 0; i < (SHP + 2) / 2; ++i) {
-            const T2 v = *reinterpret_cast<const T2 *>(sa + ws - SHP + 2 * i);
-            sv[2 * i] = v.x; sv[2 * i + 1] = v.y;
+            for (int i = 0; i < (SHP + 2) / 2; ++i) {
+                const T2 v = *reinterpret_cast<const T2 *>(sa + ws - SHP + 2 * i);
+                sv[2 * i] = v.x; sv[2 * i + 1] = v.y;
+            }
+#pragma unroll
+            for (int i = 0; i < (SH + 3) / 2; ++i) {
+                const T2 v = *reinterpret_cast<const T2 *>(da + wd + 2 * i);
+                dv[2 * i] = v.x; dv[2 * i + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i <= SH; ++i) { sv[SHP - SH + i] = sa[ws - SH + i]; dv[i] = da[wd + i]; }
         }
 #pragma unroll
-        for (int i = 0; i < (SH + 3) / 2; ++i) {
-            const T2 v = *reinterpret_cast<const T2 *>(da + wd + 2 * i);
-            dv[2 * i] = v.x; dv[2 * i + 1] = v.y;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < PPL; ++p) {
             T sw[SH + 1], dw[SH + 1];
 #pragma unroll
             for (int i = 0; i <= SH; ++i) { sw[i] = sv[SHP - SH + p + i]; dw[i] = dv[p + i]; }
@@ -194,10 +210,10 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
     // t: step (from -SH: the first SH steps only fill the rings), s: request slot, u: ring slot of this step's columns
     auto step = [&](const int t, const int s, const int u, const bool combine) __attribute__((always_inline)) {
         T(*buf)[LA] = lds[t & 1];
-        *reinterpret_cast<T2 *>(&buf[0][ws]) = raw[s][0];
-        *reinterpret_cast<T2 *>(&buf[1][wd]) = raw[s][1];
-        *reinterpret_cast<T2 *>(&buf[2][ws]) = raw[s][2];
-        *reinterpret_cast<T2 *>(&buf[3][wd]) = raw[s][3];
+        stp(&buf[0][ws], raw[s][0]);
+        stp(&buf[1][wd], raw[s][1]);
+        stp(&buf[2][ws], raw[s][2]);
+        stp(&buf[3][wd], raw[s][3]);
         if (halo_wave) {
             if (hl) { buf[hal][hw] = hv[s][0]; buf[2 + hal][hw] = hv[s][1]; }
         }
@@ -209,17 +225,22 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
         recon(buf[0], buf[1], iS[u]);
         recon(buf[2], buf[3], iD[u]);
         if (!combine) return;
-        T xe[4], xo[4];
+        T xe[2 * PPL], xo[2 * PPL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2 * PPL; ++q) {
             T sw[SH + 1], dw[SH + 1];
 #pragma unroll
             for (int i = 0; i <= SH; ++i) { sw[i] = iS[(u + i + R - SH) % R][q]; dw[i] = iD[(u + i + R - SH) % R][q]; }
             window_inv_sel<T, F>(sw, dw, a.tp, xe[q], xo[q]);
         }
         const int64_t p = p0 + t;
-        store4<T>(out + (2 * p) * a.ldd, xe);
-        store4<T>(out + (2 * p + 1) * a.ldd, xo);
+        if constexpr (PPL == 2) {
+            store4<T>(out + (2 * p) * a.ldd, xe);
+            store4<T>(out + (2 * p + 1) * a.ldd, xo);
+        } else {
+            *reinterpret_cast<T2 *>(out + (2 * p) * a.ldd) = T2{xe[0], xe[1]};
+            *reinterpret_cast<T2 *>(out + (2 * p + 1) * a.ldd) = T2{xo[0], xo[1]};
+        }
     };
 
     if constexpr (ROLL != 0) {
@@ -232,7 +253,7 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
 #pragma unroll
             for (int i = 0; i + 1 < R; ++i) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { iS[i][q] = iS[i + 1][q]; iD[i][q] = iD[i + 1][q]; }
+                for (int q = 0; q < 2 * PPL; ++q) { iS[i][q] = iS[i + 1][q]; iD[i][q] = iD[i + 1][q]; }
             }
             step(t, 0, R - 1, t >= 0);
         }
@@ -264,7 +285,7 @@ bool inv2d_long_ok(int F, int64_t n0, int64_t n1, int esize)
     return n0 >= 256 && (n0 % 256) == 0 && (n1 % 2) == 0 && h1 >= (F - 2) / 2 + 5 && h0 >= (F - 2) / 2;   // (+ 4: requests up to 4 steps ahead wrap once)
 }
 
-template <typename T, int F, int W, int D, int ROLL = 0>
+template <typename T, int F, int W, int D, int ROLL = 0, int PPL = 2>
 static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const T *x, int64_t ldx, const T *ll, int64_t ldl,
                                       T *dst, int64_t ldd, int64_t n0, int64_t n1, int cu_count, const InvLongBatch &bt)
 {
@@ -272,7 +293,7 @@ static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const
     a.x = x; a.ldx = ldx; a.ll = ll; a.ldl = ldl; a.dst = dst; a.ldd = ldd; a.n0 = n0; a.n1 = n1;
     a.bs_x = bt.bs_x; a.bs_ll = bt.bs_ll; a.bs_dst = bt.bs_dst; a.nll = bt.nll;
     const int64_t h1 = n1 >> 1;
-    a.nstrips = (int)(n0 / (256 * W));
+    a.nstrips = (int)(n0 / (128 * PPL * W));
     // a chunk pays SH prologue steps: long chunks where the array is large enough to fill the chip (8 waves per CU: two per SIMD
     // at 130 ... 210 VGPRs) with them, shorter ones below (measured r04: 8192^2 TP 64, 4096^2 TP 16, 2048^2 TP 8)
     int TP = (int)opt("WL_INVLONG_TP", 64);
@@ -285,7 +306,7 @@ static hipError_t launch_inv_long_fwd(hipStream_t st, const Taps<T> &taps, const
     a.TP = TP;
     a.nchunks = (int)((h1 + TP - 1) / TP);
     a.tp = shrink<T, F>(taps);
-    hipLaunchKernelGGL((k_inv2d_lds_long<T, F, W, D, ROLL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)bt.nplanes), dim3(64 * W), 0, st, a);
+    hipLaunchKernelGGL((k_inv2d_lds_long<T, F, W, D, ROLL, PPL>), dim3((unsigned)(a.nstrips * a.nchunks), (unsigned)bt.nplanes), dim3(64 * W), 0, st, a);
     return hipGetLastError();
 }
 
@@ -298,6 +319,13 @@ static hipError_t launch_inv_long_fw(hipStream_t st, const Taps<T> &taps, const 
     if (sizeof(T) == 8 && D > 3) D = 3;
     if constexpr (sizeof(T) == 4 && W == 1) {                   // (experiment knob: the rolled form, Float32, one wave per workgroup)
         if (opt("WL_INVLONG_ROLL", 0) != 0) return launch_inv_long_fwd<T, F, W, 1, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
+        // one pair per lane (strips of 128 rows, half the ring registers): twice the strips and four waves per SIMD.  Measured r04
+        // (db6 / db8 / db10, one level, us): 8192^2 129 / 150 / 166 -> 131 / 153 / 178 (more LDS instructions per output, 8-byte
+        // stores), 4096^2 38 / 48 / 57 -> 40 / 46 / 55, 2048^2 16 / 21 / 26 -> 14 / 18 / 22, 1024^2 14 / 18 / 23 -> 10 / 13 / 16,
+        // 512^2 13 / 17 / 22 -> 9 / 12 / 15: the small levels are short of workgroups, not of bandwidth
+        int ppl = (int)opt("WL_INVLONG_PPL", 0);
+        if (ppl != 1 && ppl != 2) ppl = (F >= 12 && (n0 <= 2048 || (F >= 16 && n0 <= 4096))) ? 1 : 2;
+        if (ppl == 1) return launch_inv_long_fwd<T, F, W, 3, 0, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     }                       // (Float64 with 4 columns in flight spills at 10 / 12 taps)
     if (D <= 1) return launch_inv_long_fwd<T, F, W, 1>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);
     if (D == 2) return launch_inv_long_fwd<T, F, W, 2>(st, taps, x, ldx, ll, ldl, dst, ldd, n0, n1, cu_count, bt);

@@ -206,8 +206,8 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 assert W.last_kernel() == kfw or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
-                # inverse, 12..20 taps, output rows a multiple of 256 (>= 512): one pass per level as well, both element types (wl_inv2d_long.hip, round 4)
-                kinv = "k_inv2d_lds_long" if (flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 512) else kexp
+                # inverse, 12..20 taps, output rows a multiple of 256: one pass per level as well, both element types (wl_inv2d_long.hip, round 4)
+                kinv = "k_inv2d_lds_long" if (flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 256) else kexp
                 assert W.last_kernel() == kinv or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
         xm = rng_array((4096, 5), dtype, flen)

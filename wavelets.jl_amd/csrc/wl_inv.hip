@@ -1148,7 +1148,7 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         bool done = false;
         // the LDS-exchange level kernel (wl_inv2d_long.hip: which filter lengths per element type), output rows a multiple of 256
         auto try_lds_long = [&]() -> hipError_t {
-            if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 512) && b.full.s[0] == 1 &&
+            if (!done && path == 0 && two_d && i_env("WL_INVLONG2D", 1) != 0 && n[0] >= i_env("WL_INVLONG2D_MIN_ROWS", 256) && b.full.s[0] == 1 &&
                 inv2d_long_ok(F, n[0], n[1], (int)sizeof(T)) && (b.full.s[1] % VEC) == 0 && (res_st.s[1] % VEC) == 0 && i_al16(x) && i_al16(res) &&
                 (!llsrc || (i_al16(llsrc) && (llsrc_st.s[1] % 2) == 0))) {
                 hipError_t e = inv2d_long_launch<T>(st, taps, x, b.full.s[1], llsrc, llsrc ? llsrc_st.s[1] : 0, res, res_st.s[1], n[0], n[1], cu_count);
@@ -1389,7 +1389,7 @@ bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, i
         !i_al16(x) || !i_al16(dst) || (ll && !i_al16(ll)) || nplanes > 65535)
         return false;
     // the LDS-exchange level kernel (wl_inv2d_long.hip) where it is enabled for this filter length and the batch is large
-    if (i_env("WL_INVLONG2D", 1) != 0 && inv2d_long_ok(F, n0, n1, (int)sizeof(T)) && n0 >= i_env("WL_INVLONG2D_MIN_ROWS", 512) &&
+    if (i_env("WL_INVLONG2D", 1) != 0 && inv2d_long_ok(F, n0, n1, (int)sizeof(T)) && n0 >= i_env("WL_INVLONG2D_MIN_ROWS", 256) &&
         (F >= 12 || n0 * n1 * nplanes >= (int64_t)i_env("WL_INVLONG_SHORT_MIN", 1 << 22))) {
         const InvLongBatch bt = {nplanes, x2, (n0 >> 1) * (n1 >> 1), n0 * n1, ll ? nll : 0};
         *err = inv2d_long_launch<T>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, bt);

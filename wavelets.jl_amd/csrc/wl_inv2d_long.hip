@@ -2,7 +2,7 @@
 // (wl_fwd2d_long.hip).  Written in round 4 for the 12 ... 20-tap filters (db6 ... db10, sym6 ... sym10, coif4, coif6, beyl), which
 // up to round 3 took two line launches + one axis launch per inverse level through an N-element intermediate (2 x the traffic,
 // 3 launches).  Also used where it measured ahead of the DPP-halo streaming kernel (k_inv2d_stream, wl_inv.hip):
-//   Float32  12 ... 20 taps: levels of >= 512 output rows;  10 taps (sym5, the default wavelet of denoise): blocks / batches of >= 2^22
+//   Float32  12 ... 20 taps: levels of >= 256 output rows;  10 taps (sym5, the default wavelet of denoise): blocks / batches of >= 2^22
 //            samples (8192^2 level 130 -> 117 us, 64 x 2048^2 batch 532 -> 436 us);  8 taps: not used (112 against 114 us, and the
 //            fused pair of k_inv2d_pair is ahead of both)
 //   Float64  8 ... 20 taps (8192^2 idwt L = 13: db4 331 -> 316 us, sym5 390 -> 355, db6 711 -> 376, db8 733 -> 437, db10 781 -> 631;

@@ -438,6 +438,7 @@ def _xwt_batch(x, wt, L, fw, y=None):
     n0, n1, nb = (int(v) for v in x.shape)
     L = min(Util.maxtransformlevels(n0), Util.maxtransformlevels(n1)) if L is None else int(L)
     y = similar(x) if y is None else y
+    _check_pair(y, x)                        # (a caller-supplied y: same shape / type / device, dense column-major)
     lib = _lib.load()
     h, st = _context(x.device)
     q = np.ascontiguousarray(wt.qmf, dtype=np.float64)

@@ -113,3 +113,22 @@ def test_library_has_no_async_load_hazard():
     except OSError:
         ver = "unknown"
     assert not report, "asynchronous-load hazards in the shipped code (%s; validated with %s):\n%s" % (ver, VALIDATED_HIPCC, msg)
+
+
+def test_instruction_mix_tool_reports_the_headline_kernels():
+    """tools/isa_stats.py (round 4): the static instruction mix of the shipped kernels.  Pins two facts the design relies on:
+    the 12 ... 20-tap inverse level kernel moves NO spilled SGPRs through lanes (its detail taps are the negated scaling taps), and
+    no dominant kernel uses scratch except the inverse pair's documented 68 bytes."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_stats.py")], capture_output=True, text=True, check=True).stdout
+    rows = {}
+    for line in out.splitlines()[2:]:
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        rows[cells[0].strip("`")] = [int(v) for v in cells[1:]]
+    assert any(k.startswith("k_fwd2d_pair<8, 2, 1, 0>") for k in rows) and any(k.startswith("k_fwd2d_lds<8, 1, 0>") for k in rows)
+    for k, v in rows.items():
+        # columns: instructions, VALU, packed, DPP, lane moves, SALU, LDS, vmem, barriers, waitcnt, VGPRs, SGPR spills, scratch
+        if k.startswith("k_inv2d_lds_long<float, 16"):
+            assert v[4] == 0 and v[11] == 0, (k, v)
+        if not k.startswith("k_inv2d_pair"):
+            assert v[12] == 0, (k, v)

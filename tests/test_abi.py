@@ -26,6 +26,22 @@ def test_header_symbols_exported(W):
         assert getattr(lib, s) is not None
 
 
+def test_fused_variant_exports_the_same_abi(W):
+    """libwavelets_mi355x_fma.so (the opt-in fused arithmetic mode, `make FMA=1`) is the same ABI built from the same sources"""
+    path = W._lib.LIB_PATHS["fused"]
+    assert os.path.exists(path), "build() makes both libraries"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    assert set(re.findall(r" T (wl_[a-z0-9_]+)", out)) == set(declared_symbols())
+    assert W.get_arithmetic() == "exact"                       # the default; switching needs no device
+    try:
+        W.set_arithmetic("fused")
+        lib = W._lib.load()
+        assert lib._name == path and lib.wl_version() == C.CDLL(W._lib.LIB_PATH).wl_version()
+    finally:
+        W.set_arithmetic("exact")
+    assert W._lib.load()._name == W._lib.LIB_PATH
+
+
 def test_hostonly_entry_points(W):
     lib = W._lib.load()
     assert lib.wl_version() == 100

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import wavelets_jl_amd as W
 
+if "--arithmetic" in sys.argv:          # "fused": the opt-in FMA build (tools/fp_contract_price.sh prices it against "exact")
+    W.set_arithmetic(sys.argv[sys.argv.index("--arithmetic") + 1])
+
 
 def timeit(fn, reps=20):
     for _ in range(3):
@@ -30,9 +33,9 @@ cdf = W.wavelet(W.WT.cdf97, W.WT.Lifting)
 for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
     es = 4 if dtype == torch.float32 else 8
     for label, shape, wt, L in (("1-D 2^24", (1 << 24,), db4, 24), ("1-D 2^20", (1 << 20,), db4, 20), ("2-D 8192^2", (8192, 8192), db4, 13),
-                                ("2-D 2048^2", (2048, 2048), db4, 11), ("3-D 256^3", (256, 256, 256), db4, 8),
+                                ("2-D 2048^2", (2048, 2048), db4, 11), ("3-D 256^3", (256, 256, 256), db4, 8), ("3-D 512^3", (512, 512, 512), db4, 9),
                                 ("2-D 8192^2 sym5", (8192, 8192), sym5, 13), ("2-D 8192^2 db8 (16 taps)", (8192, 8192), db8, 13),
-                                ("1-D 2^24 cdf9/7 lifting", (1 << 24,), cdf, 24), ("2-D 4096^2 cdf9/7 lifting", (4096, 4096), cdf, 12),
+                                ("1-D 2^24 cdf9/7 lifting", (1 << 24,), cdf, 24), ("2-D 4096^2 cdf9/7 lifting", (4096, 4096), cdf, 12), ("2-D 8192^2 cdf9/7 lifting", (8192, 8192), cdf, 13),
                                 ("3-D 256^3 cdf9/7 lifting", (256, 256, 256), cdf, 8)):
         if dtype == torch.float64 and shape == (8192, 8192) and wt is sym5:
             continue

@@ -18,7 +18,7 @@ from .util import (maxtransformlevels, sufficientpoweroftwo, detailindex, detail
                    dyadiclevel2tl, mirror, upsample, downsample, wcount, testfunction)
 from .transforms import (dwt, idwt, dwt_, idwt_, dwt_oop_, idwt_oop_, dwtc, idwtc, dwtc_, idwtc_, wpt, iwpt, wpt_, iwpt_, dwt_batch, idwt_batch,
                          to_device, to_host, similar, julia_layout, is_julia_layout,
-                         reserve_workspace, workspace_held, set_kernel_path, last_kernel, destroy_contexts, set_option, clear_options, options,
+                         reserve_workspace, workspace_held, set_kernel_path, last_kernel, destroy_contexts, set_option, clear_options, options, set_arithmetic, get_arithmetic, arithmetic,
                          DimensionMismatch, ArgumentError, HIPError)
 from .modwt import modwt, imodwt, maxmodwttransformlevels
 from .threshold import (THType, HardTH, SoftTH, SemiSoftTH, SteinTH, BiggestTH, PosTH, NegTH, DEFAULT_TH, threshold, threshold_,
@@ -33,7 +33,7 @@ __all__ = [
     "dyadicdetailindex", "dyadicdetailrange", "dyadicscalingrange", "dyadicdetailn", "maxdyadiclevel", "tl2dyadiclevel",
     "dyadiclevel2tl", "mirror", "upsample", "downsample", "wcount", "testfunction",
     "to_device", "to_host", "similar", "julia_layout", "is_julia_layout",
-    "reserve_workspace", "workspace_held", "set_kernel_path", "last_kernel", "destroy_contexts", "set_option", "clear_options", "options",
+    "reserve_workspace", "workspace_held", "set_kernel_path", "last_kernel", "destroy_contexts", "set_option", "clear_options", "options", "set_arithmetic", "get_arithmetic", "arithmetic",
     "DimensionMismatch", "ArgumentError", "HIPError",
     "modwt", "imodwt", "maxmodwttransformlevels",
     "THType", "HardTH", "SoftTH", "SemiSoftTH", "SteinTH", "BiggestTH", "PosTH", "NegTH", "DEFAULT_TH", "threshold", "threshold_",

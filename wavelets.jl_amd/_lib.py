@@ -11,6 +11,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavelets_mi355x.so")
+# The opt-in fused build (same sources, `make -C wavelets.jl_amd/csrc FMA=1`: a*b+c may contract to one rounding).  "exact" is the
+# default and the only mode whose results are bit-identical to the reference; "fused" agrees with it to the tolerances SURVEY.md
+# 8(c) states (tests/test_gpu_fused.py).  Selected explicitly with transforms.set_arithmetic(); never a fallback for one another.
+LIB_PATHS = {"exact": LIB_PATH, "fused": os.path.join(_HERE, "libwavelets_mi355x_fma.so")}
 
 WL_F32, WL_F64 = 0, 1
 
@@ -25,7 +29,8 @@ class WaveletsLibraryError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
+_mode = "exact"
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -88,20 +93,33 @@ SIGNATURES = {
 
 def load():
     """Load the shared library (no GPU needed for this step) and bind every ABI symbol."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    lib = _libs.get(_mode)
+    if lib is not None:
+        return lib
+    path = LIB_PATHS[_mode]
+    if not os.path.exists(path):
         raise WaveletsLibraryError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            f"(or `make -C wavelets.jl_amd/csrc`).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C wavelets.jl_amd/csrc{' FMA=1' if _mode == 'fused' else ''}`).  There is no CPU fallback.")
+    lib = C.CDLL(path)
     for nm, (res, args) in SIGNATURES.items():
         fn = getattr(lib, nm)          # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[_mode] = lib
     return lib
+
+
+def arithmetic() -> str:
+    return _mode
+
+
+def _select(mode: str):
+    """transforms.set_arithmetic() is the public switch (it also retires the contexts of the library being left)."""
+    global _mode
+    if mode not in LIB_PATHS:
+        raise ValueError(f"arithmetic mode must be one of {sorted(LIB_PATHS)}, got {mode!r}")
+    _mode = mode
 
 
 def strerror(rc: int) -> str:

@@ -17,7 +17,13 @@
 #include <string.h>
 #include "../../include/wavelets_mi355x.h"
 
+#ifdef WL_FMA
+// the opt-in fused build (libwavelets_mi355x_fma.so, `make FMA=1`): a*b+c may contract to one rounding; results agree with the
+// reference to the tolerance SURVEY.md 8(c) states, not bit for bit.  Same sources, same summation order.
+#pragma clang fp contract(fast)
+#else
 #pragma clang fp contract(off)
+#endif
 
 namespace wl {
 

@@ -14,6 +14,9 @@ using Wavelets: WT, Util
 using Wavelets.Transforms: Transforms
 using AMDGPU: ROCArray, ROCVector, ROCMatrix, AMDGPU
 
+# The library path is fixed at load time (`ccall` needs a constant).  Default: the bit-exact build.  Pointing
+# WAVELETS_MI355X_LIB at libwavelets_mi355x_fma.so selects the opt-in fused arithmetic mode (same ABI, same kernels built with FMA
+# contraction: agrees with the CPU reference to 1e-6*sqrt(L) relative L2 in Float32 / 1e-13*sqrt(L) in Float64, not bit for bit).
 const LIB = get(ENV, "WAVELETS_MI355X_LIB", "libwavelets_mi355x.so")
 const DT = Dict(Float32 => Cint(0), Float64 => Cint(1))
 # One context per (device, stream): a wl_ctx owns a workspace that kernels queued on its stream are still using, so two
@@ -76,14 +79,29 @@ end
 dims3(x) = Int64[size(x)..., ntuple(_ -> 1, 3 - ndims(x))...]
 
 # ---- filter bank: replaces _dwt!(y, x, filter::OrthoFilter, L, fw), transforms_filter.jl:13,113,192
-function Transforms._dwt!(y::ROCArray{T,N}, x::ROCArray{T,N}, filter::OrthoFilter, L::Integer,
-                          fw::Bool) where {T<:Union{Float32,Float64},N}
+# Dispatch: WaveletsGPUExt (loaded with AMDGPU, since AMDGPU loads GPUArrays + KernelAbstractions) defines
+#   _dwt!(y::AbstractGPUVector{Ty}, x::AbstractGPUVector{Tx}, ...), ...::AbstractGPUMatrix..., ...::AbstractGPUArray{.,3}
+# (ext/WaveletsGPUExt/filter_transforms_gpu.jl:171,216,271; lifting_transforms_gpu.jl:171,210,249).  The methods below mirror
+# them one for one on ROCVector / ROCMatrix / ROCArray{T,3}: each signature is a strict subtype of the extension's, so it is the
+# more specific method for same-T Float32/Float64 arguments by the subtype rule alone (no specificity heuristics, no ambiguity);
+# mixed element types (Tx != Ty), Integer and Complex arrays do not match and fall through to the extension, which promotes.
+# tests/test_julia_glue.py proves the element-wise `<:` statically against the reference's signatures.
+function dwt_filter_device!(y, x, filter::OrthoFilter, L::Integer, fw::Bool, ::Type{T}, N::Int) where {T}
     size(x) == size(y) || throw(DimensionMismatch("in and out array size must match"))
     q = filter.qmf                                  # Float64 taps; converted to T inside, like makereverseqmfpair
     GC.@preserve y x check(ccall((:wl_dwt_filter, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Cint, Ptr{Cvoid}),
                 ctx(), DT[T], pointer(y), pointer(x), N, dims3(x), q, length(q), L, fw, stream()))
     return y
+end
+function Transforms._dwt!(y::ROCVector{T}, x::ROCVector{T}, filter::OrthoFilter, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_filter_device!(y, x, filter, L, fw, T, 1)
+end
+function Transforms._dwt!(y::ROCMatrix{T}, x::ROCMatrix{T}, filter::OrthoFilter, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_filter_device!(y, x, filter, L, fw, T, 2)
+end
+function Transforms._dwt!(y::ROCArray{T,3}, x::ROCArray{T,3}, filter::OrthoFilter, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_filter_device!(y, x, filter, L, fw, T, 3)
 end
 
 # ---- lifting: replaces _dwt!(y, scheme::GLS, L, fw), transforms_lifting.jl:30,128,200
@@ -94,7 +112,7 @@ function flatten(s::GLS)
     cf = Float64[c for st in s.step for c in st.param.coef]
     return isup, nc, sh, cf
 end
-function Transforms._dwt!(y::ROCArray{T,N}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64},N}
+function dwt_lifting_device!(y, scheme::GLS, L::Integer, fw::Bool, ::Type{T}, N::Int) where {T}
     isup, nc, sh, cf = flatten(scheme)
     GC.@preserve y check(ccall((:wl_dwt_lifting, LIB), Cint,
                 (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
@@ -102,6 +120,15 @@ function Transforms._dwt!(y::ROCArray{T,N}, scheme::GLS, L::Integer, fw::Bool) w
                 ctx(), DT[T], pointer(y), N, dims3(y), length(isup), isup, nc, sh, cf,
                 scheme.norm1, scheme.norm2, L, fw, stream()))
     return y
+end
+function Transforms._dwt!(y::ROCVector{T}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_lifting_device!(y, scheme, L, fw, T, 1)
+end
+function Transforms._dwt!(y::ROCMatrix{T}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_lifting_device!(y, scheme, L, fw, T, 2)
+end
+function Transforms._dwt!(y::ROCArray{T,3}, scheme::GLS, L::Integer, fw::Bool) where {T<:Union{Float32,Float64}}
+    return dwt_lifting_device!(y, scheme, L, fw, T, 3)
 end
 
 # dwt(x, scheme::GLS, L) / idwt(x, scheme, L) of the reference are `y = similar(x); copyto!(y, x); _dwt!(y, scheme, L, fw)`
@@ -273,16 +300,22 @@ using Wavelets.Threshold: Threshold, HardTH, SoftTH, SemiSoftTH, SteinTH, Bigges
 const THCODE = Dict(HardTH => Cint(0), SoftTH => Cint(1), SemiSoftTH => Cint(2), SteinTH => Cint(3), PosTH => Cint(4), NegTH => Cint(5))
 # Julia computes `x[i] op t` in promote_type(T, typeof(t)): Float64 only when T is Float32 and t is a Float64
 t_is_f64(::Type{T}, t) where {T} = Cint(promote_type(T, typeof(t)) === Float64 && T !== Float64)
-function Threshold.threshold!(x::ROCArray{T}, th::Union{HardTH,SoftTH,SemiSoftTH,SteinTH}, t::Real) where {T<:Union{Float32,Float64}}
-    @assert t >= 0
-    GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
-                ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], Float64(t), t_is_f64(T, t), stream()))
-    return x
+# One method per threshold type, like the reference (threshold_main.jl:35,48,64,82,98,110): `th::Union{HardTH,...}` would be
+# more specific than the reference's method in the first slot and less specific in the second -- an ambiguity error at the call.
+for TH in (:HardTH, :SoftTH, :SemiSoftTH, :SteinTH)
+    @eval function Threshold.threshold!(x::ROCArray{T}, th::$TH, t::Real) where {T<:Union{Float32,Float64}}
+        @assert t >= 0
+        GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(x), length(x), THCODE[$TH], Float64(t), t_is_f64(T, t), stream()))
+        return x
+    end
 end
-function Threshold.threshold!(x::ROCArray{T}, th::Union{PosTH,NegTH}) where {T<:Union{Float32,Float64}}
-    GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
-                ctx(), DT[T], pointer(x), length(x), THCODE[typeof(th)], 0.0, Cint(0), stream()))
-    return x
+for TH in (:PosTH, :NegTH)
+    @eval function Threshold.threshold!(x::ROCArray{T}, th::$TH) where {T<:Union{Float32,Float64}}
+        GC.@preserve x check(ccall((:wl_threshold, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ptr{Cvoid}),
+                    ctx(), DT[T], pointer(x), length(x), THCODE[$TH], 0.0, Cint(0), stream()))
+        return x
+    end
 end
 function Threshold.threshold!(x::ROCArray{T}, ::BiggestTH, m::Int) where {T<:Union{Float32,Float64}}
     @assert m >= 0

@@ -101,6 +101,40 @@ def set_kernel_path(path: int):
         _check(_lib.load().wl_ctx_set_path(h, _FORCE_PATH))
 
 
+def set_arithmetic(mode: str):
+    """"exact" (default): every product and sum rounded separately, results bit-identical to the reference's CPU path.
+    "fused": the opt-in build of the same kernels with FMA contraction allowed (libwavelets_mi355x_fma.so) -- results agree
+    with the reference to SURVEY.md 8(c)'s tolerances (f32 relative L2 <= 1e-6*sqrt(L), f64 <= 1e-13*sqrt(L)), not bit for
+    bit.  Process-wide; the contexts (and workspaces) of the library being left are destroyed first."""
+    if mode == _lib.arithmetic():
+        return
+    if mode not in _lib.LIB_PATHS:
+        raise ValueError(f"arithmetic mode must be one of {sorted(_lib.LIB_PATHS)}, got {mode!r}")
+    if _CTX:
+        destroy_contexts()
+    _lib._select(mode)
+
+
+def get_arithmetic() -> str:
+    return _lib.arithmetic()
+
+
+class arithmetic:
+    """with W.arithmetic("fused"): ...   -- mode for the block, previous mode restored afterwards."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.saved = _lib.arithmetic()
+        set_arithmetic(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_arithmetic(self.saved)
+        return False
+
+
 def _context(device: torch.device):
     if device.type != "cuda":
         raise HIPError("wavelets_jl_amd runs on MI355X (gfx950) HIP devices only; there is no CPU path")

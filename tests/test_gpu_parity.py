@@ -1495,6 +1495,41 @@ def test_batch_of_images_bitexact(gpu, W, oracle):
             assert np.array_equal(xr[:, :, i].cpu().numpy(), e), (n0, n1, L, fname, i)
 
 
+def test_batch_of_images_padded_image_stride(gpu, W, oracle):
+    """wl_dwt_filter_batch through ctypes with image_stride > dims[0] * dims[1] (the documented C ABI; the Python / Julia wrappers
+    always pass dense strides): forward and inverse, the plane-batch kernels (n0 >= 256: k_fwd2d_* over blockIdx.y, k_inv2d_stream /
+    k_inv2d_lds_long planes) and the per-image fallback; the padding between the images is never written (round-4 advisor finding:
+    the inverse plane branch wrote image i at i * n0 * n1 instead of i * image_stride)."""
+    import ctypes as C
+    import torch
+    lib = W._lib.load()
+    for (n0, n1, nb, L, fname, dtype, pad) in ((512, 512, 3, 4, "db4", np.float32, 64), (256, 128, 4, 3, "sym5", np.float32, 4096),
+                                                (512, 256, 3, 2, "db8", np.float32, 16), (256, 256, 3, 5, "db2", np.float64, 6),
+                                                (64, 96, 5, 3, "db4", np.float32, 10), (1024, 512, 2, 6, "db4", np.float32, 20)):
+        wt = W.wavelet(getattr(W.WT, fname))
+        td = torch.float32 if dtype == np.float32 else torch.float64
+        stride = n0 * n1 + pad
+        xs = [rng_array((n0, n1), dtype, 700 + i) for i in range(nb)]
+        for fw in (1, 0):
+            ins = xs if fw else [oracle.dwt_filter(a, wt.qmf, L) for a in xs]
+            xb = torch.full((nb * stride,), 7.0, dtype=td, device=gpu)
+            yb = torch.full((nb * stride,), -3.0, dtype=td, device=gpu)
+            for i, a in enumerate(ins):
+                xb[i * stride:i * stride + n0 * n1].copy_(torch.from_numpy(np.ascontiguousarray(a.T).ravel()))
+            h, st = W.transforms._context(gpu)
+            q = np.ascontiguousarray(wt.qmf, dtype=np.float64)
+            rc = lib.wl_dwt_filter_batch(h, 0 if dtype == np.float32 else 1, C.c_void_p(yb.data_ptr()), C.c_void_p(xb.data_ptr()),
+                                         (C.c_int64 * 2)(n0, n1), nb, stride, q.ctypes.data_as(C.POINTER(C.c_double)), len(q), L, fw, st)
+            assert rc == 0, (rc, n0, n1, fname)
+            torch.cuda.synchronize()
+            yh = yb.cpu().numpy()
+            for i, a in enumerate(ins):
+                got = yh[i * stride:i * stride + n0 * n1].reshape(n1, n0).T
+                exp = oracle.dwt_filter(a, wt.qmf, L, fw=bool(fw))
+                assert np.array_equal(got, exp), (n0, n1, fname, "fw" if fw else "inv", i, W.last_kernel())
+                assert np.all(yh[i * stride + n0 * n1:(i + 1) * stride] == -3.0), ("padding written", n0, n1, fname, fw, i)
+
+
 def test_batched_planes_lds_exchange_inverse(gpu, W, oracle):
     """k_inv2d_lds_long over blockIdx.y (round 4): batches of images (wl_dwt_filter_batch inverse) and the planes of a 3-D level --
     10 taps in Float32, 8 ... 20 taps in Float64, 12 ... 20 in Float32; the first planes of a 3-D level take their approximation
@@ -1644,6 +1679,20 @@ def test_unaligned_views(gpu, W, oracle, dtype):
         assert np.array_equal(host(W, W.dwt(xv, sch, L)), oracle.dwt_lifting(x, sch, L))
         t = buf[1:1 + n].clone()
         assert np.array_equal(host(W, W.modwt(xv, db4, 3)), oracle.modwt(x, db4.qmf, 3))
+        # packet transforms: the 16-byte kernels (k_wpt_fwd_multi / _inv_multi / _tail) must step aside too
+        for tree in (W.maketree(n, min(L, 6), "full"), min(L, 5)):
+            wo = torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
+            W.wpt_(wo, xv, db4, tree)
+            assert not W.last_kernel().startswith("k_wpt"), W.last_kernel()
+            tr = tree if not isinstance(tree, int) else W.maketree(n, tree, "full")
+            assert np.array_equal(host(W, wo), oracle.wpt_filter(x, db4.qmf, tr))
+            wi = torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
+            W.iwpt_(wi, wo, db4, tree)
+            assert np.array_equal(host(W, wi), oracle.wpt_filter(host(W, wo), db4.qmf, tr, fw=False))
+            wl = xv.clone() if False else torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
+            wl.copy_(xv)
+            W.wpt_(wl, sch, tree)
+            assert np.array_equal(host(W, wl), oracle.wpt_lifting(x, sch, tr))
         tv = torch.empty(n + 3, dtype=td, device=gpu)[1:1 + n]
         tv.copy_(xv)
         W.threshold_(tv, W.SoftTH(), 0.3)

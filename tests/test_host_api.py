@@ -51,6 +51,20 @@ def test_daubechies_values(W):
     assert np.abs(W.wavelet(W.WT.db2).qmf - db2).max() < 1e-13
 
 
+def test_daubechies_taps_are_pinned_bit_for_bit(W):
+    """daubechies(N) follows the reference's order of operations (vieta on the complex zeros, `rmul!(HH, 1/norm(HH))` on the complex
+    coefficients, `real` last: wt_main.jl:271-320); the taps of this release are pinned as hex floats so that a rewrite that moves
+    one by an ulp (and with it every db-N result) is seen.  The fixture is the implementation's own output -- a drift detector."""
+    import json
+    import os
+    from wavelets_jl_amd import wt
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "daubechies_taps_pinned.json")))["taps"]
+    for N in range(1, 11):
+        q = wt.daubechies(N)
+        assert [float(v).hex() for v in q] == pin[str(N)], N
+        assert np.array_equal(W.wavelet(getattr(W.WT, f"db{N}")).qmf, q / np.linalg.norm(q))      # the constructor renormalises (wt_main.jl:153)
+
+
 def test_qmf_pairs(W):
     f = W.wavelet(W.WT.db2)
     sc, dc = W.WT.makereverseqmfpair(f, True)

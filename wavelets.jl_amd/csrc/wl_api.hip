@@ -27,12 +27,27 @@ int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st, bool ordered)
     const size_t want = (bytes + 255) & ~(size_t)255;
     const bool pool = wl::opt("WL_WS_SYNC_ALLOC", 0) == 0;
     void *p = nullptr;
+    if (ordered) {
+        // A growth while the call's stream is being captured into a hipGraph would record alloc / free nodes and leave the context
+        // pointing at graph-owned memory that later eager calls use: refuse (reserve wl_workspace_bytes_full before capturing).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { ctx->last_hip = (int)hipErrorStreamCaptureUnsupported; return WL_EHIP; }
+    }
     if (ordered && pool && (ctx->ws == nullptr || ctx->ws_pooled)) {
         if (ctx->ws) { WL_HIP(ctx, hipFreeAsync(ctx->ws, st)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
         hipError_t e = hipMallocAsync(&p, want, st);
-        if (e != hipSuccess) { (void)hipGetLastError(); ctx->last_hip = (int)e; return WL_ENOMEM; }
-        ctx->ws = p; ctx->ws_bytes = want; ctx->ws_pooled = true;
-        return WL_OK;
+        if (e == hipSuccess) {
+            ctx->ws = p; ctx->ws_bytes = want; ctx->ws_pooled = true;
+            return WL_OK;
+        }
+        // The released block cannot be reused by the pool before the stream reaches the release, so old + new had to fit.  Fall
+        // through to the synchronising path (device sync, pool trimmed, retry) before reporting WL_ENOMEM.
+        (void)hipGetLastError();
+        hipMemPool_t mp = nullptr;
+        int dev = 0;
+        if (hipDeviceSynchronize() == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess && mp)
+            (void)hipMemPoolTrimTo(mp, 0);
+        (void)hipGetLastError();
     }
     WL_HIP(ctx, hipDeviceSynchronize());
     if (ctx->ws) {
@@ -667,7 +682,10 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
         rc = wl_stage_to_device(ctx, dtree, tree, (size_t)ncopy, st);
         if (rc) return rc;
     }
-    const bool fast = (ctx->path == 0) && opt("WL_WPT_FAST", 1) != 0;
+    // the packet kernels (k_wpt_fwd_multi / _inv_multi / _tail) move 16-byte vectors straight on x, y and the work buffer: a view that
+    // starts 4 or 8 bytes off the grid (buf[1:1+n]) takes the per-depth kernels, which gate on alignment themselves
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool fast = (ctx->path == 0) && opt("WL_WPT_FAST", 1) != 0 && al16(x) && al16(y) && al16(w.T0);
 
     if (lifting) {
         // wpt!(y, scheme, ...) is in place for the caller.  A fused lifting level cannot run in place (its [s ; d] outputs land

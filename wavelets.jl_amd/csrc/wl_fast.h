@@ -170,7 +170,7 @@ bool fwd2d_planes(hipStream_t st, const Taps<T> &taps, const T *src, T *y, int64
                   int64_t nplanes, int nll, int cu_count, hipError_t *err);
 template <typename T>
 bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
-                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel = nullptr);
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel = nullptr, int64_t dst_plane_stride = 0);
 
 // 3-D lifting transform of a cube (2^k <= 512 per side) through the axis-streaming and short-line kernels.
 template <typename T>

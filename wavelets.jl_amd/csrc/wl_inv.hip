@@ -1280,7 +1280,8 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         if (!done && path == 0 && (fastF || (F >= 12 && F <= 20)) && b.nd == 3 && b.nt == 2 && b.full.s[0] == 1 && (l == 1 || res_st.s[1] == n[0])) {
             hipError_t e = hipSuccess;
             const char *kn = nullptr;
-            done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e, &kn);
+            done = inv2d_planes<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, n[0], n[1], n[2], llsrc ? (int)n[2] : 0, cu_count, &e, &kn,
+                                   res_st.s[2]);      // (l == 1: y's own plane stride, the caller's image_stride; deeper levels: dense)
             WL_TRYI(e);
             if (done) dominant = kn;
         }
@@ -1380,18 +1381,19 @@ template bool fast_lines_inv_level<double>(hipStream_t, const Taps<double> &, co
 // -> plane p of dst (dense n0 x n1).
 template <typename T>
 bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *dst, int64_t n0, int64_t n1,
-                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel)
+                  int64_t nplanes, int nll, int cu_count, hipError_t *err, const char **kernel, int64_t dst_ps)
 {
+    if (dst_ps <= 0) dst_ps = n0 * n1;               // dense destination planes (the 3-D inverse level); a batch of images passes its own
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
     if ((F % 2) != 0 || F > 20 || n0 < 256 || (n0 % 8) != 0 || n1 < 16 || (n1 % 16) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 ||
-        !i_al16(x) || !i_al16(dst) || (ll && !i_al16(ll)) || nplanes > 65535)
+        (dst_ps % VEC) != 0 || !i_al16(x) || !i_al16(dst) || (ll && !i_al16(ll)) || nplanes > 65535)
         return false;
     // the LDS-exchange level kernel (wl_inv2d_long.hip) where it is enabled for this filter length and the batch is large
     if (i_env("WL_INVLONG2D", 1) != 0 && inv2d_long_ok(F, n0, n1, (int)sizeof(T)) && n0 >= i_env("WL_INVLONG2D_MIN_ROWS", 256) &&
         (F >= 12 || n0 * n1 * nplanes >= (int64_t)i_env("WL_INVLONG_SHORT_MIN", 1 << 22))) {
-        const InvLongBatch bt = {nplanes, x2, (n0 >> 1) * (n1 >> 1), n0 * n1, ll ? nll : 0};
+        const InvLongBatch bt = {nplanes, x2, (n0 >> 1) * (n1 >> 1), dst_ps, ll ? nll : 0};
         *err = inv2d_long_launch<T>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, bt);
         if (kernel) *kernel = "k_inv2d_lds_long";
         return true;
@@ -1400,14 +1402,14 @@ bool inv2d_planes(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, i
     if (kernel) *kernel = "k_inv2d_stream";
     bool ok = false;
     WL_DISPATCH_FI(F, *err = launch_inv2d<T, FF, 2>(st, taps, x, x1, ll, n0 >> 1, dst, n0, n0, n1, cu_count, nplanes, x2,
-                                                     (n0 >> 1) * (n1 >> 1), n0 * n1, nll);
+                                                     (n0 >> 1) * (n1 >> 1), dst_ps, nll);
                    ok = true);
     return ok;
 }
 template bool inv2d_planes<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *, int64_t,
-                                  int64_t, int64_t, int, int, hipError_t *, const char **);
+                                  int64_t, int64_t, int, int, hipError_t *, const char **, int64_t);
 template bool inv2d_planes<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *, int64_t,
-                                   int64_t, int64_t, int, int, hipError_t *, const char **);
+                                   int64_t, int64_t, int, int, hipError_t *, const char **, int64_t);
 
 template int filter_inv_levels<float>(void *, bool, int, int, hipStream_t, const BoxSpec &, float *, const float *,
                                       const Taps<float> &, int, const char **, int *);

@@ -246,10 +246,11 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
         rc = _lib.load().wl_denoise_ti_filter(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
                                               q.ctypes.data_as(C.POINTER(C.c_double)), len(q), int(L), dnt.th.code, float(dnt.t), nsv,
                                               sig, st)
-        if not (one_spin and _lib.STATUS.get(rc) == "WL_ENOMEM"):
+        if _lib.STATUS.get(rc) != "WL_ENOMEM":
             _check(rc, h)
             return y
-        # (one spin and no room for its workspace: the reference's own sequence below, which needs far less)
+        # (no room for the batch's workspace -- about ws + 2 N prod(nspin) elements, 5.5 N for one spin: the reference's own
+        #  sequence below runs the same device kernels one spin at a time and needs only the transform's two buffers)
     if (TI and isinstance(wt, GLS) and (x.dim() == 1 or (x.dim() == 2 and len(nsp) == 2)) and isinstance(dnt.th, THType)
             and dnt.th.code is not None and 0 <= dnt.th.code <= 3):
         # the same device-resident batch for a lifting scheme (wl_denoise_ti_lifting, round 4): shifted signals as one
@@ -262,10 +263,13 @@ def denoise(x, wt=_DEFAULT, L: Optional[int] = None, dnt: Optional[DNFT] = None,
         iu, nc, sh, cf = wt.flatten()
         nsl = [int(np.prod(nsp))] if x.dim() == 1 else list(nsp)
         nsv = (C.c_int64 * 3)(*(nsl + [1] * (3 - len(nsl))))
-        _check(_lib.load().wl_denoise_ti_lifting(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
-                                                 len(iu), _i32p(iu), _i32p(nc), _i32p(sh), _f64p(cf), wt.norm1, wt.norm2,
-                                                 int(L), dnt.th.code, float(dnt.t), nsv, sig, st), h)
-        return y
+        rc = _lib.load().wl_denoise_ti_lifting(h, _dtype_code(x), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), x.dim(), _dims(x),
+                                               len(iu), _i32p(iu), _i32p(nc), _i32p(sh), _f64p(cf), wt.norm1, wt.norm2,
+                                               int(L), dnt.th.code, float(dnt.t), nsv, sig, st)
+        if _lib.STATUS.get(rc) != "WL_ENOMEM":
+            _check(rc, h)
+            return y
+        # (as above: the per-spin loop below needs far less memory than the batch)
     sigma = estnoise(x, wt)
     t = sigma * dnt.t
     if TI:

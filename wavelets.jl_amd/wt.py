@@ -206,8 +206,14 @@ def daubechies(N: int) -> np.ndarray:
         pairs = np.concatenate([centre + radius, centre - radius])
         inside = pairs[np.abs(pairs) <= 1 + eps]
     zeros = np.concatenate([np.full(N, -1.0 + 0j), inside])
-    h = np.real(np.poly(zeros))                                          # monic polynomial with these zeros, highest power first
-    return (h / np.linalg.norm(h)).astype(np.float64)
+    # monic polynomial with these zeros, highest power first, kept COMPLEX (np.poly would drop the imaginary parts of conjugate
+    # pairs before the normalisation); then the reference's own order of operations (wt_main.jl:316-319):
+    # rmul!(HH, 1/norm(HH)) on the complex coefficients -- a multiplication by the reciprocal of the complex norm -- and real() last
+    c = np.ones(1, dtype=np.complex128)
+    for r in zeros:
+        c = np.concatenate([c, [0]]) - r * np.concatenate([[0], c])      # vieta (wt_main.jl:346-361): C[i+1] = C[i+1] - R[k] * C[i]
+    c = c * (1.0 / np.linalg.norm(c))
+    return np.ascontiguousarray(c.real, dtype=np.float64)
 
 
 # ---- OrthoFilter (wt_main.jl:139-163) --------------------------------------------------------

@@ -1743,3 +1743,58 @@ def test_whole_c5_batch_on_one_gpu(gpu, W):
     assert (xr - x).abs().max().item() < 1e-4
     del x, y, xr
     torch.cuda.empty_cache()
+
+
+def test_2d_array_beyond_2_31_elements(gpu, W, oracle):
+    """A 2-D transform whose element offsets do not fit 32 bits: 65536 x 49152 Float32 (3.2e9 elements, 12.9 GB; the headline
+    kernels index with int64_t -- C5's 2^32 elements only cover dwtc).  Level 1 is compared bit for bit with the reference order
+    on sampled columns whose offsets lie beyond 2^31 and 2^32 elements (dim-2 pass restated in numpy, un-fused, ascending /
+    descending tap order as wl_internal.h states it; dim-1 pass = the oracle's 1-D transform of that column); the deeper levels
+    through the exact sub-problem (the L = 14 result on the LL4 block equals the oracle run on the L = 4 result's LL4 block);
+    the whole array through the round trip."""
+    import torch
+    n0, n1 = 65536, 49152
+    assert n0 * n1 > 2 ** 31
+    g = torch.Generator(device=gpu).manual_seed(77)
+    x = torch.randn(n1, n0, generator=g, dtype=torch.float32, device=gpu).t()          # Julia layout, n0 x n1
+    assert W.is_julia_layout(x)
+    wt = W.wavelet(W.WT.db4)
+    h = wt.qmf.astype(np.float32)
+    F = len(h)
+    gg = np.array([h[m] if m % 2 == 0 else np.float32(h[m] * np.float32(-1)) for m in range(F)], dtype=np.float32)
+    y = W.dwt(x, wt, 2)
+    assert W.last_kernel() == "k_fwd2d_pair", W.last_kernel()
+    nx = n1 // 2
+
+    def col(j):
+        return x[:, j % n1].cpu().numpy()
+
+    for k in (0, 3, nx // 2 + 5, 16384 + 7, nx - 1, nx - 2):         # output column k: input columns 2k .. 2k+7 (periodic)
+        s = h[0] * col(2 * k)
+        for m in range(1, F):
+            s = s + h[m] * col(2 * k + m)
+        d = gg[F - 1] * col(2 * k + 2 - F)
+        for m in range(F - 2, -1, -1):
+            d = d + gg[m] * col(2 * k + 1 - m)
+        es = oracle.dwt_filter(s, wt.qmf, 1)
+        ed = oracle.dwt_filter(d, wt.qmf, 1)
+        # scaling column k: its detail rows (the DS quadrant) are final after level 1; detail column k: the whole column is
+        assert np.array_equal(y[n0 // 2:, k].cpu().numpy(), es[n0 // 2:]), ("ds", k)
+        assert np.array_equal(y[:, nx + k].cpu().numpy(), ed), ("sd/dd", k)
+    # deeper levels: exact sub-problem
+    y4 = W.dwt(x, wt, 4)
+    ll4 = W.to_host(y4[:n0 >> 4, :n1 >> 4])
+    del y4
+    yL = W.dwt(x, wt, 14)
+    assert np.array_equal(W.to_host(yL[:n0 >> 4, :n1 >> 4]), oracle.dwt2d_filter_mt(np.asfortranarray(ll4), wt.qmf, 10))
+    # level-1 quadrants of the deep transform equal those of the L = 2 call (they are final after level 1)
+    assert torch.equal(yL[:, nx:], y[:, nx:]) and torch.equal(yL[n0 // 2:, :nx], y[n0 // 2:, :nx])
+    del y
+    xr = W.idwt(yL, wt, 14)
+    del yL
+    num = float(torch.linalg.vector_norm((xr - x).double()))
+    den = float(torch.linalg.vector_norm(x.double()))
+    assert num / den < 1e-5, num / den
+    del xr, x
+    W.destroy_contexts()
+    torch.cuda.empty_cache()

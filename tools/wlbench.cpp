@@ -12,6 +12,7 @@
 //     check=1                print a checksum of y
 //     opt=KEY:VAL,...        wl_ctx_set_option pairs
 //     dwtc=1                 batched column-wise transform of n1 signals of length n0 (wl_dwtc_filter)
+//     rot=1                  number of distinct input arrays the calls rotate over (bench.py rotates 3 x 256 MiB for C3)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -67,7 +68,7 @@ int main(int argc, char **argv)
 {
     std::map<std::string, std::string> kv = {{"n0", "8192"}, {"n1", "8192"}, {"n2", "1"}, {"L", "0"}, {"filt", "db4"}, {"dtype", "f32"},
                                              {"fw", "1"}, {"reps", "50"}, {"warm", "20"}, {"mode", "seq"}, {"check", "1"}, {"opt", ""},
-                                             {"path", "0"}};
+                                             {"path", "0"}, {"rot", "1"}};
     for (int i = 1; i < argc; ++i) {
         const char *eq = strchr(argv[i], '=');
         if (!eq) { fprintf(stderr, "bad arg %s\n", argv[i]); return 1; }
@@ -116,17 +117,24 @@ int main(int argc, char **argv)
     }
 #endif
     void *x = nullptr, *y = nullptr;
-    CK(hipMalloc(&x, N * es));
+    const int rot = std::max(1, atoi(kv["rot"].c_str()));
+    std::vector<void *> xs(rot, nullptr);
+    for (int r = 0; r < rot; ++r) {
+        CK(hipMalloc(&xs[r], N * es));
+        if (dtype == WL_F32) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float *)xs[r], N, 42u + 977u * r);
+        else hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, (double *)xs[r], N, 42u + 977u * r);
+    }
+    x = xs[0];
     CK(hipMalloc(&y, N * es));
-    if (dtype == WL_F32) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float *)x, N, 42u);
-    else hipLaunchKernelGGL(k_fill64, dim3(4096), dim3(256), 0, 0, (double *)x, N, 42u);
     CK(hipMemset(y, 0, N * es));
     rc = wl_ctx_reserve(ctx, lifting ? wl_workspace_bytes_full(dtype, nd, dims, L) : wl_workspace_bytes(dtype, nd, dims, L));
     if (rc) { fprintf(stderr, "reserve: %s\n", wl_strerror(rc)); return 2; }
     CK(hipDeviceSynchronize());
     const bool batched = kv.count("dwtc") && atoi(kv["dwtc"].c_str()) != 0;      // dwtc=1: n1 signals of length n0 (columns)
     if (batched && atoi(kv["L"].c_str()) == 0) L = wl_maxtransformlevels(dims[0]);
+    int ncall = 0;
     auto call = [&]() {
+        x = xs[ncall++ % rot];
         if (lifting) return wl_dwt_lifting_oop(ctx, dtype, y, x, nd, dims, 4, ls_upd, ls_nc, ls_sh, ls_c, 1.1496043988603355, 0.8698644516247099, L, fw, nullptr);
         if (batched) return wl_dwtc_filter(ctx, dtype, y, x, dims[0], dims[1], dims[0], qmf.data(), (int)qmf.size(), L, fw, nullptr);
         return wl_dwt_filter(ctx, dtype, y, x, nd, dims, qmf.data(), (int)qmf.size(), L, fw, nullptr);

@@ -75,6 +75,42 @@ __device__ __forceinline__ void vstore16(T *p, const T (&v)[N])
     }
 }
 
+// N elements in chunks of at most 16 bytes, with a cache policy (NT: non-temporal, see "cache policy" below)
+template <bool NT, typename T, int N>
+__device__ __forceinline__ void ldg_pol(const T *p, T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef typename VecOf<T, C>::type V;
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+        if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p + c * C));
+        else t = *reinterpret_cast<const V *>(p + c * C);
+        if constexpr (C == 1) v[c] = t;
+        else {
+#pragma unroll
+            for (int i = 0; i < C; ++i) v[c * C + i] = t[i];
+        }
+    }
+}
+template <bool NT, typename T, int N>
+__device__ __forceinline__ void stg_pol(T *p, const T (&v)[N])
+{
+    constexpr int C = ((int)(16 / sizeof(T)) < N) ? (int)(16 / sizeof(T)) : N;
+    typedef typename VecOf<T, C>::type V;
+#pragma unroll
+    for (int c = 0; c < N / C; ++c) {
+        V t;
+        if constexpr (C == 1) t = v[c];
+        else {
+#pragma unroll
+            for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
+        }
+        if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<V *>(p + c * C));
+        else *reinterpret_cast<V *>(p + c * C) = t;
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope
 // release fence, which on gfx9 waits for every outstanding GLOBAL store (vmcnt(0)); kernels that
 // stream results to HBM between barriers and never read them back do not need that.
@@ -221,27 +257,144 @@ __device__ __forceinline__ void wg_lds_sync(bool multi)
 // two ring slots it guards, so every consumer depends on the wait through its data.
 typedef float F4 __attribute__((ext_vector_type(4)));
 typedef double D2 __attribute__((ext_vector_type(2)));
+// ---- cache policy of the streaming kernels (round 5, profiles/r05_cache_policy.md) ----
+// `nt` on a global load / store marks the line non-temporal: it streams through the XCD's L2 (and the Infinity Cache) instead of
+// displacing what is resident.  A level kernel reads every input sample once and writes every detail coefficient once, while the
+// approximation it writes is the NEXT launch's input: with the input loads (and the deeper level's detail stores) non-temporal, the
+// approximation stays in L2 for the tail kernels, and the level kernel itself no longer evicts its own halo re-reads.
+// Measured on 8192^2 f32 db4, three inputs in rotation: levels 1-2 114.5 -> 107.0 us, the whole 13-level transform 149.4 -> 128.2 us;
+// one level (k_fwd2d_lds) 108.8 -> 96.2 us.  Float64 pair kernel: +4 % slower with it, so not there.  Per call site; the WL_P_*
+// macros are the shipped choice (overridable with -D in tools/mkvariant.sh experiment builds).  Results are unaffected.
+#ifndef WL_P_PAIR_LD
+#define WL_P_PAIR_LD 1      // k_fwd2d_pair: main waves' column loads
+#endif
+#ifndef WL_P_PAIR_LDH
+#define WL_P_PAIR_LDH 0     // ... the halo wave's loads
+#endif
+#ifndef WL_P_PAIR_ST1
+#define WL_P_PAIR_ST1 0     // ... level-l detail stores
+#endif
+#ifndef WL_P_PAIR_ST2
+#define WL_P_PAIR_ST2 1     // ... level-(l+1) detail stores
+#endif
+#ifndef WL_P_LDS_LD
+#define WL_P_LDS_LD 1       // k_fwd2d_lds (Float32): column loads
+#endif
+#ifndef WL_P_LDS_ST
+#define WL_P_LDS_ST 0       // ... detail stores
+#endif
+#ifndef WL_P_LDS64_LD
+#define WL_P_LDS64_LD 0     // k_fwd2d_lds64
+#endif
+#ifndef WL_P_PAIR64_LD
+#define WL_P_PAIR64_LD 0    // k_fwd2d_pair64
+#endif
+#ifndef WL_P_LONG_LD
+#define WL_P_LONG_LD 1      // k_fwd2d_lds_long (12..20 taps): 8192^2 sym8 293.1 -> 288.9 us
+#endif
+#ifndef WL_P_TILE_LD
+#define WL_P_TILE_LD 0      // k_fwd2d_tileB: window loads
+#endif
+#ifndef WL_P_TILE_ST
+#define WL_P_TILE_ST 0      // ... detail stores
+#endif
+#ifndef WL_P_M1D_LD
+#define WL_P_M1D_LD 0       // k_fwd1d_multi: staging loads of the input tile
+#endif
+#ifndef WL_P_M1D_ST
+#define WL_P_M1D_ST 0       // ... detail stores
+#endif
+#ifndef WL_P_LIFT3_LD
+#define WL_P_LIFT3_LD 0     // k_lift1d_fwd3: input loads
+#endif
+#ifndef WL_P_LIFT3_ST
+#define WL_P_LIFT3_ST 0     // ... level-1 detail stores
+#endif
+#ifndef WL_P_LIFTI3_LD
+#define WL_P_LIFTI3_LD 1    // k_lift1d_inv3: detail loads (2^24 cdf9/7 inverse 50.9 -> 49.6 us)
+#endif
+#ifndef WL_P_LIFTI3_ST
+#define WL_P_LIFTI3_ST 0    // ... output stores
+#endif
+#ifndef WL_P_IPAIR_LD
+#define WL_P_IPAIR_LD 1     // k_inv2d_pair: coefficient loads of the level-l waves (with _ST: 8192^2 db4 idwt 155.9 -> 142.1 us)
+#endif
+#ifndef WL_P_IPAIR_LD2
+#define WL_P_IPAIR_LD2 0    // ... of the level-(l+1) wave
+#endif
+#ifndef WL_P_IPAIR_ST
+#define WL_P_IPAIR_ST 1     // ... output stores
+#endif
+#ifndef WL_P_I1D2_LD
+#define WL_P_I1D2_LD 1      // k_inv1d_stream2: detail loads (2^24 db4 inverse 56.5 -> 55.8 us)
+#endif
+#ifndef WL_P_I1D2_ST
+#define WL_P_I1D2_ST 0      // ... output stores
+#endif
+#ifndef WL_P_I2DS_LD
+#define WL_P_I2DS_LD 0      // k_inv2d_stream: coefficient loads
+#endif
+#ifndef WL_P_I2DS_ST
+#define WL_P_I2DS_ST 0      // ... output stores
+#endif
+#ifndef WL_P_ILONG_LD
+#define WL_P_ILONG_LD 1     // k_inv2d_lds_long, Float32 only: coefficient loads (with _ST: sym5 idwt 171.4 -> 161.4, sym8 246.4 -> 237.5 us;
+                            // Float64 +7 % slower with it)
+#endif
+#ifndef WL_P_ILONG_ST
+#define WL_P_ILONG_ST 1     // ... output stores
+#endif
+#ifndef WL_P_LIFT2D_LD
+#define WL_P_LIFT2D_LD 0    // k_lift2d_inv: coefficient loads
+#endif
+#ifndef WL_P_LIFT2D_ST
+#define WL_P_LIFT2D_ST 0    // ... output stores
+#endif
+#ifndef WL_P_LIFT2DF_LD
+#define WL_P_LIFT2DF_LD 0   // k_lift2d_fwd: input loads
+#endif
+#ifndef WL_P_LIFT2DF_ST
+#define WL_P_LIFT2DF_ST 0   // ... coefficient stores
+#endif
+template <bool NT, typename V>
+__device__ __forceinline__ void store_pol(V *p, const V v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V load_pol(const V *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 // V = any 16-byte vector type (F4: four Float32 rows, D2: two Float64 rows)
-template <typename V, typename T>
+template <bool NT = false, typename V, typename T>
 __device__ __forceinline__ void gload16(V &dst, const T *p)
 {
     static_assert(sizeof(V) == 16, "one global_load_dwordx4");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 // one row per lane (the halo wave of the fused pair kernel)
-template <typename T>
+template <bool NT = false, typename T>
 __device__ __forceinline__ void gload4(float &dst, const T *p)
 {
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (NT) asm volatile("global_load_dword %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+    else asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 // The same load, skipped when the wave-uniform flag is 0.  The destination is read-write for the compiler (the old contents
 // survive a skipped load), so there is no control flow -- and no phi / register copy -- around the asynchronous load.
-template <typename V, typename T>
+template <bool NT = false, typename V, typename T>
 __device__ __forceinline__ void gload16_if(V &dst, const T *p, int flag)
 {
     static_assert(sizeof(V) == 16, "one global_load_dwordx4");
-    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwl_skip%=\n\tglobal_load_dwordx4 %0, %1, off\n.Lwl_skip%=:"
-                 : "+v"(dst) : "v"(p), "s"(flag) : "memory", "scc");
+    if constexpr (NT)
+        asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwl_skip%=\n\tglobal_load_dwordx4 %0, %1, off nt\n.Lwl_skip%=:"
+                     : "+v"(dst) : "v"(p), "s"(flag) : "memory", "scc");
+    else
+        asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 .Lwl_skip%=\n\tglobal_load_dwordx4 %0, %1, off\n.Lwl_skip%=:"
+                     : "+v"(dst) : "v"(p), "s"(flag) : "memory", "scc");
 }
 // "at most N vector-memory operations outstanding".  Loads return in issue order among themselves, so this covers every load
 // that has at least N younger LOADS behind it.  Do not count younger stores towards N: round 3 measured (one transform in

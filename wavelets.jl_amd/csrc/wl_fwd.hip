@@ -584,7 +584,7 @@ __device__ __forceinline__ void multi1d_levels(const Multi1DArgs<T, F> &a, const
             const int io = i - H[t];                  // pair i + q is owned iff 0 <= io + q < ownt
             if (quads && mis == 0) {
                 if (io >= 0 && io + PPT <= ownt) {
-                    vstore16<T, PPT>(dd + k0 + io, dO);
+                    stg_pol<WL_P_M1D_ST != 0, T, PPT>(dd + k0 + io, dO);
                     if (lastlev) vstore16<T, PPT>(sg + k0 + io, so);
                 }
             } else if (quads && PPT == 4 && mis == 2) {
@@ -595,7 +595,7 @@ __device__ __forceinline__ void multi1d_levels(const Multi1DArgs<T, F> &a, const
                 const int ia = io + 2;
                 if (lane != 63) {
                     if (ia >= 0 && ia + 4 <= ownt) {
-                        vstore16<T, 4>(dd + k0 + ia, q4);
+                        stg_pol<WL_P_M1D_ST != 0, T, 4>(dd + k0 + ia, q4);
                         if (lastlev) vstore16<T, 4>(sg + k0 + ia, s4);
                     }
                 } else if (ia >= 0 && ia + 2 <= ownt) {   // (the completing lane belongs to another wave: two 8-byte halves)
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(256) k_fwd1d_multi(Multi1DArgs<T, F> a)
                     int64_t gidx = astart + (int64_t)c * VEC;
                     if (gidx < 0) gidx += n;
                     if (gidx >= n) gidx -= n;
-                    vload<T, VEC>(src + gidx, v[u]);
+                    ldg_pol<WL_P_M1D_LD != 0, T, VEC>(src + gidx, v[u]);
                 }
             }
 #pragma unroll

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
     for (int c = 0; c < R - 2; ++c) {
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
-        gload16(ring[c], base + jc * a.lds);
+        gload16<WL_P_LONG_LD != 0>(ring[c], base + jc * a.lds);
     }
 #pragma unroll
     for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
-                gload16_if(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds, prefetch);
+                gload16_if<WL_P_LONG_LD != 0>(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds, prefetch);
             }
             // loads only in the count (wl_dev.h); once the prefetch has stopped, fewer than 2 PFD loads are behind: drain.  One
             // asm statement, not an `if` around two waits: see wait_vm_sel

@@ -588,8 +588,8 @@ __global__ void __launch_bounds__(256) k_inv1d_stream2(Inv1D2Args<T, F> a)
         if (kw >= nx2) kw -= nx2;
         T sv[2], dv[2], d1v[4];
         ldn<T, 2>(s2 + kw, sv);
-        ldn<T, 2>(d2 + kw, dv);
-        ldn<T, 4>(d1 + 2 * kw, d1v);
+        ldg_pol<WL_P_I1D2_LD != 0, T, 2>(d2 + kw, dv);
+        ldg_pol<WL_P_I1D2_LD != 0, T, 4>(d1 + 2 * kw, d1v);
         // deeper level: pairs kw, kw+1 -> a1[0..3]
         T sx2[2 + SH], dx2[2 + SH];
 #pragma unroll
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256) k_inv1d_stream2(Inv1D2Args<T, F> a)
         T out[8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) inv_pair<T, F>(&sx1[p], &dx1[p], a.tp, out[2 * p], out[2 * p + 1]);
-        if (lane >= HL && lane < 64 - HR && k2 < nx2) stn<T, 8>(dst + 4 * k2, out);
+        if (lane >= HL && lane < 64 - HR && k2 < nx2) stg_pol<WL_P_I1D2_ST != 0, T, 8>(dst + 4 * k2, out);
     }
 }
 
@@ -745,10 +745,10 @@ __global__ void __launch_bounds__(64, (F == 10 && sizeof(T) == 4 && PPL == 2) ? 
         if (js < 0) js += h1;
         int64_t jd = p0 + t + SH;
         if (jd >= h1) jd -= h1;
-        ldn<T, PPL>(ls_base + js * ls_ld, rLs[slot]);
-        ldn<T, PPL>(ld_base + js * a.ldx, rLd[slot]);
-        ldn<T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
-        ldn<T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
+        ldg_pol<WL_P_I2DS_LD != 0, T, PPL>(ls_base + js * ls_ld, rLs[slot]);
+        ldg_pol<WL_P_I2DS_LD != 0, T, PPL>(ld_base + js * a.ldx, rLd[slot]);
+        ldg_pol<WL_P_I2DS_LD != 0, T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
+        ldg_pol<WL_P_I2DS_LD != 0, T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
     };
     // prologue: steps -SH .. -1 fill the reconstructed rings; their raw columns pass through slots (c - SH) mod 4
 #pragma unroll
@@ -776,8 +776,8 @@ __global__ void __launch_bounds__(64, (F == 10 && sizeof(T) == 4 && PPL == 2) ? 
         }
         if (store) {
             const int64_t p = p0 + t;
-            stn<T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
-            stn<T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
+            stg_pol<WL_P_I2DS_ST != 0, T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
+            stg_pol<WL_P_I2DS_ST != 0, T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
         }
     };
     int t0 = 0;
@@ -888,10 +888,10 @@ __global__ void __launch_bounds__(192, MW) k_inv2d_pair(InvPairArgs<F> a)
             int64_t jd = p0a + t + SH;
             if (jd < 0) jd += h1a;
             if (jd >= h1a) jd -= h1a;
-            ldn<T, PPL>(ls_base + js * ls_ld, rLs[slot]);
-            ldn<T, PPL>(ld_base + js * a.ldx, rLd[slot]);
-            ldn<T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
-            ldn<T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
+            ldg_pol<WL_P_IPAIR_LD2 != 0, T, PPL>(ls_base + js * ls_ld, rLs[slot]);
+            ldg_pol<WL_P_IPAIR_LD2 != 0, T, PPL>(ld_base + js * a.ldx, rLd[slot]);
+            ldg_pol<WL_P_IPAIR_LD2 != 0, T, PPL>(rs_base + jd * a.ldx, rRs[slot]);
+            ldg_pol<WL_P_IPAIR_LD2 != 0, T, PPL>(rd_base + jd * a.ldx, rRd[slot]);
         };
 #pragma unroll
         for (int c = 0; c < SH; ++c) load_raw(c - SH, (c - SH + R) % R);
@@ -951,9 +951,9 @@ __global__ void __launch_bounds__(192, MW) k_inv2d_pair(InvPairArgs<F> a)
         if (js < 0) js += h1;
         int64_t jd = p0 + t + SH;
         if (jd >= h1) jd -= h1;
-        ldn<T, PPL>(ld_base + js * a.ldx, ld);
-        ldn<T, PPL>(rs_base + jd * a.ldx, rs);
-        ldn<T, PPL>(rd_base + jd * a.ldx, rd);
+        ldg_pol<WL_P_IPAIR_LD != 0, T, PPL>(ld_base + js * a.ldx, ld);
+        ldg_pol<WL_P_IPAIR_LD != 0, T, PPL>(rs_base + jd * a.ldx, rs);
+        ldg_pol<WL_P_IPAIR_LD != 0, T, PPL>(rd_base + jd * a.ldx, rd);
     };
     T pLd[SH > 0 ? SH : 1][PPL], pRs[SH > 0 ? SH : 1][PPL], pRd[SH > 0 ? SH : 1][PPL];      // raw columns of the prologue steps
 #pragma unroll
@@ -992,8 +992,8 @@ __global__ void __launch_bounds__(192, MW) k_inv2d_pair(InvPairArgs<F> a)
             }
             if (store) {
                 const int64_t p = p0 + t;
-                stn<T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
-                stn<T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
+                stg_pol<WL_P_IPAIR_ST != 0, T, 2 * PPL>(out + (2 * p) * a.ldd, xe);
+                stg_pol<WL_P_IPAIR_ST != 0, T, 2 * PPL>(out + (2 * p + 1) * a.ldd, xo);
             }
         }
     }

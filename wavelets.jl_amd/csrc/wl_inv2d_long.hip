@@ -97,7 +97,7 @@ __device__ __forceinline__ void store4(T *p, const T (&v)[4])
         V t;
 #pragma unroll
         for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
-        *reinterpret_cast<V *>(p + c * C) = t;
+        store_pol<(WL_P_ILONG_ST != 0 && sizeof(T) == 4)>(reinterpret_cast<V *>(p + c * C), t);
     }
 }
 
@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(64 * W, (sizeof(T) == 8 && F >= 14) ? 1 : 2) k
 
     T raw[D][4][PPL];                                         // requests in flight: D steps ahead
     auto ldp = [&](const T *q, T (&v)[PPL]) __attribute__((always_inline)) {
-        if constexpr (PPL == 2) { const T2 t2 = *reinterpret_cast<const T2 *>(q); v[0] = t2.x; v[1] = t2.y; }
-        else v[0] = *q;
+        if constexpr (PPL == 2) { const T2 t2 = load_pol<(WL_P_ILONG_LD != 0 && sizeof(T) == 4)>(reinterpret_cast<const T2 *>(q)); v[0] = t2.x; v[1] = t2.y; }
+        else v[0] = load_pol<(WL_P_ILONG_LD != 0 && sizeof(T) == 4)>(q);
     };
     auto stp = [&](T *q, const T (&v)[PPL]) __attribute__((always_inline)) {
         if constexpr (PPL == 2) *reinterpret_cast<T2 *>(q) = T2{v[0], v[1]};

@@ -18,6 +18,7 @@
 // x += c1*a; x += c2*b; ... (lift_perboundary!, :437-451); no FMA contraction.
 #include "wl_fast.h"
 #include "wl_lift_shapes.h"
+#include "wl_dev.h"
 
 
 namespace wl {
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256) k_lift1d_fwd3(Lift3Args<T> a)
         if (kw < 0) kw += half;
         if (kw >= half) kw -= half;
         T v[8];
-        ld8<T>(a.src + line * a.src_ls + 2 * kw, v);
+        ldg_pol<WL_P_LIFT3_LD != 0, T, 8>(a.src + line * a.src_ls + 2 * kw, v);
         T s1[4], d1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[j] = v[2 * j]; d1[j] = v[2 * j + 1]; }
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(256) k_lift1d_fwd3(Lift3Args<T> a)
         d3[0] = s2[1] * a.norm1;
         lift_steps_lane<T, ID, 1>(s3, d3, a.c, kw >> 2, half >> 2);
         if (lane >= ML && lane < 64 - ML && k0 < half) {
-            stN<T, 4>(a.d1 + line * a.d1_ls + k0, dO1);
+            stg_pol<WL_P_LIFT3_ST != 0, T, 4>(a.d1 + line * a.d1_ls + k0, dO1);
             typedef T V2 __attribute__((ext_vector_type(2)));
             V2 t2; t2[0] = dO2[0]; t2[1] = dO2[1];
             *reinterpret_cast<V2 *>(a.y + line * a.y_ls + (n >> 2) + (k0 >> 1)) = t2;
@@ -367,8 +368,8 @@ __global__ void __launch_bounds__(256) k_lift1d_inv3(LiftInv3Args<T> a)
         T s3[1], d3[1], d2[2], d1[4];
         s3[0] = a.norm1 * a.s3[line * a.s3_ls + kw];
         d3[0] = a.norm2 * x[h3 + kw];
-        ldv_l<T, 2>(x + 2 * h3 + 2 * kw, d2);
-        ldv_l<T, 4>(x + 4 * h3 + 4 * kw, d1);
+        ldg_pol<WL_P_LIFTI3_LD != 0, T, 2>(x + 2 * h3 + 2 * kw, d2);
+        ldg_pol<WL_P_LIFTI3_LD != 0, T, 4>(x + 4 * h3 + 4 * kw, d1);
         lift_steps_lane<T, ID, 1>(s3, d3, a.c, kw, h3);
         T s2[2], d2n[2];
         s2[0] = a.norm1 * s3[0]; s2[1] = a.norm1 * d3[0];                 // merge!, then normalize! of the next level
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(256) k_lift1d_inv3(LiftInv3Args<T> a)
         T out[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { out[2 * j] = s1[j]; out[2 * j + 1] = d1n[j]; }
-        if (lane >= ML && lane < 64 - ML && k3 < h3) stv_l<T, 8>(a.dst + line * a.o_ls + 8 * k3, out);
+        if (lane >= ML && lane < 64 - ML && k3 < h3) stg_pol<WL_P_LIFTI3_ST != 0, T, 8>(a.dst + line * a.o_ls + 8 * k3, out);
     }
 }
 
@@ -2438,8 +2439,8 @@ __device__ __forceinline__ void lift2d_fwd_body(const Lift2DArgs<T> &a)
     };
     auto load_pair = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
         const int64_t iw = wrapi(tau);
-        ldv_l<T, RPL>(base + (2 * iw) * a.lds, rs[slot]);
-        ldv_l<T, RPL>(base + (2 * iw + 1) * a.lds, rd[slot]);
+        ldg_pol<WL_P_LIFT2DF_LD != 0, T, RPL>(base + (2 * iw) * a.lds, rs[slot]);
+        ldg_pol<WL_P_LIFT2DF_LD != 0, T, RPL>(base + (2 * iw + 1) * a.lds, rd[slot]);
     };
 #pragma unroll
     for (int c = 0; c < PF; ++c) load_pair(tau0 + c, c % R);
@@ -2508,11 +2509,11 @@ __device__ __forceinline__ void lift2d_fwd_body(const Lift2DArgs<T> &a)
             }
             if (valid) {
                 if (!odd) {
-                    stv_l<T, 4>(llp + k0 + io * ldl, o0);                      // LL rows k0..k0+3
-                    stv_l<T, 4>(yb + h0 + k0 + io * a.ldy, o1);                // HL
+                    stg_pol<false, T, 4>(llp + k0 + io * ldl, o0);                                     // LL rows k0..k0+3
+                    stg_pol<WL_P_LIFT2DF_ST != 0, T, 4>(yb + h0 + k0 + io * a.ldy, o1);                // HL
                 } else {
-                    stv_l<T, 4>(yb + (k0 - 2) + (h1 + io) * a.ldy, o0);        // LH rows k0-2..k0+1
-                    stv_l<T, 4>(yb + h0 + (k0 - 2) + (h1 + io) * a.ldy, o1);   // HH
+                    stg_pol<WL_P_LIFT2DF_ST != 0, T, 4>(yb + (k0 - 2) + (h1 + io) * a.ldy, o0);        // LH rows k0-2..k0+1
+                    stg_pol<WL_P_LIFT2DF_ST != 0, T, 4>(yb + h0 + (k0 - 2) + (h1 + io) * a.ldy, o1);   // HH
                 }
             }
         }
@@ -2591,10 +2592,10 @@ __device__ __forceinline__ void lift2d_inv_body(const Lift2DArgs<T> &a)
     };
     auto load_raw = [&](const int64_t tau, const int slot) __attribute__((always_inline)) {
         const int64_t iw = wrapi(tau);
-        ldv_l<T, 2>(ls_base + iw * ls_ld, qLs[slot]);
-        ldv_l<T, 2>(ld_base + iw * a.lds, qLd[slot]);
-        ldv_l<T, 2>(rs_base + iw * a.lds, qRs[slot]);
-        ldv_l<T, 2>(rd_base + iw * a.lds, qRd[slot]);
+        ldg_pol<WL_P_LIFT2D_LD != 0, T, 2>(ls_base + iw * ls_ld, qLs[slot]);
+        ldg_pol<WL_P_LIFT2D_LD != 0, T, 2>(ld_base + iw * a.lds, qLd[slot]);
+        ldg_pol<WL_P_LIFT2D_LD != 0, T, 2>(rs_base + iw * a.lds, qRs[slot]);
+        ldg_pol<WL_P_LIFT2D_LD != 0, T, 2>(rd_base + iw * a.lds, qRd[slot]);
     };
 #pragma unroll
     for (int c = 0; c < PF; ++c) load_raw(tau0 + c, c % R);
@@ -2647,8 +2648,8 @@ __device__ __forceinline__ void lift2d_inv_body(const Lift2DArgs<T> &a)
         const int64_t io = tau - DL;
         if (valid && io >= p0 && io < pend) {
             const int slot = ((u - DL) % R + R) % R;
-            stv_l<T, RPL>(yb + gi + (2 * io) * a.ldy, rs[slot]);
-            stv_l<T, RPL>(yb + gi + (2 * io + 1) * a.ldy, rd[slot]);
+            stg_pol<WL_P_LIFT2D_ST != 0, T, RPL>(yb + gi + (2 * io) * a.ldy, rs[slot]);
+            stg_pol<WL_P_LIFT2D_ST != 0, T, RPL>(yb + gi + (2 * io + 1) * a.ldy, rd[slot]);
         }
     };
     const int64_t nstep = (pend - p0) + VM + DL;

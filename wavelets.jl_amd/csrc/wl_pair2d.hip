@@ -183,14 +183,14 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                 }
                 if constexpr (HS == 4) {
                     *reinterpret_cast<T4 *>(cl + s2row) = T4{P[0].x, P[1].x, P[2].x, P[3].x};
-                    *reinterpret_cast<T4 *>(ck + (hm2i + d2row)) = T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x};
-                    *reinterpret_cast<T4 *>(ckd + s2row) = T4{P[0].y, P[1].y, P[2].y, P[3].y};
-                    *reinterpret_cast<T4 *>(ckd + (hm2i + d2row)) = T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y};
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ck + (hm2i + d2row)), T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x});
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ckd + s2row), T4{P[0].y, P[1].y, P[2].y, P[3].y});
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ckd + (hm2i + d2row)), T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y});
                 } else {
                     *reinterpret_cast<T2 *>(cl + s2row) = T2{P[0].x, P[1].x};
-                    *reinterpret_cast<T2 *>(ck + (hm2i + d2row)) = T2{Q[0].x, Q[1].x};
-                    *reinterpret_cast<T2 *>(ckd + s2row) = T2{P[0].y, P[1].y};
-                    *reinterpret_cast<T2 *>(ckd + (hm2i + d2row)) = T2{Q[0].y, Q[1].y};
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
+                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
                 }
             }
         }
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
             int64_t jc = j0 + c;
             if (jc >= ns) jc -= ns;
             if (BT) { jc -= crot; if (jc < 0) jc += ns; }
-            gload4(hring[c], hbase + jc * a.lds);
+            gload4<WL_P_PAIR_LDH != 0>(hring[c], hbase + jc * a.lds);
         }
 #pragma unroll
         for (int c = 0; c < R; c += 2) wait_vm<0>(hring[c], hring[c + 1]);
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     if (jc >= ns) jc -= ns;
                     if (jc >= ns) jc -= ns;
                     if (BT) { jc -= crot; if (jc < 0) jc += ns; }
-                    gload4(hring[(2 * u + R - 2 + e) % R], hbase + jc * a.lds);
+                    gload4<WL_P_PAIR_LDH != 0>(hring[(2 * u + R - 2 + e) % R], hbase + jc * a.lds);
                 }
             }
             if (produce) {
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
         if (BT) { jc -= crot; if (jc < 0) jc += ns; }
-        gload16(ring[c], base + jc * a.lds);
+        gload16<WL_P_PAIR_LD != 0>(ring[c], base + jc * a.lds);
     }
 #pragma unroll
     for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
                 if (BT) { jc -= crot; if (jc < 0) jc += ns; }
-                gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
+                gload16<WL_P_PAIR_LD != 0>(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
             }
         }
         if (produce) {
@@ -431,10 +431,10 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         }
         T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy;      // (uniform)
         if (!odd) {
-            *reinterpret_cast<T4 *>(ck + (hmi + kod)) = T4{Q[0].x, Q[1].x, rA[0], rA[1]};
+            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ck + (hmi + kod)), T4{Q[0].x, Q[1].x, rA[0], rA[1]});
         } else {
-            *reinterpret_cast<T4 *>(ckd + (ko - 2)) = T4{rA[0], rA[1], P[0].y, P[1].y};
-            *reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)) = T4{rB[0], rB[1], Q[0].y, Q[1].y};
+            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ckd + (ko - 2)), T4{rA[0], rA[1], P[0].y, P[1].y});
+            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)), T4{rB[0], rB[1], Q[0].y, Q[1].y});
         }
     };
 

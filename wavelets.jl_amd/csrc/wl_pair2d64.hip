@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
     for (int c = 0; c < R - 2; ++c) {
         int64_t jc = j0 + c;
         if (jc >= ns) jc -= ns;
-        gload16(ring[c], base + jc * a.lds);
+        gload16<WL_P_PAIR64_LD != 0>(ring[c], base + jc * a.lds);
     }
 #pragma unroll
     for (int c = 0; c < R; c += 2) wait_vm<0>(ring[c], ring[c + 1]);
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
                 int64_t jc = j0 + 2 * t + (R - 2) + e;
                 if (jc >= ns) jc -= ns;
                 if (jc >= ns) jc -= ns;
-                gload16(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
+                gload16<WL_P_PAIR64_LD != 0>(ring[(2 * u + R - 2 + e) % R], base + jc * a.lds);
             }
         }
         if (produce) {

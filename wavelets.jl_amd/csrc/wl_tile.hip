@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
             for (int m = 0; m < NC; ++m) {
                 int c = gc + m;
                 if (c >= a.N) c -= a.N;
-                xw[m] = *reinterpret_cast<const F4t *>(a.src + gr + (int64_t)c * a.lds);
+                xw[m] = load_pol<WL_P_TILE_LD != 0>(reinterpret_cast<const F4t *>(a.src + gr + (int64_t)c * a.lds));
             }
 #pragma unroll
             for (int kk = 0; kk < KG; ++kk) {
@@ -254,8 +254,8 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
                 int rd = r0h + 4 * q + 4;
                 if (rd >= hm) rd -= hm;
                 T *yc = a.y + col * a.ldy;
-                *reinterpret_cast<F4t *>(yc + hm + rd) = dO;                  // ds or dd
-                if (!is_s) *reinterpret_cast<F4t *>(yc + (r0h + 4 * q)) = so;  // sd
+                store_pol<WL_P_TILE_ST != 0>(reinterpret_cast<F4t *>(yc + hm + rd), dO);                  // ds or dd
+                if (!is_s) store_pol<WL_P_TILE_ST != 0>(reinterpret_cast<F4t *>(yc + (r0h + 4 * q)), so);  // sd
             }
         }
     }

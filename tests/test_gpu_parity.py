@@ -1414,6 +1414,69 @@ def test_wpt_bitexact(gpu, W, oracle, dtype):
         W.wpt(dev(W, x), wt, bad)
 
 
+def _random_tree(W, n, depth, rs, p=0.6):
+    nn = 2 ** W.maxtransformlevels(n) - 1
+    t = np.zeros(nn, dtype=np.uint8)
+    t[0] = 1
+    for i in range(1, min(nn, 2 ** depth - 1)):
+        t[i] = 1 if (t[(i + 1) // 2 - 1] and rs.random() < p) else 0
+    return t
+
+
+def test_wpt_partial_trees_on_the_packet_kernels(gpu, W, oracle):
+    """Round 5: partially split trees (`maketree(n, L, :dwt)`, best-basis-like random trees) take the fused packet kernels too --
+    the node bits travel as a per-segment split mask, leaves are passed through inside the launch (transforms_filter.jl:325-356,
+    util_main.jl:301-344).  Bit-equal to the oracle in both directions, `last_kernel` pins the tier, and at 2^22 a dwt-shaped and a
+    random tree of depth 9 run within 1.5 x of the full tree of the same depth."""
+    import torch
+    rs = np.random.default_rng(21)
+    cases = []
+    for n, dtype, depth in ((1 << 18, np.float32, 7), (1 << 16, np.float64, 9), (1 << 14, np.float32, 14), (1 << 12, np.float32, 12),
+                            (3 << 14, np.float32, 4), (1 << 20, np.float32, 5)):
+        trees = [("dwt", W.maketree(n, depth, "dwt")), ("rand", _random_tree(W, n, depth, rs)), ("rand-sparse", _random_tree(W, n, depth, rs, 0.35))]
+        cases.append((n, dtype, depth, trees))
+    for n, dtype, depth, trees in cases:
+        x = rng_array((n,), dtype, n % 977)
+        for tag, tree in trees:
+            assert W.isvalidtree(np.zeros(n), tree)
+            for fname in ("db4", "haar", "sym5"):
+                wt = W.wavelet(getattr(W.WT, fname))
+                ye = oracle.wpt_filter(x, wt.qmf, tree)
+                y = host(W, W.wpt(dev(W, x), wt, tree))
+                kf = W.last_kernel()
+                assert np.array_equal(y, ye), (n, tag, fname, kf)
+                assert kf.startswith("k_wpt_fwd"), (n, tag, fname, kf)
+                xr = host(W, W.iwpt(dev(W, ye), wt, tree))
+                ki = W.last_kernel()
+                assert np.array_equal(xr, oracle.wpt_filter(ye, wt.qmf, tree, fw=False)), (n, tag, fname, ki)
+                if n & (n - 1) == 0:
+                    assert ki.startswith("k_wpt_inv"), (n, tag, fname, ki)
+    # timing at 2^22, depth 9
+    n, depth = 1 << 22, 9
+    wt = W.wavelet(W.WT.db4)
+    x = torch.randn(n, dtype=torch.float32, device=gpu)
+    y = W.similar(x)
+
+    def t_us(tree, inverse=False):
+        f = (lambda: W.iwpt_(y, x, wt, tree)) if inverse else (lambda: W.wpt_(y, x, wt, tree))
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(30):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 30 * 1e3
+    full = W.maketree(n, depth, "full")
+    for inverse in (False, True):
+        tf = t_us(full, inverse)
+        td = t_us(W.maketree(n, depth, "dwt"), inverse)
+        tr = t_us(_random_tree(W, n, depth, rs), inverse)
+        assert td <= 1.5 * tf + 10 and tr <= 1.5 * tf + 10, (inverse, tf, td, tr)      # (+10 us: the staged copy of the node bits)
+
+
 def test_wpt_fast_paths_bitexact_and_pinned(gpu, W, oracle):
     """Round 4: fully split depths run on k_wpt_fwd_multi (up to 3 depths per pass over HBM) and k_wpt_fwd_tail / k_wpt_inv_tail
     (every depth of the segments that fit a workgroup in ONE launch), lifting depths on the fused line kernel -- bit-equal to the

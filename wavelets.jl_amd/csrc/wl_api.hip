@@ -733,10 +733,15 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     std::vector<Step> plan;
     const int F = taps->F;
     const int TSw = wpt_tile_samples<T>();
+    // round 5: the packet kernels take the node bits (per-segment split mask), so partially split depths (a dwt-shaped tree, a best-basis
+    // tree) ride the same fused passes -- leaves are passed through inside the launch -- instead of one generic launch per depth
+    const uint8_t *pmask = any_partial ? dtree : nullptr;
     for (int i = 0; i < K;) {
         const int d = depths[i];
-        int run = 0;                                     // fully split depths d, d +- 1, ... in processing order
-        while (fast && i + run < K && kind[i + run] == 2 && depths[i + run] == (fw ? d + run : d - run)) ++run;
+        int run = 0;                                     // consecutive depths d, d +- 1, ... in processing order (fully or partially split)
+        while (fast && i + run < K && depths[i + run] == (fw ? d + run : d - run)) ++run;
+        bool run_partial = false;
+        for (int k = 0; k < run; ++k) run_partial = run_partial || kind[i + k] != 2;
         if (run >= 1 && fw) {
             const int64_t nj = n >> d;
             if (wpt_tail_ok<T>(F, n, nj, run)) { plan.push_back({2, d, run}); i += run; continue; }
@@ -747,7 +752,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             const int stages = (lim + 2) / 3;
             int NL = (lim + stages - 1) / stages;
             while (NL >= 1 && !wpt_fwd_multi_ok<T>(F, n, nj, NL)) --NL;
-            if (NL >= 1 && (NL > 1 || opt("WL_WPT_MULTI1", 0))) { plan.push_back({1, d, NL}); i += NL; continue; }
+            if (NL >= 1 && (NL > 1 || run_partial || opt("WL_WPT_MULTI1", 0))) { plan.push_back({1, d, NL}); i += NL; continue; }
         } else if (run >= 1 && !fw) {
             // deepest first: take every depth of the run whose segments still fit a workgroup
             int nd = 0;
@@ -756,8 +761,9 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             // big segments: up to three depths per pass (k_wpt_inv_multi), the run split evenly over the fewest launches
             const int stages = (run + 2) / 3;
             int NL = (run + stages - 1) / stages;
-            while (NL >= 2 && !wpt_inv_multi_ok<T>(F, n, n >> (d - NL + 1), NL)) --NL;
-            if (NL >= 2) { plan.push_back({3, d - NL + 1, NL}); i += NL; continue; }
+            const int nlmin = run_partial ? 1 : 2;
+            while (NL >= nlmin && !wpt_inv_multi_ok<T>(F, n, n >> (d - NL + 1), NL)) --NL;
+            if (NL >= nlmin) { plan.push_back({3, d - NL + 1, NL}); i += NL; continue; }
         }
         plan.push_back({0, d, 1});
         ++i;
@@ -770,13 +776,13 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
         const int d = sp.d;
         T *out = ((P - 1 - i) % 2 == 0) ? y : w.T0;
         if (sp.kindk == 1) {
-            WL_HIP(ctx, wpt_fwd_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd));
+            WL_HIP(ctx, wpt_fwd_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd, pmask));
             name = "k_wpt_fwd_multi";
         } else if (sp.kindk == 3) {
-            WL_HIP(ctx, wpt_inv_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd));
+            WL_HIP(ctx, wpt_inv_multi_launch<T>(st, *taps, cur, out, n, n >> d, sp.nd, pmask));
             name = "k_wpt_inv_multi";
         } else if (sp.kindk == 2) {
-            WL_HIP(ctx, wpt_tail_launch<T>(st, *taps, fw, cur, out, n, n >> d, sp.nd));
+            WL_HIP(ctx, wpt_tail_launch<T>(st, *taps, fw, cur, out, n, n >> d, sp.nd, pmask));
             if (std::strncmp(name, "k_wpt", 5) != 0) name = fw ? "k_wpt_fwd_tail" : "k_wpt_inv_tail";
         } else {
             const int64_t nj = n >> d, nseg = (int64_t)1 << d;

@@ -196,10 +196,10 @@ hipError_t inv2d_long_launch(hipStream_t st, const Taps<T> &taps, const T *x, in
 // ---- fully split depths of the packet transform (wl_wpt.hip) ----
 template <typename T> int wpt_tile_samples();
 template <typename T> bool wpt_fwd_multi_ok(int F, int64_t n, int64_t nj, int NL);
-template <typename T> hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL);
+template <typename T> hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask = nullptr);
 template <typename T> bool wpt_inv_multi_ok(int F, int64_t n, int64_t nj, int NL);
-template <typename T> hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL);
+template <typename T> hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask = nullptr);
 template <typename T> bool wpt_tail_ok(int F, int64_t n, int64_t nj, int ndepth);
-template <typename T> hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth);
+template <typename T> hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth, const uint8_t *mask = nullptr);
 
 }  // namespace wl

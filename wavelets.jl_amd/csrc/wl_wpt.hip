@@ -29,6 +29,10 @@ struct WptMultiArgs {
     int NL, TS;
     int bs[4];                      // band stride in LDS at fused level t (elements, multiple of 16 bytes)
     int buf_elems;                  // elements per LDS buffer
+    // partially split trees (round 5): node bits of the whole tree on the device (one byte per node, node (2^D - 1) + p = segment p
+    // of depth D; nullptr: every segment of every fused depth splits) and the depth of the first fused level.  A valid tree has no
+    // set node below an unset one, so "bit clear" means "this region is (part of) a leaf: pass it through".
+    const uint8_t *mask; int depth;
     TapsF<T, F> tp;
 };
 
@@ -104,9 +108,29 @@ __global__ void __launch_bounds__(256) k_wpt_fwd_multi(WptMultiArgs<T, F> a)
         // leaves: band b of the root segment lives at root * nj + b * (nj >> NL), this tile's piece at (r0 >> NL)
         const int64_t leaf = a.nj >> NL;
         T *out0 = a.dst + root * a.nj + (r0 >> NL);
+        const int64_t segb = root << (t - 1);                             // first segment of depth a.depth + t - 1 under this root
         for (int g = tid; g < total; g += 256) {
             const int b = g / gpb;
             const int i = (g - b * gpb) * PPT;
+            if (a.mask) {
+                // live: every ancestor of parent band b inside this launch splits; bit: the band itself splits
+                bool live = true;
+                for (int u = 1; u < t; ++u)
+                    live = live && a.mask[(((int64_t)1 << (a.depth + u - 1)) - 1) + (root << (u - 1)) + (b >> (t - u))] != 0;
+                if (!live) continue;
+                if (a.mask[(((int64_t)1 << (a.depth + t - 1)) - 1) + segb + b] == 0) {
+                    // a leaf of the tree: its owned samples (parent-band local index 2 (i + q) + F - 2 <-> owned pair i + q - H[t]) go out as they are
+                    typedef typename VecOf<T, 2>::type P2;
+                    T *lo = a.dst + root * a.nj + (int64_t)b * (a.nj >> (t - 1)) + (r0 >> (t - 1));
+#pragma unroll
+                    for (int q = 0; q < PPT; ++q) {
+                        const int io = i + q - H[t];
+                        if (io >= 0 && io < ownt)
+                            *reinterpret_cast<P2 *>(lo + 2 * io) = *reinterpret_cast<const P2 *>(Ain + b * bsi + 2 * (i + q) + F - 2);
+                    }
+                    continue;
+                }
+            }
             T xv[NWIN];
             vload16<T, NWIN>(Ain + b * bsi + 2 * i, xv);                  // window of pairs i .. i+PPT-1 of parent band b
             T so[PPT], dO[PPT];
@@ -148,6 +172,7 @@ struct WptInvMultiArgs {
     int G[4];                       // halo (samples per side) of a band at fused level t
     int bs[4];                      // band stride in LDS at fused level t
     int buf_elems;
+    const uint8_t *mask; int depth; // as WptMultiArgs; depth = the SHALLOWEST fused depth
     TapsF<T, F> tp;
 };
 
@@ -198,6 +223,25 @@ __global__ void __launch_bounds__(256) k_wpt_inv_multi(WptInvMultiArgs<T, F> a)
         for (int g = tid; g < total; g += 256) {
             const int b = g / gpb;
             const int q0 = (g - b * gpb) * PPT;
+            if (a.mask && a.mask[(((int64_t)1 << (a.depth + t - 1)) - 1) + (root << (t - 1)) + b] == 0) {
+                // parent band b is (part of) a leaf: its samples are taken from the source as they are -- local pair q <-> element
+                // (r0 >> (t-1)) - G[t-1] + 2 q of the band (mod its length).  (If an ancestor is a leaf too nobody reads this band.)
+                const int64_t plen = a.nj >> (t - 1);
+                const T *pb = a.src + root * a.nj + (int64_t)b * plen;
+                const int64_t start = (r0 >> (t - 1)) - a.G[t - 1];
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) {
+                    if (q0 + p < hp) {
+                        int64_t gi = start + 2 * (q0 + p);
+                        if (gi < 0) gi += plen;
+                        if (gi >= plen) gi -= plen;
+                        const T2 v = *reinterpret_cast<const T2 *>(pb + gi);
+                        if (!last) *reinterpret_cast<T2 *>(Pout + b * bsp + 2 * (q0 + p)) = v;
+                        else *reinterpret_cast<T2 *>(out0 + 2 * (q0 + p)) = v;
+                    }
+                }
+                continue;
+            }
             const T *S = Cin + (2 * b) * bsc + q0 + eps;
             const T *D = Cin + (2 * b + 1) * bsc + q0 + SH + eps;
             T sv[PPT + SH], dv[PPT + SH];
@@ -235,6 +279,7 @@ struct WptTailArgs {
     int lgts;                       // chunk = 2^lgts samples per workgroup
     int lgm;                        // segment length 2^lgm at the SHALLOWEST depth handled here (<= chunk)
     int ndepth;                     // depths handled (segments shrink / grow by 2 per depth), 1 <= ndepth <= lgm
+    const uint8_t *mask; int depth; // as WptMultiArgs; depth = the shallowest depth handled (segments of 2^lgm)
     TapsF<T, F> tp;
 };
 
@@ -280,6 +325,12 @@ __global__ void __launch_bounds__(512) k_wpt_fwd_tail(WptTailArgs<T, F> a)
         for (int p = tid; p < (TS >> 1); p += nthr) {
             const int sg = p >> (lgm - 1), k = p & (hm - 1);
             const T *sb = A + (sg << lgm);
+            if (a.mask && a.mask[(((int64_t)1 << (a.depth + dep)) - 1) + ((int64_t)blockIdx.x << (a.lgts - lgm)) + sg] == 0) {
+                T *ob = B + (sg << lgm);               // (part of) a leaf: passed through
+                ob[k] = sb[k];
+                ob[hm + k] = sb[hm + k];
+                continue;
+            }
             T xv[NW];
 #pragma unroll
             for (int e = 0; e < NW / 2; ++e) {
@@ -321,6 +372,10 @@ __global__ void __launch_bounds__(512) k_wpt_inv_tail(WptTailArgs<T, F> a)
         for (int p = tid; p < (TS >> 1); p += nthr) {
             const int sg = p >> (lgm - 1), pp = p & (hm - 1);
             const T *sb = A + (sg << lgm);
+            if (a.mask && a.mask[(((int64_t)1 << (a.depth + dep)) - 1) + ((int64_t)blockIdx.x << (a.lgts - lgm)) + sg] == 0) {
+                *reinterpret_cast<T2 *>(B + (sg << lgm) + 2 * pp) = *reinterpret_cast<const T2 *>(sb + 2 * pp);
+                continue;
+            }
             T sw[SH + 1], dw[SH + 1];
 #pragma unroll
             for (int q = 0; q <= SH; ++q) {
@@ -359,11 +414,12 @@ bool wpt_fwd_multi_ok(int F, int64_t n, int64_t nj, int NL)
 }
 
 template <typename T, int F>
-static hipError_t launch_wpt_multi_f(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+static hipError_t launch_wpt_multi_f(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask)
 {
     constexpr int VEC = 16 / sizeof(T);
     WptMultiArgs<T, F> a;
     a.src = src; a.dst = dst; a.nj = nj; a.NL = NL; a.TS = wpt_tile_samples<T>();
+    a.mask = mask; a.depth = ilog2(n / nj);
     int H[4];
     H[NL] = 0;
     for (int t = NL; t >= 1; --t) H[t - 1] = 2 * H[t] + (F - 2);
@@ -384,14 +440,14 @@ static hipError_t launch_wpt_multi_f(hipStream_t st, const Taps<T> &taps, const 
 }
 
 template <typename T>
-hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+hipError_t wpt_fwd_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask)
 {
     switch (taps.F) {
-    case 2: return launch_wpt_multi_f<T, 2>(st, taps, src, dst, n, nj, NL);
-    case 4: return launch_wpt_multi_f<T, 4>(st, taps, src, dst, n, nj, NL);
-    case 6: return launch_wpt_multi_f<T, 6>(st, taps, src, dst, n, nj, NL);
-    case 8: return launch_wpt_multi_f<T, 8>(st, taps, src, dst, n, nj, NL);
-    case 10: return launch_wpt_multi_f<T, 10>(st, taps, src, dst, n, nj, NL);
+    case 2: return launch_wpt_multi_f<T, 2>(st, taps, src, dst, n, nj, NL, mask);
+    case 4: return launch_wpt_multi_f<T, 4>(st, taps, src, dst, n, nj, NL, mask);
+    case 6: return launch_wpt_multi_f<T, 6>(st, taps, src, dst, n, nj, NL, mask);
+    case 8: return launch_wpt_multi_f<T, 8>(st, taps, src, dst, n, nj, NL, mask);
+    case 10: return launch_wpt_multi_f<T, 10>(st, taps, src, dst, n, nj, NL, mask);
     default: return hipErrorInvalidValue;
     }
 }
@@ -415,11 +471,12 @@ bool wpt_inv_multi_ok(int F, int64_t n, int64_t nj, int NL)
 }
 
 template <typename T, int F>
-static hipError_t launch_wpt_inv_multi_f(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+static hipError_t launch_wpt_inv_multi_f(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask)
 {
     constexpr int VEC = 16 / sizeof(T);
     WptInvMultiArgs<T, F> a;
     a.src = src; a.dst = dst; a.nj = nj; a.NL = NL; a.TS = wpt_tile_samples<T>();
+    a.mask = mask; a.depth = ilog2(n / nj);
     wpt_inv_halos<T>(F, NL, a.G);
     int maxlen = 0;
     for (int t = 0; t <= 3; ++t) a.bs[t] = 0;
@@ -438,14 +495,14 @@ static hipError_t launch_wpt_inv_multi_f(hipStream_t st, const Taps<T> &taps, co
 }
 
 template <typename T>
-hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL)
+hipError_t wpt_inv_multi_launch(hipStream_t st, const Taps<T> &taps, const T *src, T *dst, int64_t n, int64_t nj, int NL, const uint8_t *mask)
 {
     switch (taps.F) {
-    case 2: return launch_wpt_inv_multi_f<T, 2>(st, taps, src, dst, n, nj, NL);
-    case 4: return launch_wpt_inv_multi_f<T, 4>(st, taps, src, dst, n, nj, NL);
-    case 6: return launch_wpt_inv_multi_f<T, 6>(st, taps, src, dst, n, nj, NL);
-    case 8: return launch_wpt_inv_multi_f<T, 8>(st, taps, src, dst, n, nj, NL);
-    case 10: return launch_wpt_inv_multi_f<T, 10>(st, taps, src, dst, n, nj, NL);
+    case 2: return launch_wpt_inv_multi_f<T, 2>(st, taps, src, dst, n, nj, NL, mask);
+    case 4: return launch_wpt_inv_multi_f<T, 4>(st, taps, src, dst, n, nj, NL, mask);
+    case 6: return launch_wpt_inv_multi_f<T, 6>(st, taps, src, dst, n, nj, NL, mask);
+    case 8: return launch_wpt_inv_multi_f<T, 8>(st, taps, src, dst, n, nj, NL, mask);
+    case 10: return launch_wpt_inv_multi_f<T, 10>(st, taps, src, dst, n, nj, NL, mask);
     default: return hipErrorInvalidValue;
     }
 }
@@ -464,12 +521,13 @@ bool wpt_tail_ok(int F, int64_t n, int64_t nj, int ndepth)
 }
 
 template <typename T, int F>
-static hipError_t launch_wpt_tail_f(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth)
+static hipError_t launch_wpt_tail_f(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth, const uint8_t *mask)
 {
     WptTailArgs<T, F> a;
     const int TS = wpt_tile_samples<T>();
     const int64_t chunk = (n < TS) ? n : TS;
     a.src = src; a.dst = dst; a.lgts = ilog2(chunk); a.lgm = ilog2(nj); a.ndepth = ndepth;
+    a.mask = mask; a.depth = ilog2(n / nj);
     a.tp = shrink<T, F>(taps);
     const size_t shmem = 2 * (size_t)chunk * sizeof(T);
     const int threads = chunk >= 2048 ? 512 : (chunk >= 512 ? 256 : 64);
@@ -479,14 +537,14 @@ static hipError_t launch_wpt_tail_f(hipStream_t st, const Taps<T> &taps, int fw,
 }
 
 template <typename T>
-hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth)
+hipError_t wpt_tail_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, T *dst, int64_t n, int64_t nj, int ndepth, const uint8_t *mask)
 {
     switch (taps.F) {
-    case 2: return launch_wpt_tail_f<T, 2>(st, taps, fw, src, dst, n, nj, ndepth);
-    case 4: return launch_wpt_tail_f<T, 4>(st, taps, fw, src, dst, n, nj, ndepth);
-    case 6: return launch_wpt_tail_f<T, 6>(st, taps, fw, src, dst, n, nj, ndepth);
-    case 8: return launch_wpt_tail_f<T, 8>(st, taps, fw, src, dst, n, nj, ndepth);
-    case 10: return launch_wpt_tail_f<T, 10>(st, taps, fw, src, dst, n, nj, ndepth);
+    case 2: return launch_wpt_tail_f<T, 2>(st, taps, fw, src, dst, n, nj, ndepth, mask);
+    case 4: return launch_wpt_tail_f<T, 4>(st, taps, fw, src, dst, n, nj, ndepth, mask);
+    case 6: return launch_wpt_tail_f<T, 6>(st, taps, fw, src, dst, n, nj, ndepth, mask);
+    case 8: return launch_wpt_tail_f<T, 8>(st, taps, fw, src, dst, n, nj, ndepth, mask);
+    case 10: return launch_wpt_tail_f<T, 10>(st, taps, fw, src, dst, n, nj, ndepth, mask);
     default: return hipErrorInvalidValue;
     }
 }
@@ -495,15 +553,15 @@ template int wpt_tile_samples<float>();
 template int wpt_tile_samples<double>();
 template bool wpt_fwd_multi_ok<float>(int, int64_t, int64_t, int);
 template bool wpt_fwd_multi_ok<double>(int, int64_t, int64_t, int);
-template hipError_t wpt_fwd_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int);
-template hipError_t wpt_fwd_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int);
+template hipError_t wpt_fwd_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int, const uint8_t *);
+template hipError_t wpt_fwd_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int, const uint8_t *);
 template bool wpt_inv_multi_ok<float>(int, int64_t, int64_t, int);
 template bool wpt_inv_multi_ok<double>(int, int64_t, int64_t, int);
-template hipError_t wpt_inv_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int);
-template hipError_t wpt_inv_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int);
+template hipError_t wpt_inv_multi_launch<float>(hipStream_t, const Taps<float> &, const float *, float *, int64_t, int64_t, int, const uint8_t *);
+template hipError_t wpt_inv_multi_launch<double>(hipStream_t, const Taps<double> &, const double *, double *, int64_t, int64_t, int, const uint8_t *);
 template bool wpt_tail_ok<float>(int, int64_t, int64_t, int);
 template bool wpt_tail_ok<double>(int, int64_t, int64_t, int);
-template hipError_t wpt_tail_launch<float>(hipStream_t, const Taps<float> &, int, const float *, float *, int64_t, int64_t, int);
-template hipError_t wpt_tail_launch<double>(hipStream_t, const Taps<double> &, int, const double *, double *, int64_t, int64_t, int);
+template hipError_t wpt_tail_launch<float>(hipStream_t, const Taps<float> &, int, const float *, float *, int64_t, int64_t, int, const uint8_t *);
+template hipError_t wpt_tail_launch<double>(hipStream_t, const Taps<double> &, int, const double *, double *, int64_t, int64_t, int, const uint8_t *);
 
 }  // namespace wl

@@ -35,3 +35,32 @@ for pw, L in ((22, 6), (22, 22), (18, 18), (16, 16), (14, 14), (24, 4)):
         slow = t_us(fn)
         W.clear_options()
         print(f"| {name} 2^{pw} depth {L} f32 | {fast:.1f} | {k} | {slow:.1f} |")
+
+# ---- partially split trees (round 5: the packet kernels take the node bits as a per-segment split mask) ----
+import numpy as np
+print()
+print("| tree (2^22, db4, f32) | wpt us | kernel | iwpt us | kernel | wpt us, per-depth tier |")
+print("|---|---|---|---|---|---|")
+n = 1 << 22
+x = torch.randn(n, generator=g, dtype=torch.float32).cuda()
+y = W.similar(x)
+rs = np.random.default_rng(5)
+
+
+def rand_tree(depth, p):
+    t = np.zeros(n - 1, dtype=np.uint8)
+    t[0] = 1
+    for i in range(1, 2 ** depth - 1):
+        t[i] = 1 if (t[(i + 1) // 2 - 1] and rs.random() < p) else 0
+    return t
+
+
+for label, tree in (("full, depth 9", W.maketree(n, 9, "full")), ("dwt-shaped, depth 9", W.maketree(n, 9, "dwt")), ("random (p = 0.6), depth 9", rand_tree(9, 0.6)),
+                    ("full, depth 22", W.maketree(n, 22, "full")), ("dwt-shaped, depth 22", W.maketree(n, 22, "dwt")), ("random (p = 0.8), depth 16", rand_tree(16, 0.8))):
+    W.reserve_workspace(x, 22, full=True)
+    tf = t_us(lambda: W.wpt_(y, x, db4, tree)); kf = W.last_kernel()
+    ti = t_us(lambda: W.iwpt_(y, x, db4, tree)); ki = W.last_kernel()
+    W.set_option("WL_WPT_FAST", 0)
+    ts = t_us(lambda: W.wpt_(y, x, db4, tree))
+    W.clear_options()
+    print(f"| {label} | {tf:.1f} | {kf} | {ti:.1f} | {ki} | {ts:.1f} |")

@@ -1862,3 +1862,27 @@ def test_2d_array_beyond_2_31_elements(gpu, W, oracle):
     del xr, x
     W.destroy_contexts()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
+    """Round 5 experiment kept as an option (WL_3D_SLAB, off by default: measured slower, wl_axis.hip): the forward 3-D level in SLABS of
+    output plane pairs (axis-3 pass of a slab, then the fused 2-D level kernel on exactly the planes it produced).  Forced here on
+    small boxes (WL_3D_SLAB_MIN_MIB = 0, slabs of 8 / 16 pairs): bit for bit against the whole-box passes and the oracle, including
+    the slabs whose detail planes wrap around the end of the detail half (transforms_filter.jl:246-290)."""
+    for shape, L in (((256, 64, 64), 2), ((256, 32, 128), 1), ((512, 16, 96), 1)):
+        x = rng_array(shape, dtype, shape[2])
+        xd = dev(W, x)
+        for fname in ("db4", "haar", "db2", "db5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            W.set_option("WL_3D_SLAB", 0)
+            y0 = host(W, W.dwt(xd, wt, L))
+            assert W.last_kernel() == "k_fwd_axis_stream"
+            for slab in (8, 16):
+                W.set_option("WL_3D_SLAB", slab)
+                W.set_option("WL_3D_SLAB_MIN_MIB", 0)
+                y1 = host(W, W.dwt(xd, wt, L))
+                assert np.array_equal(y0, y1), (shape, fname, slab, int((y0 != y1).sum()))
+            W.clear_options()
+            if shape[0] * shape[1] * shape[2] <= 1 << 20:
+                assert np.array_equal(y0, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname)

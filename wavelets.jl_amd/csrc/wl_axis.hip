@@ -64,6 +64,7 @@ struct AxisArgs {
     int64_t R, C;                                  // rows (contiguous), axis length
     int TJ;                                        // forward: input columns per chunk (multiple of 16); inverse: output pairs per chunk (multiple of 8)
     int nstrips, nchunks;
+    int chunk0;                                    // first chunk of this launch (slab launches of the 3-D level cover a chunk range)
     TapsA<T, F> tp;
 };
 
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(64) k_fwd_axis_stream(AxisArgs<T, F> a)
     constexpr int SH = (F - 2) / 2, R = axis_ring(F), U = R / 2, PFD = (R - F) / 2;
     const int lane = threadIdx.x;
     const int strip = (int)(blockIdx.x % (unsigned)a.nstrips);
-    const int chunk = (int)(blockIdx.x / (unsigned)a.nstrips);
+    const int chunk = a.chunk0 + (int)(blockIdx.x / (unsigned)a.nstrips);
     const int64_t row = ((int64_t)strip * 64 + lane) * RPL;
     const bool valid = row < a.R;
     const int64_t rr = valid ? row : 0;
@@ -410,18 +411,24 @@ static hipError_t launch_short(hipStream_t st, const Taps<T> &taps, ShortArgs<T,
 
 template <typename T, int F, int FW>
 static hipError_t launch_axis(hipStream_t st, const Taps<T> &taps, const T *src, int64_t lds, int64_t bs_src,
-                              T *dst, int64_t ldd, int64_t bs_dst, int64_t R, int64_t C, int64_t batch, int cu_count)
+                              T *dst, int64_t ldd, int64_t bs_dst, int64_t R, int64_t C, int64_t batch, int cu_count,
+                              int64_t col_lo = 0, int64_t col_hi = -1, int tj_forced = 0)
 {
     constexpr int RPL = 16 / sizeof(T);
     AxisArgs<T, F> a;
-    a.src = src; a.lds = lds; a.bs_src = bs_src; a.dst = dst; a.ldd = ldd; a.bs_dst = bs_dst; a.R = R; a.C = C;
+    a.src = src; a.lds = lds; a.bs_src = bs_src; a.dst = dst; a.ldd = ldd; a.bs_dst = bs_dst; a.R = R; a.C = C; a.chunk0 = 0;
     a.nstrips = (int)((R + 64 * RPL - 1) / (64 * RPL));
     const int64_t units = FW ? C : (C >> 1);           // chunked quantity: input columns (fw) / output pairs (inv)
     const int unit = FW ? axis_ring(F) : axis_ring_inv(F);
     int TJ = FW ? 128 : 64;
     while (TJ > unit && (int64_t)a.nstrips * ((units + TJ - 1) / TJ) * batch < (int64_t)cu_count * 8) TJ >>= 1;
+    if (tj_forced > 0) TJ = tj_forced;
     a.TJ = TJ;
     a.nchunks = (int)((units + TJ - 1) / TJ);
+    if (col_hi >= 0) {                             // (forward only) the chunks of input columns [col_lo, col_hi): both multiples of TJ
+        a.chunk0 = (int)(col_lo / TJ);
+        a.nchunks = (int)((col_hi - col_lo) / TJ);
+    }
     a.tp = shrink_a<T, F>(taps);
     for (int64_t b0 = 0; b0 < batch; b0 += 32768) {
         const int64_t nb = (batch - b0 < 32768) ? (batch - b0) : 32768;
@@ -460,6 +467,43 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
         return false;
     bool ok = false;
     WL_DISPATCH_FA(F, {
+        // An option, OFF by default (round 5, measured): the level in SLABS of output plane pairs -- the axis-3 pass of a slab writes
+        // 2 * slab planes of T0 and the plane kernel consumes exactly those planes next, in the hope that the intermediate array stays
+        // in the Infinity Cache instead of making a round trip through HBM.  512^3 db4 L = 9: whole-box passes 566 us; slabs of 64 / 32 /
+        // 16 / 8 plane pairs 593 / 611 / 767 / 1020 us -- three smaller launches per slab cost more than the cache gives back (the two
+        // whole-box passes of level 1 already move their 2.1 GB at 4.7 TB/s).  Kept for the A/B (bit-identical, tested).
+        const int64_t P = n0 * n1, SHp = (FF - 2) / 2;
+        int64_t slab = opt("WL_3D_SLAB", 0);                         // output plane pairs per slab; 0: whole-box passes
+        if (slab > 0) {
+            while (slab > 8 && 2 * slab * P * (int64_t)sizeof(T) > ((int64_t)opt("WL_3D_SLAB_MIB", 64) << 20)) slab >>= 1;
+            int tj = 128;
+            while (tj > 16 && ((2 * slab) % tj) != 0) tj >>= 1;
+            if (h2 % slab != 0 || (2 * slab) % tj != 0 || h2 <= slab || P * n2 * (int64_t)sizeof(T) < ((int64_t)opt("WL_3D_SLAB_MIN_MIB", 256) << 20) ||
+                n0 < 256 || opt("WL_NO_PLANES", 0) != 0)
+                slab = 0;
+            if (slab > 0) {
+                bool all = true;
+                for (int64_t k0 = 0; k0 < h2 && *err == hipSuccess; k0 += slab) {
+                    const int64_t k1 = k0 + slab;
+                    *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, P, 0, P, n2, 1, cu_count, 2 * k0, 2 * k1, tj);
+                    if (*err != hipSuccess) break;
+                    // scaling planes k0 .. k1-1: their approximation quadrant goes on to ll
+                    all = all && fwd2d_planes<T>(st, taps, T0 + k0 * P, y + k0 * y2, y1, y2, ll ? ll + k0 * h0 * h1 : nullptr, n0, n1, k1 - k0,
+                                                 (int)(k1 - k0), cu_count, err);
+                    if (*err != hipSuccess || !all) break;
+                    // detail planes h2 + (k + SH) mod h2
+                    int64_t d0 = k0 + SHp, d1 = k1 + SHp;
+                    if (d0 >= h2) { d0 -= h2; d1 -= h2; }
+                    const int64_t e1 = d1 > h2 ? h2 : d1;
+                    all = all && fwd2d_planes<T>(st, taps, T0 + (h2 + d0) * P, y + (h2 + d0) * y2, y1, y2, nullptr, n0, n1, e1 - d0, 0, cu_count, err);
+                    if (*err == hipSuccess && all && d1 > h2)
+                        all = all && fwd2d_planes<T>(st, taps, T0 + h2 * P, y + h2 * y2, y1, y2, nullptr, n0, n1, d1 - h2, 0, cu_count, err);
+                }
+                if (!all && *err == hipSuccess) *err = hipErrorInvalidValue;   // (fwd2d_planes accepted this shape for the whole box below before)
+                ok = true;
+                break;
+            }
+        }
         // planes: axis 3 on the (n0*n1) x n2 matrix
         *err = launch_axis<T, FF, 1>(st, taps, cur, c2, 0, T0, n0 * n1, 0, n0 * n1, n2, 1, cu_count);
         // rows + columns of every plane in ONE launch when the planes are big enough for the fused 2-D level kernel

@@ -302,7 +302,7 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 #define WL_P_M1D_LD 0       // k_fwd1d_multi: staging loads of the input tile
 #endif
 #ifndef WL_P_M1D_ST
-#define WL_P_M1D_ST 0       // ... detail stores
+#define WL_P_M1D_ST 1       // ... detail stores (C5 shard 939 -> 926 us, C2 49.6 -> 49.0; loads: slower)
 #endif
 #ifndef WL_P_LIFT3_LD
 #define WL_P_LIFT3_LD 0     // k_lift1d_fwd3: input loads
@@ -348,13 +348,25 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 #define WL_P_LIFT2D_LD 0    // k_lift2d_inv: coefficient loads
 #endif
 #ifndef WL_P_LIFT2D_ST
-#define WL_P_LIFT2D_ST 0    // ... output stores
+#define WL_P_LIFT2D_ST 1    // ... output stores (8192^2 cdf9/7 idwt 235.1 -> 231.9 us; loads: slower)
 #endif
 #ifndef WL_P_LIFT2DF_LD
 #define WL_P_LIFT2DF_LD 0   // k_lift2d_fwd: input loads
 #endif
 #ifndef WL_P_LIFT2DF_ST
-#define WL_P_LIFT2DF_ST 0   // ... coefficient stores
+#define WL_P_LIFT2DF_ST 1   // ... detail stores (8192^2 cdf9/7 dwt 230.7 -> 220.2 us; loads: slower)
+#endif
+#ifndef WL_P_PAIR64_ST1
+#define WL_P_PAIR64_ST1 1   // k_fwd2d_pair64: level-l detail stores (with _ST2: 8192^2 Float64 dwt 286.2 -> 282.4 us; loads: slower)
+#endif
+#ifndef WL_P_PAIR64_ST2
+#define WL_P_PAIR64_ST2 1   // ... level-(l+1) detail stores
+#endif
+#ifndef WL_P_LDS64_ST
+#define WL_P_LDS64_ST 0     // k_fwd2d_lds64: detail stores
+#endif
+#ifndef WL_P_LONG_ST
+#define WL_P_LONG_ST 1      // k_fwd2d_lds_long: detail stores (sym8 dwt 291.2 -> 286.1 us)
 #endif
 template <bool NT, typename V>
 __device__ __forceinline__ void store_pol(V *p, const V v)

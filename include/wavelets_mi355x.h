@@ -35,7 +35,12 @@
  *    WL_EALIAS -> ArgumentError.
  *  - Arithmetic: sums are evaluated in the reference's order with separate multiply
  *    and add roundings (no FMA contraction), so Float32/Float64 results are
- *    bit-identical to the reference CPU loops on the same taps.
+ *    bit-identical to the reference CPU loops on the same taps.  A second library
+ *    with the same ABI, libwavelets_mi355x_fma.so (the same sources built with FMA
+ *    contraction allowed, `make FMA=1`), is the opt-in "fused" arithmetic mode: it
+ *    agrees with the reference to ||y - ref||_2 / ||ref||_2 <= 1e-6 sqrt(L) (Float32),
+ *    1e-13 sqrt(L) (Float64) instead of bit for bit.  A host selects it by loading
+ *    that file; neither library ever falls back on the other.
  *  - There is no CPU fallback: without a gfx950 device every entry point that needs
  *    one returns WL_EHIP / WL_ENODEVICE.
  */

@@ -1886,3 +1886,29 @@ def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
             W.clear_options()
             if shape[0] * shape[1] * shape[2] <= 1 << 20:
                 assert np.array_equal(y0, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname)
+
+
+def test_long_filter_tiles_bitexact(gpu, W, oracle):
+    """Round 5: the small cache-resident levels (128 .. 256 rows by default; up to 1024 with WL_TILE_LONG_MAX) of the 12..20-tap filters take
+    the LDS tile kernel, two levels per launch (wl_tile.hip: the dim-1 window generalised to 24 / 32 rows, detail rows shifted by 8 / 12) instead of one streaming
+    launch per level and two line passes at 128^2.  Bit for bit against the oracle and against the per-level tier, every filter
+    length, square and non-square blocks, odd numbers of remaining levels (transforms_filter.jl:113-188)."""
+    for (n0, n1, L) in ((1024, 1024, 10), (512, 512, 3), (256, 256, 8), (128, 128, 7), (1024, 256, 2), (128, 512, 3), (256, 1024, 8), (2048, 2048, 4)):
+        x = rng_array((n0, n1), np.float32, n0 + n1)
+        xd = dev(W, x)
+        for fname in ("db6", "db7", "sym8", "db9", "db10", "coif4", "beyl"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            if n0 * n1 > 1 << 20 and fname not in ("sym8", "db10"):
+                continue
+            y = host(W, W.dwt(xd, wt, L))
+            if max(n0, n1) <= 256:
+                assert W.last_kernel() == "k_fwd2d_tile", (n0, n1, L, fname, W.last_kernel())
+            W.set_option("WL_TILE_LONG", 0)
+            y0 = host(W, W.dwt(xd, wt, L))
+            W.clear_options()
+            assert np.array_equal(y, y0), (n0, n1, L, fname, int((y != y0).sum()))
+            W.set_option("WL_TILE_LONG_MAX", 1024)                      # the tiles on every size they are built for
+            y1 = host(W, W.dwt(xd, wt, L))
+            W.clear_options()
+            assert np.array_equal(y, y1), (n0, n1, L, fname, int((y != y1).sum()))
+            assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, L)), (n0, n1, L, fname)

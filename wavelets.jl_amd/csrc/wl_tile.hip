@@ -25,10 +25,20 @@ struct TileArgs {
     TapsF<T, F> tp;
 };
 
+// dim-1 pass of a thread: s rows 4q .. 4q+3 and d rows 4q+DS .. 4q+DS+3 from window rows 8q .. 8q+WINR-1.  DS = the shift of the stored
+// d rows, a multiple of 4 >= (F-2)/2 (a group of four d rows never straddles the periodic wrap): 4 up to 10 taps (WINR = 16, the
+// layout of rounds 2-4), 8 for 12..18 taps (24 rows), 12 for 20 taps (32 rows) -- round 5: the tiles also serve the 12..20-tap filters
+template <int F>
+struct TileGeomF {
+    static constexpr int SHD = (F - 2) / 2;
+    static constexpr int DS = (F <= 10) ? 4 : ((SHD + 3) / 4) * 4;
+    static constexpr int WINR = (((F + 6 > 2 * DS + 8) ? F + 6 : 2 * DS + 8) + 3) & ~3;
+    static constexpr int HR = WINR - 8;
+};
 // extents of the tile at level l (l = 0: the launch's input), OT = 64 owned input samples per side
 template <int F, int NL, int l>
 struct TileDim {
-    static constexpr int HR = 8, HC = F - 2;                       // one-sided halos per level: rows (d rows shifted by 4), columns
+    static constexpr int HR = TileGeomF<F>::HR, HC = F - 2;        // one-sided halos per level: rows (d rows shifted by DS), columns
     static constexpr int R = 2 * TileDim<F, NL, l + 1>::R + HR;    // rows / columns of this level's input that the tile needs
     static constexpr int C = 2 * TileDim<F, NL, l + 1>::C + HC;
 };
@@ -79,14 +89,15 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
         if (k < OWN) *reinterpret_cast<F4t *>(T + 4 * iq + (CN + k) * ldT) = d;
     }
     lds_barrier();
-    // ---- dim-1 pass: column c of T, rows 8q .. 8q+15 -> s rows 4q .. 4q+3, d rows 4q+4 .. 4q+7
+    // ---- dim-1 pass: column c of T, rows 8q .. 8q+WINR-1 -> s rows 4q .. 4q+3, d rows 4q+DS .. 4q+DS+3
     constexpr int QG = (RN + 3) / 4;                // groups of four output rows (covers the RN approximation rows needed below)
+    constexpr int DS = TileGeomF<F>::DS, WINR = TileGeomF<F>::WINR;
     for (int it = tid; it < QG * (CN + OWN); it += nthr) {
         const int q = it % QG, c = it / QG;
         const TT *p = T + 8 * q + c * ldT;
-        TT E[16];
+        TT E[WINR];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < WINR / 4; ++v) {
             const F4t t = *reinterpret_cast<const F4t *>(p + 4 * v);
             E[4 * v] = t.x; E[4 * v + 1] = t.y; E[4 * v + 2] = t.z; E[4 * v + 3] = t.w;
         }
@@ -96,9 +107,9 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
             TT s = tp.h[0] * E[2 * j];
 #pragma unroll
             for (int m = 1; m < F; ++m) s = s + tp.h[m] * E[2 * j + m];
-            TT d = tp.g[F - 1] * E[2 * j + 10 - F];
+            TT d = tp.g[F - 1] * E[2 * j + 2 * DS + 2 - F];
 #pragma unroll
-            for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * E[2 * j + 9 - m];
+            for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * E[2 * j + 2 * DS + 1 - m];
             so[j] = s; dO[j] = d;
         }
         const bool is_s = c < CN;
@@ -113,7 +124,7 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
             int64_t col;
             if (is_s) col = c0h + cc;                                   // s along dim 2
             else { int kd = c0h + cc + SH; if (kd >= hn) kd -= hn; col = hn + kd; }
-            int rd = r0h + 4 * q + 4;
+            int rd = r0h + 4 * q + DS;
             if (rd >= hm) rd -= hm;
             TT *yc = y + col * ldy;
             *reinterpret_cast<F4t *>(yc + hm + rd) = dO;                // ds or dd
@@ -291,7 +302,8 @@ hipError_t fwd2d_tileB_launch(hipStream_t st, const Taps<float> &taps, const flo
 
 bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N)
 {
-    if (F < 2 || F > 10 || (F & 1) || NL < 1 || NL > 3) return false;
+    if (F < 2 || F > 20 || (F & 1) || NL < 1 || NL > 3) return false;
+    if (F > 10 && NL > 2) return false;            // (12..20 taps: Float32, at most two levels -- the staged tile grows with (F-2)(2^NL - 1))
     // tiles of 64 x 64; the d rows / columns wrap in groups of four at every level; the tile with halo must not wrap twice
     return M >= 128 && N >= 128 && (M % 64) == 0 && (N % 64) == 0 && M <= 4096 && N <= 4096 && (M >> NL) % 4 == 0 && (N >> NL) >= 1;
 }
@@ -324,8 +336,8 @@ static hipError_t launch_tile_f(hipStream_t st, const Taps<T> &taps, int NL, con
     case 1: return launch_tile_fn<T, F, 1>(st, a);
     case 2: return launch_tile_fn<T, F, 2>(st, a);
     default:
-        if constexpr (sizeof(T) == 4) return launch_tile_fn<T, F, 3>(st, a);
-        else return hipErrorInvalidValue;          // (three levels of Float64 do not fit the 160 KiB of LDS)
+        if constexpr (sizeof(T) == 4 && F <= 10) return launch_tile_fn<T, F, 3>(st, a);
+        else return hipErrorInvalidValue;          // (three levels of Float64 / of a long filter do not fit the 160 KiB of LDS)
     }
 }
 
@@ -339,8 +351,19 @@ hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const 
     case 6: return launch_tile_f<T, 6>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
     case 8: return launch_tile_f<T, 8>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
     case 10: return launch_tile_f<T, 10>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
-    default: return hipErrorInvalidValue;
+    default: break;
     }
+    if constexpr (sizeof(T) == 4) {                // 12..20 taps: Float32 only (wl_fwd.hip sends only those here)
+        switch (taps.F) {
+        case 12: return launch_tile_f<T, 12>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+        case 14: return launch_tile_f<T, 14>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+        case 16: return launch_tile_f<T, 16>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+        case 18: return launch_tile_f<T, 18>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+        case 20: return launch_tile_f<T, 20>(st, taps, NL, src, lds, y, ldy, ll, ldll, M, N);
+        default: break;
+        }
+    }
+    return hipErrorInvalidValue;
 }
 template hipError_t fwd2d_tile_launch<float>(hipStream_t, const Taps<float> &, int, const float *, int64_t, float *, int64_t, float *, int64_t, int,
                                              int);

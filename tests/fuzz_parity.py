@@ -46,6 +46,36 @@ def one_case(r, verbose=False):
     Lmax = W.maxtransformlevels(x)
     L = Lmax if r.random() < 0.5 else int(r.integers(min(1, Lmax), Lmax + 1))
     xd = W.to_device(x)
+    if nd == 1 and shape[0] >= 4 and r.random() < 0.2:          # packet transform over a random valid tree (round 5: split masks)
+        n = shape[0]
+        Lm = W.maxtransformlevels(n)
+        depth = int(r.integers(1, min(Lm, 12) + 1)) if Lm >= 1 else 0
+        tree = np.zeros(2 ** Lm - 1, dtype=np.uint8)
+        if depth >= 1 and len(tree):
+            tree[0] = 1
+            p = float(r.choice([0.35, 0.6, 0.85, 1.0]))
+            for i in range(1, min(len(tree), 2 ** depth - 1)):
+                tree[i] = 1 if (tree[(i + 1) // 2 - 1] and r.random() < p) else 0
+        if lifting:
+            sch = W.wavelet(getattr(W.WT, str(r.choice(SCHEMES))), W.WT.Lifting)
+            ye = oracle.wpt_lifting(x, sch, tree)
+            y = W.to_host(W.wpt(xd, sch, tree)); kf = W.last_kernel()
+            xr = W.to_host(W.iwpt(W.to_device(ye), sch, tree)); ki = W.last_kernel()
+            xe = oracle.wpt_lifting(ye, sch, tree, fw=False)
+            tag = f"wpt lifting {sch.name} {dtype.__name__} n={n} depth={depth} [{kf} | {ki}]"
+        else:
+            name = str(r.choice(FILTERS))
+            wt = W.wavelet(getattr(W.WT, name))
+            ye = oracle.wpt_filter(x, wt.qmf, tree)
+            y = W.to_host(W.wpt(xd, wt, tree)); kf = W.last_kernel()
+            xr = W.to_host(W.iwpt(W.to_device(ye), wt, tree)); ki = W.last_kernel()
+            xe = oracle.wpt_filter(ye, wt.qmf, tree, fw=False)
+            tag = f"wpt {name} {dtype.__name__} n={n} depth={depth} [{kf} | {ki}]"
+        if verbose:
+            print(tag)
+        assert np.array_equal(y, ye), "FORWARD " + tag
+        assert np.array_equal(xr, xe), "INVERSE " + tag
+        return (kf, ki)
     if nd == 2 and not lifting and r.random() < 0.25:          # batched columns: every column its own 1-D transform
         name = str(r.choice(FILTERS))
         wt = W.wavelet(getattr(W.WT, name))

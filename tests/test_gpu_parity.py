@@ -1912,3 +1912,45 @@ def test_long_filter_tiles_bitexact(gpu, W, oracle):
             W.clear_options()
             assert np.array_equal(y, y1), (n0, n1, L, fname, int((y != y1).sum()))
             assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, L)), (n0, n1, L, fname)
+
+
+def test_3d_box_beyond_2_31_elements(gpu, W):
+    """A 3-D box whose element offsets do not fit 32 bits (512 x 2048 x 2304 Float32 = 2.4e9 elements, 9.7 GB): the axis / plane
+    kernels of the fast 3-D tier against the one-thread-per-output generic tier (different kernels, different index arithmetic:
+    device-vs-device, every element), forward and inverse, plus the round trip."""
+    import torch
+    n = (512, 2048, 2304)
+    assert n[0] * n[1] * n[2] > 2 ** 31
+    g = torch.Generator(device=gpu).manual_seed(31)
+    x = torch.randn(n[2], n[1], n[0], generator=g, dtype=torch.float32, device=gpu).permute(2, 1, 0)      # Julia layout
+    assert W.is_julia_layout(x)
+    wt = W.wavelet(W.WT.db4)
+    y = W.dwt(x, wt, 2)
+    assert W.last_kernel() == "k_fwd_axis_stream", W.last_kernel()
+    try:
+        W.set_kernel_path(1)
+        yg = W.dwt(x, wt, 2)
+        assert W.last_kernel().startswith("k_generic"), W.last_kernel()
+    finally:
+        W.set_kernel_path(0)
+    assert torch.equal(y, yg)
+    del yg
+    xr = W.idwt(y, wt, 2)
+    assert W.last_kernel() == "k_inv_axis_stream", W.last_kernel()
+    try:
+        W.set_kernel_path(1)
+        xg = W.idwt(y, wt, 2)
+    finally:
+        W.set_kernel_path(0)
+    assert torch.equal(xr, xg)
+    del xg, y
+    # round trip, in chunks (the Float64 norms of 2.4e9 elements would need 40 GB of temporaries)
+    num = den = 0.0
+    for k in range(0, n[2], 256):
+        a, b = xr[:, :, k:k + 256].double(), x[:, :, k:k + 256].double()
+        num += float(((a - b) ** 2).sum())
+        den += float((b ** 2).sum())
+    assert (num / den) ** 0.5 < 1e-5
+    del xr, x
+    W.destroy_contexts()
+    torch.cuda.empty_cache()

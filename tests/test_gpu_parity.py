@@ -203,6 +203,9 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 kexp = "k_vl_lines" if flen == 24 else "k_long_lines"      # (24 taps: the register-window kernels at every size)
                 # forward, Float32, 12..20 taps, rows a multiple of 256: one pass per level (wl_fwd2d_long.hip, its own test below)
                 kfw = "k_fwd2d_lds_long" if (dtype == np.float32 and flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0) else kexp
+                # ... and its cache-resident levels (<= 1024 rows, two or more levels left) on the LDS tile kernel (round 5)
+                if kfw == "k_fwd2d_lds_long" and max(shape) <= 1024 and min(shape) >= 128 and L >= 2:
+                    kfw = "k_fwd2d_tile"
                 assert W.last_kernel() == kfw or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(y, ye), (fname, shape, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
@@ -340,6 +343,7 @@ def test_long_filter_single_pass_2d_kernel(gpu, W, oracle, wmain, tj):
     W.set_option("WL_LONG_TJ", tj)
     W.set_option("WL_LONG_WG_PER_CU", 0)
     W.set_option("WL_LONG2D_MIN_ROWS", 256)
+    W.set_option("WL_TILE_LONG", 0)                  # (round 5: these small blocks would otherwise take the LDS tile kernel, its own test below)
     shapes = (((512, 512), (1, 2, 3)), ((1024, 2048), (1, 2)), ((2048, 256), (1, 3)), ((256, 96), (1,)), ((768, 130), (1,)), ((1280, 1056), (1, 2)))
     for shape, Ls in shapes:
         x = rng_array(shape, np.float32, sum(shape) + wmain + tj)
@@ -1889,8 +1893,8 @@ def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
 
 
 def test_long_filter_tiles_bitexact(gpu, W, oracle):
-    """Round 5: the small cache-resident levels (128 .. 256 rows by default; up to 1024 with WL_TILE_LONG_MAX) of the 12..20-tap filters take
-    the LDS tile kernel, two levels per launch (wl_tile.hip: the dim-1 window generalised to 24 / 32 rows, detail rows shifted by 8 / 12) instead of one streaming
+    """Round 5: the cache-resident levels (128 .. 1024 rows; WL_TILE_LONG_MAX) of the 12..20-tap filters take the LDS tile kernel, two
+    levels per launch (wl_tile.hip: the dim-1 window generalised to 24 / 32 rows, detail rows shifted by 8 / 12) instead of one streaming
     launch per level and two line passes at 128^2.  Bit for bit against the oracle and against the per-level tier, every filter
     length, square and non-square blocks, odd numbers of remaining levels (transforms_filter.jl:113-188)."""
     for (n0, n1, L) in ((1024, 1024, 10), (512, 512, 3), (256, 256, 8), (128, 128, 7), (1024, 256, 2), (128, 512, 3), (256, 1024, 8), (2048, 2048, 4)):
@@ -1901,13 +1905,13 @@ def test_long_filter_tiles_bitexact(gpu, W, oracle):
             if n0 * n1 > 1 << 20 and fname not in ("sym8", "db10"):
                 continue
             y = host(W, W.dwt(xd, wt, L))
-            if max(n0, n1) <= 256:
+            if max(n0, n1) <= 1024:
                 assert W.last_kernel() == "k_fwd2d_tile", (n0, n1, L, fname, W.last_kernel())
             W.set_option("WL_TILE_LONG", 0)
             y0 = host(W, W.dwt(xd, wt, L))
             W.clear_options()
             assert np.array_equal(y, y0), (n0, n1, L, fname, int((y != y0).sum()))
-            W.set_option("WL_TILE_LONG_MAX", 1024)                      # the tiles on every size they are built for
+            W.set_option("WL_TILE_LONG_MAX", 256)                       # the tiles on the two smallest levels only
             y1 = host(W, W.dwt(xd, wt, L))
             W.clear_options()
             assert np.array_equal(y, y1), (n0, n1, L, fname, int((y != y1).sum()))

@@ -1369,15 +1369,14 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 }
             }
         }
-        // ---- 12..20 taps, Float32, blocks of 128 .. 256 rows: two levels per launch through the LDS tile kernel (round 5).  These
-        //      levels ran one streaming launch each (12 us apiece, short of workgroups) and the 128^2 level as two line passes:
-        //      8192^2 sym8 285.4 -> 279.0 us, db10 327.7 -> 320.6, 512^2 sym8 full depth 48.5 -> 42.0.  Not above 256 rows: a tile with
-        //      its recomputed halo is 2.9 x its payload at 16 taps, and from 512^2 on the streaming kernel is level with it or ahead
-        //      (db6 512^2: 41.8 us streaming, 50.9 tiles; WL_TILE_LONG_MAX to experiment).
+        // ---- 12..20 taps, Float32, blocks of 128 .. 1024 rows: two levels per launch through the LDS tile kernel (round 5).  These
+        //      levels ran one streaming launch each (12-13 us apiece, short of workgroups) and the 128^2 level as two line passes:
+        //      8192^2 db6 246 -> 224 us, sym8 286 -> 261, db10 329 -> 303; 1024^2 sym8 full depth 60.5 -> 36.8, 512^2 48.5 -> 29.8.
+        //      Not above 1024 rows (2048^2: four rounds of one 512-thread workgroup per CU: sym8 8192^2 280 us, 4096^2 too: 356).
         if constexpr (sizeof(T) == 4) {
             auto al4 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
-            if (path == 0 && F >= 12 && F <= 20 && (F % 2) == 0 && two_d && env_int("WL_TILE_LONG", 1) && n[0] <= env_int("WL_TILE_LONG_MAX", 256) &&
-                n[1] <= env_int("WL_TILE_LONG_MAX", 256) && cur_st.s[0] == 1 && (cur_st.s[1] % 4) == 0 && al4(cur) && (b.full.s[1] % 4) == 0 && al4(y) &&
+            if (path == 0 && F >= 12 && F <= 20 && (F % 2) == 0 && two_d && env_int("WL_TILE_LONG", 1) && n[0] <= env_int("WL_TILE_LONG_MAX", 1024) &&
+                n[1] <= env_int("WL_TILE_LONG_MAX", 1024) && cur_st.s[0] == 1 && (cur_st.s[1] % 4) == 0 && al4(cur) && (b.full.s[1] % 4) == 0 && al4(y) &&
                 al4(llbuf) && b.full.s[0] == 1) {
                 int NL = (L - l + 1) >= 2 ? 2 : 1;
                 while (NL > 1 && !fwd2d_tile_ok(F, NL, n[0], n[1])) --NL;

@@ -73,17 +73,19 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
     typedef TT F4t __attribute__((ext_vector_type(4)));
     constexpr int SH = (F - 2) / 2;
     constexpr int RQ = (R + 3) / 4;                 // row quads of the input
+    // g[m] = (-1)^m h[m] exactly (make_taps): only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap
+    auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -tp.h[m] : tp.h[m]; };
     // ---- dim-2 pass: X (R x C) -> T: columns [0, CN) = s (window columns 2k .. 2k+F-1), columns [CN, CN+OWN) = d[k + SH]
     for (int it = tid; it < RQ * CN; it += nthr) {
         const int iq = it % RQ, k = it / RQ;
         const TT *p = X + 4 * iq + (2 * k) * ldX;
         F4t x0 = *reinterpret_cast<const F4t *>(p);
-        F4t s = tp.h[0] * x0, d = tp.g[F - 1] * x0;
+        F4t s = tp.h[0] * x0, d = gq(F - 1) * x0;
 #pragma unroll
         for (int m = 1; m < F; ++m) {
             const F4t xm = *reinterpret_cast<const F4t *>(p + m * ldX);
             s = s + tp.h[m] * xm;
-            d = d + tp.g[F - 1 - m] * xm;
+            d = d + gq(F - 1 - m) * xm;
         }
         *reinterpret_cast<F4t *>(T + 4 * iq + k * ldT) = s;
         if (k < OWN) *reinterpret_cast<F4t *>(T + 4 * iq + (CN + k) * ldT) = d;
@@ -107,9 +109,9 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
             TT s = tp.h[0] * E[2 * j];
 #pragma unroll
             for (int m = 1; m < F; ++m) s = s + tp.h[m] * E[2 * j + m];
-            TT d = tp.g[F - 1] * E[2 * j + 2 * DS + 2 - F];
+            TT d = gq(F - 1) * E[2 * j + 2 * DS + 2 - F];
 #pragma unroll
-            for (int m = F - 2; m >= 0; --m) d = d + tp.g[m] * E[2 * j + 2 * DS + 1 - m];
+            for (int m = F - 2; m >= 0; --m) d = d + gq(m) * E[2 * j + 2 * DS + 1 - m];
             so[j] = s; dO[j] = d;
         }
         const bool is_s = c < CN;
@@ -134,8 +136,9 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
     lds_barrier();
 }
 
+// (12..20 taps: 512 threads -- with 1024 the 128-VGPR budget spilled 28 registers of the 24- / 32-row dim-1 window to scratch)
 template <typename T, int F, int NL>
-__global__ void __launch_bounds__(1024) k_fwd2d_tile(TileArgs<T, F> a)
+__global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T, F> a)
 {
     typedef TileLds<F, NL> L;
     typedef T F4t __attribute__((ext_vector_type(4)));
@@ -321,7 +324,9 @@ static hipError_t launch_tile_fn(hipStream_t st, const TileArgs<T, F> &a)
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    hipLaunchKernelGGL((k_fwd2d_tile<T, F, NL>), dim3((unsigned)(a.M / 64), (unsigned)(a.N / 64)), dim3((unsigned)opt("WL_TILE_THREADS", 1024)), shmem, st, a);
+    unsigned nthr = (unsigned)opt("WL_TILE_THREADS", 1024);
+    if (F > 10 && nthr > 512) nthr = 512;
+    hipLaunchKernelGGL((k_fwd2d_tile<T, F, NL>), dim3((unsigned)(a.M / 64), (unsigned)(a.N / 64)), dim3(nthr), shmem, st, a);
     return hipGetLastError();
 }
 

@@ -376,6 +376,7 @@ def test_long_filter_single_pass_2d_inverse_kernel(gpu, W, oracle, dtype, wmain,
     same bits."""
     W.set_option("WL_INVLONG_W", wmain)
     W.set_option("WL_INVLONG_TP", tp)
+    W.set_option("WL_TILE_INV_LONG", 0)              # (round 5: the small blocks would otherwise take the two-level inverse tiles, own test below)
     W.set_option("WL_INVLONG_D", {8: 1, 20: 2, 64: 4}[tp])
     W.set_option("WL_INVLONG_PPL", {8: 2, 20: 1, 64: 0}[tp])       # pairs per lane: forced 2, forced 1 (Float32, W = 1), by size
     W.set_option("WL_INVLONG_WAVES_PER_CU", 0)
@@ -1958,3 +1959,24 @@ def test_3d_box_beyond_2_31_elements(gpu, W):
     del xr, x
     W.destroy_contexts()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_long_filter_inverse_tiles_bitexact(gpu, W, oracle, dtype):
+    """Round 5: the two-level inverse LDS tiles (k_inv2d_tile2, wl_tile.hip) also serve the 12..20-tap filters: the reconstruction
+    levels of 128 .. 1024 output rows run two per launch instead of one streaming launch each (and two line passes at 128^2).
+    Bit for bit against the oracle and against the per-level tier (transforms_filter.jl:151-155,174-183)."""
+    for (n0, n1, L) in ((1024, 1024, 10), (512, 512, 3), (256, 256, 8), (128, 128, 7), (1024, 256, 2), (256, 1024, 8), (2048, 2048, 5)):
+        y = rng_array((n0, n1), dtype, n0 + 3 * n1)
+        yd = dev(W, y)
+        for fname in ("db6", "db7", "sym8", "db9", "db10", "coif4", "beyl"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            if n0 * n1 > 1 << 20 and fname not in ("sym8", "db10"):
+                continue
+            x = host(W, W.idwt(yd, wt, L))
+            k = W.last_kernel()
+            W.set_option("WL_TILE_INV_LONG", 0)
+            x0 = host(W, W.idwt(yd, wt, L))
+            W.clear_options()
+            assert np.array_equal(x, x0), (n0, n1, L, fname, k, int((x != x0).sum()))
+            assert np.array_equal(x, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (n0, n1, L, fname, k)

@@ -1182,7 +1182,9 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
             }
         }
         // ---- small 2-D blocks: two levels (l and l-1) per launch, LDS tiles (wl_tile.hip) ----
-        if (!done && fastF && two_d && path == 0 && l >= 2 && i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
+        // (round 5: 12..20 taps as well -- these levels ran one streaming launch each and the 128^2 level as two line passes)
+        if (!done && (fastF || (F >= 12 && F <= 20 && (F % 2) == 0 && i_env("WL_TILE_INV_LONG", 1) != 0)) && two_d && path == 0 && l >= 2 &&
+            i_env("WL_TILE_INV", 1) != 0 && b.full.s[0] == 1) {
             int64_t n1[3];
             level_box(b, l - 1, n1);                        // output extents of the shallower level
             if (inv2d_tile2_ok<T>(F, n1[0], n1[1]) && n1[0] <= i_env("WL_TILE_INV_MAX", 1024) && n1[1] <= i_env("WL_TILE_INV_MAX", 1024)) {

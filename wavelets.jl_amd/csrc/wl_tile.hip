@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(1024) k_inv2d_tile2(TileInvArgs<T, F> a)
 template <typename T>
 bool inv2d_tile2_ok(int F, int64_t M, int64_t N)
 {
-    if (F < 2 || F > 10 || (F & 1)) return false;
+    if (F < 2 || F > 20 || (F & 1)) return false;      // (round 5: 12..20 taps too -- the staged pieces grow with (F-2)/2, 66 KB at 16 taps Float32)
     return M >= 128 && N >= 128 && M <= 1024 && N <= 1024 && (M % 64) == 0 && (N % 64) == 0;
 }
 
@@ -525,6 +525,11 @@ hipError_t inv2d_tile2_launch(hipStream_t st, const Taps<T> &taps, const T *x, i
     case 6: return launch_inv_tile2_f<T, 6>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
     case 8: return launch_inv_tile2_f<T, 8>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
     case 10: return launch_inv_tile2_f<T, 10>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 12: return launch_inv_tile2_f<T, 12>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 14: return launch_inv_tile2_f<T, 14>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 16: return launch_inv_tile2_f<T, 16>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 18: return launch_inv_tile2_f<T, 18>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
+    case 20: return launch_inv_tile2_f<T, 20>(st, taps, x, ldx, ll, ldl, dst, ldd, M, N);
     default: return hipErrorInvalidValue;
     }
 }

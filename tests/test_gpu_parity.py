@@ -211,6 +211,9 @@ def test_long_filter_kernels(gpu, W, oracle, dtype):
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
                 # inverse, 12..20 taps, output rows a multiple of 256: one pass per level as well, both element types (wl_inv2d_long.hip, round 4)
                 kinv = "k_inv2d_lds_long" if (flen <= 20 and len(shape) == 2 and shape[0] % 256 == 0 and shape[0] >= 256) else kexp
+                # ... the last two levels of a block of <= 1024 rows in one launch of the two-level inverse tiles (round 5)
+                if kinv == "k_inv2d_lds_long" and max(shape) <= 1024 and min(shape) >= 128 and L >= 2:
+                    kinv = "k_inv2d_tile2"
                 assert W.last_kernel() == kinv or not big, (fname, shape, L, W.last_kernel())
                 assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (fname, shape, L, "inv")
         xm = rng_array((4096, 5), dtype, flen)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# option sweeps through tools/wlbench.bin (per-context options, no rebuild): bash tools/sweep_opts.sh   (GPU box, repo root)
+# Option sweeps through tools/wlbench.bin (per-context options: no rebuild).  On the GPU box, from the repo root:
+#   bash tools/sweep_opts.sh "<wlbench args>" OPT_A:1,OPT_B:2 OPT_A:0 ...     one line per option set (and one without options),
+#   three runs each, 200 back-to-back calls on three rotating inputs.  Example (round 5, the long-filter inverse tiles):
+#   bash tools/sweep_opts.sh "n0=8192 n1=8192 L=13 fw=0 filt=sym8" WL_TILE_INV_LONG:0
 B=./tools/wlbench.bin
-run() { echo -n "$* : "; for r in 1 2 3; do $B "$@" mode=seq reps=200 warm=60 rot=3 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['avg_us'], end=' ')"; done; echo; }
-for f in db6 sym8 db10; do
-  for v in 1 0; do run n0=8192 n1=8192 L=13 fw=0 filt=$f opt=WL_TILE_INV_LONG:$v; done
-done
-for v in 1 0; do run n0=8192 n1=8192 L=13 fw=0 filt=sym8 dtype=f64 opt=WL_TILE_INV_LONG:$v; done
-for v in 1 0; do run n0=1024 n1=1024 L=10 fw=0 filt=sym8 opt=WL_TILE_INV_LONG:$v; done
-for v in 1 0; do run n0=512 n1=512 L=9 fw=0 filt=db6 opt=WL_TILE_INV_LONG:$v; done
+ARGS=$1; shift
+run() { echo -n "${2:-(default)} : "; for r in 1 2 3; do $B $1 mode=seq reps=200 warm=60 rot=3 ${2:+opt=$2} | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['avg_us'], end=' ')"; done; echo; }
+run "$ARGS"
+for o in "$@"; do run "$ARGS" "$o"; done

@@ -1983,3 +1983,28 @@ def test_long_filter_inverse_tiles_bitexact(gpu, W, oracle, dtype):
             W.clear_options()
             assert np.array_equal(x, x0), (n0, n1, L, fname, k, int((x != x0).sum()))
             assert np.array_equal(x, oracle.dwt_filter(y, wt.qmf, L, fw=False)), (n0, n1, L, fname, k)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lifting_two_level_tiles_2d(gpu, W, oracle, dtype):
+    """Round 5: k_lift2d_tile2_fwd -- two forward 2-D lifting levels per launch on the cache-resident blocks (128 .. 2048 rows): the
+    first level's approximation stays in LDS.  Bit for bit against the oracle and against the one-level tiles: the three shipped
+    schemes, both element types, odd / even numbers of levels, the 2 x 2 tile grid (cones wrap onto the tile's own block)
+    (transforms_lifting.jl:128-194)."""
+    for n, Ls in ((128, (1, 2, 3, 7)), (256, (2, 8)), (512, (3, 4)), (1024, (2, 10)), (2048, (5,)), (192, (2, 6)), (4096, (5,))):
+        x = rng_array((n, n), dtype, n)
+        xd = dev(W, x)
+        for sname in ("cdf97", "db2", "haar"):
+            if n >= 2048 and sname != "cdf97":
+                continue
+            sch = W.wavelet(getattr(W.WT, sname), W.WT.Lifting)
+            for L in Ls:
+                W.set_option("WL_LIFT_TILE2_MAX", 4096)               # (default: Float32 blocks of <= 1024 rows; forced on for every size
+                W.set_option("WL_LIFT_TILE2_F64", 1)                  #  and for Float64 here)
+                y = host(W, W.dwt(xd, sch, L))
+                W.set_option("WL_LIFT_TILE2", 0)
+                y0 = host(W, W.dwt(xd, sch, L))
+                W.clear_options()
+                assert np.array_equal(y, y0), (n, sname, L, int((y != y0).sum()), np.argwhere(y != y0)[:4].tolist())
+                if n <= 1024:
+                    assert np.array_equal(y, oracle.dwt_lifting(x, sch, L)), (n, sname, L)

@@ -98,6 +98,10 @@ hipError_t fwd2d_tileB_launch(hipStream_t st, const Taps<float> &taps, const flo
 // one 2-D lifting level of a square block of 128 ... 2048 rows (a multiple of 64) in one launch of 64 x 64 tiles (wl_lift_tile.hip);
 // id = the scheme shape (even: forward, odd: inverse); arguments as the level kernels of wl_lift.hip
 bool lift2d_tile_ok(int id, int64_t n);
+bool lift2d_tile2_ok(int id, int64_t n);
+template <typename T>
+hipError_t lift2d_tile2_fwd_launch(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll, int64_t ldl,
+                                   int64_t n);
 template <typename T>
 hipError_t lift2d_tile_launch(int id, int fw, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
                               int64_t ldl, int64_t n);

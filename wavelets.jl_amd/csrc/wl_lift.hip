@@ -2956,6 +2956,18 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
                 any_fast = true;
                 break;
             }
+            // (round 5) ... two levels per launch where two are left, Float32, up to 1024 rows: the level-l approximation stays in LDS
+            // (k_lift2d_tile2_fwd).  cdf9/7 full depth: 1024^2 42.5 -> 34.0 us, 2048^2 58.2 -> 50.2, 4096^2 99.5 -> 92.8, 8192^2 218.4 -> 216.4.
+            // Not from 2048 rows (1024 tiles of 512 threads with a 1.9 x halo: 58 -> 65 us) and not for Float64 (79 KB of LDS: 51.5 -> 62.7).
+            if (aligned && (sizeof(T) == 4 || l_env("WL_LIFT_TILE2_F64", 0) != 0) && l_env("WL_LIFT_TILE", 1) != 0 && l_env("WL_LIFT_TILE2", 1) != 0 && (L - l + 1) >= 2 && n <= l_env("WL_LIFT_TILE2_MAX", 1024) &&
+                lift2d_tile2_ok(id, n) && (cur_ls % VEC) == 0 && al16(cur) && al16(llbuf) && cur != y) {
+                const bool last2 = (l + 1 == L);
+                WL_E((lift2d_tile2_fwd_launch<T>(id, st, sc, cur, cur_ls, y, ldy, last2 ? (T *)nullptr : llbuf, n >> 2, n)));
+                any_fast = true; tiled = true;
+                cur = llbuf; cur_ls = n >> 2; pp ^= 1;
+                ++l;
+                continue;
+            }
             // cache-resident levels: 64 x 64 tiles, one launch per level without the marching kernels' latency chain
             if (aligned && l_env("WL_LIFT_TILE", 1) != 0 && n <= l_env("WL_LIFT_TILE_MAX", 2048) && lift2d_tile_ok(id, n) && (id == 0 || id == 2 || id == 4) &&
                 (cur_ls % VEC) == 0 && al16(cur) && al16(llbuf) && cur != y) {

@@ -183,6 +183,170 @@ __global__ void __launch_bounds__(256) k_lift2d_tile_fwd(LiftTileArgs<T> a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// forward, TWO levels per launch (round 5): the tile above with the level-1 approximation kept in LDS.  The second level needs the
+// 32 x 32 level-1 approximations of the tile plus its own cone (HS samples on every side), so level 1 runs on a region widened
+// accordingly -- P1 = 32 + 2 HS "approximation-owned" pairs per dimension, 2 P1 + 2 HS staged samples (88 for cdf9/7) -- and stores
+// the details of the 32 x 32 truly owned pairs only; its approximations go to a second LDS array on which level 2 is the same
+// two passes at half the size.  Cones are recomputed, tiles are independent; the level-1 approximation never reaches memory.
+// 512 threads: every pass maps one segment position to a wave (seg_line_steps takes the wave-uniform position tests).
+template <int ID>
+struct TileGeom2 {
+    static constexpr int HPE = TileGeom<ID>::HPE, HS = TileGeom<ID>::HS;
+    static constexpr int P1 = 32 + 2 * HS;              // level-1 pairs per dimension whose approximation level 2 needs
+    static constexpr int REG1 = 2 * P1 + 2 * HS;        // staged samples per dimension
+    static constexpr int LD1 = REG1 + 4;
+    static constexpr int REG2 = P1;                     // level-2 region: 32 owned samples + HS on every side
+    static constexpr int LD2 = REG2 + 4;
+    static constexpr int ELEMS = LD1 * REG1 + LD2 * REG2 + 16;
+};
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(512) k_lift2d_tile2_fwd(LiftTileArgs<T> a)
+{
+    typedef TileGeom2<ID> G;
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    constexpr int HPE = G::HPE, HS = G::HS, P1 = G::P1, REG1 = G::REG1, LD1 = G::LD1, REG2 = G::REG2, LD2 = G::LD2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);             // level-1 region, column-major, leading dimension LD1
+    T *Q = P + LD1 * REG1;                              // level-1 approximations of the P1 x P1 pairs = the level-2 region
+    const int tid = threadIdx.x;
+    const int n = a.n, h = n >> 1, h2 = n >> 2;
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    // ---- stage: P[r + c * LD1] = x[(64 bx - 3 HS + r) mod n, (64 by - 3 HS + c) mod n] ----
+    {
+        constexpr int CPC = REG1 / VEC, NCH = CPC * REG1, PER = (NCH + 511) / 512;
+        V v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 512 * u;
+            if (id < NCH) {
+                const int col = id / CPC, cc = id - col * CPC;
+                const int gi = wrap_into(64 * bx - 3 * HS + VEC * cc, n), gj = wrap_into(64 * by - 3 * HS + col, n);
+                v[u] = *reinterpret_cast<const V *>(a.src + gi + (int64_t)gj * a.lds);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 512 * u;
+            if (id < NCH) {
+                const int col = id / CPC, cc = id - col * CPC;
+                *reinterpret_cast<V *>(P + VEC * cc + col * LD1) = v[u];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ================= level 1, dim 2: task = (region row r, half of the P1 column pairs) =================
+    {
+        constexpr int SEG = P1 / 2, NP = SEG + 2 * HPE;
+        const int seg = (tid >> 6) & 1, r = ((tid >> 7) << 6) + (tid & 63);          // waves 0..3 (rows 0..127), one segment per wave
+        const bool active = (tid < 256) && r < REG1;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                s[q] = P[r + (2 * (SEG * seg + q)) * LD1];
+                d[q] = P[r + (2 * (SEG * seg + q) + 1) * LD1];
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * by - HS - HPE + SEG * seg, h), h);
+        }
+        lds_barrier();
+        if (active) {
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; ++q) {
+                P[r + (2 * (SEG * seg + q)) * LD1] = s[q] * a.norm1;
+                P[r + (2 * (SEG * seg + q) + 1) * LD1] = d[q] * a.norm2;
+            }
+        }
+        lds_barrier();
+    }
+    // ================= level 1, dim 1: task = (one of the 2 P1 columns, quarter of the P1 row pairs) =================
+    {
+        constexpr int SEG = P1 / 4, NP = SEG + 2 * HPE;
+        static_assert((P1 % 4) == 0 && ((2 * SEG) % VEC) == 0 && ((2 * NP) % VEC) == 0, "segments must stay 16-byte aligned");
+        const int seg = tid >> 7, jc = tid & 127;                                    // waves 2 seg, 2 seg + 1: columns 0..127 of that segment
+        if (jc < 2 * P1) {
+            const int c = HS + jc;                      // region column: even = scaling column of pair jc / 2, odd = detail column
+            T v[2 * NP];
+#pragma unroll
+            for (int e = 0; e < 2 * NP / VEC; ++e) {
+                const V t = *reinterpret_cast<const V *>(P + 2 * SEG * seg + VEC * e + c * LD1);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[VEC * e + i] = t[i];
+            }
+            T s[NP], d[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { s[q] = v[2 * q]; d[q] = v[2 * q + 1]; }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * bx - HS - HPE + SEG * seg, h), h);
+            const bool dcol = (jc & 1) != 0;
+            const int pc = (jc >> 1) - HS;              // column pair relative to the tile's owned pairs (owned: 0 .. 31)
+            const bool cown = pc >= 0 && pc < 32;
+            const int gkc = 32 * by + pc;               // global column pair (valid where cown)
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) {
+                const T so = s[HPE + q] * a.norm1, dO = d[HPE + q] * a.norm2;
+                const int pr = SEG * seg + q - HS;      // row pair relative to the owned ones
+                if (!dcol) Q[(SEG * seg + q) + (jc >> 1) * LD2] = so;                // approximation: level 2's input (all P1 x P1)
+                if (cown && pr >= 0 && pr < 32) {
+                    const int gk = 32 * bx + pr;
+                    const int64_t col = (int64_t)((dcol ? h : 0) + gkc) * a.ldy;
+                    if (dcol) a.y[gk + col] = so;                                    // s rows of a detail column
+                    a.y[h + gk + col] = dO;                                          // d rows of either column
+                }
+            }
+        }
+    }
+    lds_barrier();
+    // ================= level 2 on Q (REG2 = 32 + 2 HS samples per dimension), as the one-level kernel at half the size =================
+    {
+        constexpr int SEG = 8, NP = SEG + 2 * HPE;
+        // dim 2: task = (region row r < REG2, half of the 16 owned column pairs): waves 0, 1
+        const int seg = (tid >> 6) & 1, r = tid & 63;
+        const bool active = (tid < 128) && r < REG2;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                s[q] = Q[r + (2 * (SEG * seg + q)) * LD2];
+                d[q] = Q[r + (2 * (SEG * seg + q) + 1) * LD2];
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(16 * by - HPE + SEG * seg, h2), h2);
+        }
+        lds_barrier();
+        if (active) {
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; ++q) {
+                Q[r + (2 * (SEG * seg + q)) * LD2] = s[q] * a.norm1;
+                Q[r + (2 * (SEG * seg + q) + 1) * LD2] = d[q] * a.norm2;
+            }
+        }
+        lds_barrier();
+    }
+    {
+        // dim 1: task = (owned column jc < 32, half of the 16 owned row pairs): waves 0, 1 (segment = wave)
+        constexpr int SEG = 8, NP = SEG + 2 * HPE;
+        const int seg = tid >> 6, jc = tid & 63;
+        if (tid < 128 && jc < 32) {
+            const int c = HS + jc;
+            T s[NP], d[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { s[q] = Q[2 * (SEG * seg + q) + c * LD2]; d[q] = Q[2 * (SEG * seg + q) + 1 + c * LD2]; }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(16 * bx - HPE + SEG * seg, h2), h2);
+            const int gk = 16 * bx + SEG * seg;          // first owned level-2 row pair of this task
+            const int gkc = 16 * by + (jc >> 1);
+            const bool dcol = (jc & 1) != 0;
+            T *const lo = (!dcol && a.ll) ? (a.ll + gk + (int64_t)gkc * a.ldl) : (a.y + gk + (int64_t)((dcol ? h2 : 0) + gkc) * a.ldy);
+            T *const hi = a.y + h2 + gk + (int64_t)((dcol ? h2 : 0) + gkc) * a.ldy;
+#pragma unroll
+            for (int q = 0; q < SEG; ++q) {
+                lo[q] = s[HPE + q] * a.norm1;
+                hi[q] = d[HPE + q] * a.norm2;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // inverse: the four quadrant pieces staged de-interleaved (scaling rows | detail rows, scaling columns | detail columns), dim-1
 // pass (normalize -> steps -> merge along the rows) on every region column, then dim-2 pass on the owned rows
 template <typename T, int ID>
@@ -288,6 +452,46 @@ hipError_t launch_tile_id(hipStream_t st, const LiftTileArgs<T> &a)
 }  // namespace
 
 bool lift2d_tile_ok(int id, int64_t n) { return id >= 0 && id <= 5 && n >= 128 && n <= 16384 && (n % 64) == 0; }
+// two forward levels per launch: the tile grid is that of the first level; the second level (n / 2) must still be a multiple of 32
+bool lift2d_tile2_ok(int id, int64_t n) { return (id == 0 || id == 2 || id == 4) && n >= 128 && n <= 16384 && (n % 64) == 0; }
+
+template <typename T, int ID>
+static hipError_t launch_tile2_fwd_id(hipStream_t st, const LiftTileArgs<T> &a)
+{
+    constexpr size_t shmem = (size_t)TileGeom2<ID>::ELEMS * sizeof(T);
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lift2d_tile2_fwd<T, ID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    const unsigned g = (unsigned)(a.n / 64);
+    hipLaunchKernelGGL((k_lift2d_tile2_fwd<T, ID>), dim3(g, g), dim3(512), shmem, st, a);
+    return hipGetLastError();
+}
+
+// ll: destination of the level-2 approximation (dense, leading dimension ldl) or nullptr (-> the top-left corner of y)
+template <typename T>
+hipError_t lift2d_tile2_fwd_launch(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll, int64_t ldl,
+                                   int64_t n)
+{
+    LiftTileArgs<T> a;
+    a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldl = ldl; a.n = (int)n;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    switch (id) {
+    case 0: return launch_tile2_fwd_id<T, 0>(st, a);
+    case 2: return launch_tile2_fwd_id<T, 2>(st, a);
+    case 4: return launch_tile2_fwd_id<T, 4>(st, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+template hipError_t lift2d_tile2_fwd_launch<float>(int, hipStream_t, const LiftScheme<float> &, const float *, int64_t, float *, int64_t, float *, int64_t, int64_t);
+template hipError_t lift2d_tile2_fwd_launch<double>(int, hipStream_t, const LiftScheme<double> &, const double *, int64_t, double *, int64_t, double *, int64_t,
+                                                    int64_t);
 
 template <typename T>
 hipError_t lift2d_tile_launch(int id, int fw, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,

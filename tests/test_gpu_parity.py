@@ -2008,3 +2008,13 @@ def test_lifting_two_level_tiles_2d(gpu, W, oracle, dtype):
                 assert np.array_equal(y, y0), (n, sname, L, int((y != y0).sum()), np.argwhere(y != y0)[:4].tolist())
                 if n <= 1024:
                     assert np.array_equal(y, oracle.dwt_lifting(x, sch, L)), (n, sname, L)
+                # ... and the two-level inverse tiles (k_lift2d_tile2_inv): the coarser level's result never leaves LDS
+                W.set_option("WL_LIFT_TILE2_MAX", 4096)
+                W.set_option("WL_LIFT_TILE2_F64", 1)
+                xr = host(W, W.idwt(dev(W, y0), sch, L))
+                W.set_option("WL_LIFT_TILE2", 0)
+                xr0 = host(W, W.idwt(dev(W, y0), sch, L))
+                W.clear_options()
+                assert np.array_equal(xr, xr0), (n, sname, L, "inverse", int((xr != xr0).sum()), np.argwhere(xr != xr0)[:4].tolist())
+                if n <= 1024:
+                    assert np.array_equal(xr, oracle.dwt_lifting(y0, sch, L, fw=False)), (n, sname, L, "inverse")

@@ -99,6 +99,10 @@ hipError_t fwd2d_tileB_launch(hipStream_t st, const Taps<float> &taps, const flo
 // id = the scheme shape (even: forward, odd: inverse); arguments as the level kernels of wl_lift.hip
 bool lift2d_tile_ok(int id, int64_t n);
 bool lift2d_tile2_ok(int id, int64_t n);
+bool lift2d_tile2_inv_ok(int id, int64_t n);
+template <typename T>
+hipError_t lift2d_tile2_inv_launch(int id, hipStream_t st, const LiftScheme<T> &sc, const T *x, int64_t ldx, T *out, int64_t ldo, const T *ll, int64_t ldl,
+                                   int64_t n);
 template <typename T>
 hipError_t lift2d_tile2_fwd_launch(int id, hipStream_t st, const LiftScheme<T> &sc, const T *src, int64_t lds, T *y, int64_t ldy, T *ll, int64_t ldl,
                                    int64_t n);

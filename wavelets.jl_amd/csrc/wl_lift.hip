@@ -3062,6 +3062,21 @@ int lifting_2d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, int64_t 
             const int64_t n = n0 >> (l - 1), h = n >> 1;
             T *out = (l == 1) ? y : (pp ? w.B : w.A);
             const int64_t ldo = (l == 1) ? ldy : n;
+            // (round 5) two reconstruction levels per launch (output 2 n <= 1024 rows, Float32): the coarser level's result is produced in
+            // LDS where the finer level's staging expects its approximation quadrant (k_lift2d_tile2_inv)
+            if (aligned && (sizeof(T) == 4 || l_env("WL_LIFT_TILE2_F64", 0) != 0) && l_env("WL_LIFT_TILE", 1) != 0 && l_env("WL_LIFT_TILE2", 1) != 0 && l >= 2 &&
+                2 * n <= l_env("WL_LIFT_TILE2_MAX", 1024) && lift2d_tile2_inv_ok(id, 2 * n) && (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0))) {
+                const int64_t nf = 2 * n;
+                T *out2 = (l - 1 == 1) ? y : (pp ? w.B : w.A);
+                const int64_t ldo2 = (l - 1 == 1) ? ldy : nf;
+                if (out2 != x) {
+                    WL_E((lift2d_tile2_inv_launch<T>(id, st, sc, x, ldy, out2, ldo2, llsrc, ll_ls, nf)));
+                    any_fast = true; tiled = true;
+                    llsrc = out2; ll_ls = ldo2; pp ^= 1;
+                    --l;
+                    continue;
+                }
+            }
             if (aligned && l_env("WL_LIFT_TILE", 1) != 0 && n <= l_env("WL_LIFT_TILE_MAX", 2048) && lift2d_tile_ok(id, n) && (id == 1 || id == 3 || id == 5) &&
                 (!llsrc || (al16(llsrc) && (ll_ls % 2) == 0)) && out != x) {
                 WL_E((lift2d_tile_launch<T>(id, 0, st, sc, x, ldy, out, ldo, const_cast<T *>(llsrc), ll_ls, n)));

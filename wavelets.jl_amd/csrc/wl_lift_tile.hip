@@ -440,6 +440,174 @@ __global__ void __launch_bounds__(256) k_lift2d_tile_inv(LiftTileArgs<T> a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// inverse, TWO levels per launch (round 5): the reconstruction of the coarser level is produced in LDS exactly where the finer
+// level's staging expects its approximation quadrant.  A tile owns 64 x 64 samples of the FINE output (n x n).  Fine level: REGP =
+// 32 + 2 HPE pairs per dimension as above; their scaling-row / scaling-column block (REGP x REGP samples of the coarse output) is
+// what the coarse level must deliver: OWc = REGP / 2 = 16 + HPE / 2 ... pairs per dimension plus its own cone, REGPc = OWc + 2 HPE staged
+// pairs.  Coarse dim-1 / dim-2 passes, then the fine ones of the one-level kernel.  a.src: coefficient array (both levels' details),
+// a.ll: approximation source of the COARSE level (or nullptr: the corner of a.src), a.y: the n x n result.
+template <int ID>
+struct TileGeomInv2 {
+    static constexpr int HPE = TileGeom<ID>::HPE;
+    static constexpr int REGP = TileGeom<ID>::REGP, REG = TileGeom<ID>::REG, LD = TileGeom<ID>::LD;
+    static constexpr int OWC = REGP / 2;                // coarse output pairs per dimension the fine level needs
+    static constexpr int REGPC = OWC + 2 * HPE;         // ... plus the coarse cone: staged coarse pairs
+    static constexpr int REGC = 2 * REGPC, LDC = REGC + 4;
+    static constexpr int ELEMS = LD * REG + LDC * REGC + 16;
+};
+
+template <typename T, int ID>
+__global__ void __launch_bounds__(256) k_lift2d_tile2_inv(LiftTileArgs<T> a)
+{
+    typedef TileGeomInv2<ID> G;
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    constexpr int HPE = G::HPE, HS = 2 * HPE, REG = G::REG, REGP = G::REGP, LD = G::LD;
+    constexpr int OWC = G::OWC, REGPC = G::REGPC, REGC = G::REGC, LDC = G::LDC;
+    static_assert((HPE % 2) == 0 && (OWC % 2) == 0, "the coarse region must start at a whole pair and split into two segments");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *P = reinterpret_cast<T *>(smem_raw);             // fine staging (layout of k_lift2d_tile_inv)
+    T *C = P + LD * REG;                                // coarse staging, same layout with REGPC
+    const int tid = threadIdx.x;
+    const int n = a.n, h = n >> 1, hc = n >> 2;
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    const int c0x = 16 * bx - HPE / 2 - HPE, c0y = 16 * by - HPE / 2 - HPE;      // global coarse pair of coarse region pair 0
+    // ---- stage the coarse pieces (scalar: the region starts at an odd row where HPE / 2 is odd) ----
+    {
+        const T *const lls = a.ll ? a.ll : a.src;
+        const int64_t ldl = a.ll ? a.ldl : a.lds;
+        for (int id = tid; id < REGC * REGC; id += 256) {
+            const int cs = id / REGC, rem = id - cs * REGC;
+            const int rdet = (rem >= REGPC) ? 1 : 0, cdet = (cs >= REGPC) ? 1 : 0;
+            const int gk = wrap_into(c0x + (rem - rdet * REGPC), hc), gc = wrap_into(c0y + (cs - cdet * REGPC), hc);
+            const T *p = (!rdet && !cdet) ? (lls + gk + (int64_t)gc * ldl) : (a.src + (rdet ? hc : 0) + gk + (int64_t)((cdet ? hc : 0) + gc) * a.lds);
+            C[rem + cs * LDC] = *p;
+        }
+    }
+    // ---- stage the fine detail pieces (the scaling x scaling block comes from the coarse level below) ----
+    {
+        constexpr int CPH = REGP / 2, NCH = 2 * CPH * REG, PER = (NCH + 255) / 256;
+        V2 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int cs = id / (2 * CPH), rem = id - cs * (2 * CPH);
+                const int rdet = (rem >= CPH) ? 1 : 0, cc = rem - rdet * CPH;
+                const int cdet = (cs >= REGP) ? 1 : 0;
+                if (rdet || cdet) {
+                    const int gk = wrap_into(32 * bx - HPE + 2 * cc, h), gc = wrap_into(32 * by - HPE + (cs - cdet * REGP), h);
+                    v[u] = *reinterpret_cast<const V2 *>(a.src + (rdet ? h : 0) + gk + (int64_t)((cdet ? h : 0) + gc) * a.lds);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int id = tid + 256 * u;
+            if (id < NCH) {
+                const int cs = id / (2 * CPH), rem = id - cs * (2 * CPH);
+                const int rdet = (rem >= CPH) ? 1 : 0, cdet = (cs >= REGP) ? 1 : 0;
+                if (rdet || cdet) *reinterpret_cast<V2 *>(P + 2 * rem + cs * LD) = v[u];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ================= coarse level, dim 1: task = (column slot cs < REGC, half of the OWC output row pairs); waves 0, 1 =================
+    {
+        constexpr int SEG = OWC / 2, NP = SEG + 2 * HPE;
+        const int seg = tid >> 6, cs = tid & 63;
+        const bool active = (tid < 128) && cs < REGC;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                s[q] = a.norm1 * C[SEG * seg + q + cs * LDC];
+                d[q] = a.norm2 * C[REGPC + SEG * seg + q + cs * LDC];
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(c0x + SEG * seg, hc), hc);
+        }
+        lds_barrier();
+        if (active) {
+            // merged rows of the owned pairs, interleaved: coarse output row 2 (SEG seg + q - HPE), + 1   (rows 0 .. REGP - 1)
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; ++q) {
+                C[2 * (SEG * seg + q - HPE) + cs * LDC] = s[q];
+                C[2 * (SEG * seg + q - HPE) + 1 + cs * LDC] = d[q];
+            }
+        }
+        lds_barrier();
+    }
+    // ================= coarse level, dim 2: task = (output row r < REGP, half of the OWC output column pairs); waves 0, 1 =================
+    {
+        constexpr int SEG = OWC / 2, NP = SEG + 2 * HPE;
+        const int seg = tid >> 6, r = tid & 63;
+        if (tid < 128 && r < REGP) {
+            T s[NP], d[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                s[q] = a.norm1 * C[r + (SEG * seg + q) * LDC];
+                d[q] = a.norm2 * C[r + (REGPC + SEG * seg + q) * LDC];
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(c0y + SEG * seg, hc), hc);
+            // coarse output (row r, columns 2 (SEG seg + q - HPE), + 1) = the fine level's scaling x scaling block
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; ++q) {
+                P[r + (2 * (SEG * seg + q - HPE)) * LD] = s[q];
+                P[r + (2 * (SEG * seg + q - HPE) + 1) * LD] = d[q];
+            }
+        }
+    }
+    lds_barrier();
+    // ================= fine level: the two passes of k_lift2d_tile_inv =================
+    {
+        constexpr int SEG = 16, NP = SEG + 2 * HPE;
+        const int seg = (tid >> 6) & 1, cs = ((tid >> 7) << 6) + (tid & 63);      // (one segment position per wave)
+        const bool active = cs < REG;
+        T s[NP], d[NP];
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < NP / VEC; ++e) {
+                const V t = *reinterpret_cast<const V *>(P + SEG * seg + VEC * e + cs * LD);
+                const V u = *reinterpret_cast<const V *>(P + REGP + SEG * seg + VEC * e + cs * LD);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { s[VEC * e + i] = a.norm1 * t[i]; d[VEC * e + i] = a.norm2 * u[i]; }
+            }
+            seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * bx - HPE + SEG * seg, h), h);
+        }
+        lds_barrier();
+        if (active) {
+#pragma unroll
+            for (int q = HPE; q < HPE + SEG; q += VEC / 2) {
+                V t;
+#pragma unroll
+                for (int i = 0; i < VEC / 2; ++i) { t[2 * i] = s[q + i]; t[2 * i + 1] = d[q + i]; }
+                *reinterpret_cast<V *>(P + 2 * (SEG * seg + q) + cs * LD) = t;
+            }
+        }
+        lds_barrier();
+    }
+    {
+        constexpr int SEG = 8, NP = SEG + 2 * HPE;
+        const int ir = tid & 63, seg = tid >> 6;
+        const int r = HS + ir;
+        T s[NP], d[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            s[q] = a.norm1 * P[r + (SEG * seg + q) * LD];
+            d[q] = a.norm2 * P[r + (REGP + SEG * seg + q) * LD];
+        }
+        seg_line_steps<T, ID, NP>(s, d, a.c, wrap_into(32 * by - HPE + SEG * seg, h), h);
+        T *const o = a.y + 64 * bx + ir + (int64_t)(2 * (32 * by + SEG * seg)) * a.ldy;
+#pragma unroll
+        for (int q = 0; q < SEG; ++q) {
+            o[(int64_t)(2 * q) * a.ldy] = s[HPE + q];
+            o[(int64_t)(2 * q + 1) * a.ldy] = d[HPE + q];
+        }
+    }
+}
+
 template <typename T, int ID, int FW>
 hipError_t launch_tile_id(hipStream_t st, const LiftTileArgs<T> &a)
 {
@@ -471,6 +639,48 @@ static hipError_t launch_tile2_fwd_id(hipStream_t st, const LiftTileArgs<T> &a)
     hipLaunchKernelGGL((k_lift2d_tile2_fwd<T, ID>), dim3(g, g), dim3(512), shmem, st, a);
     return hipGetLastError();
 }
+
+bool lift2d_tile2_inv_ok(int id, int64_t n) { return (id == 1 || id == 3 || id == 5) && n >= 256 && n <= 16384 && (n % 64) == 0; }
+
+template <typename T, int ID>
+static hipError_t launch_tile2_inv_id(hipStream_t st, const LiftTileArgs<T> &a)
+{
+    constexpr size_t shmem = (size_t)TileGeomInv2<ID>::ELEMS * sizeof(T);
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lift2d_tile2_inv<T, ID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done_dev = dev;
+    }
+    const unsigned g = (unsigned)(a.n / 64);
+    hipLaunchKernelGGL((k_lift2d_tile2_inv<T, ID>), dim3(g, g), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
+// two inverse levels: x = coefficient array (leading dimension ldx), ll = approximation source of the COARSER level (or nullptr: x's
+// corner), out = the n x n reconstruction of the finer level
+template <typename T>
+hipError_t lift2d_tile2_inv_launch(int id, hipStream_t st, const LiftScheme<T> &sc, const T *x, int64_t ldx, T *out, int64_t ldo, const T *ll, int64_t ldl,
+                                   int64_t n)
+{
+    LiftTileArgs<T> a;
+    a.src = x; a.lds = ldx; a.y = out; a.ldy = ldo; a.ll = const_cast<T *>(ll); a.ldl = ldl; a.n = (int)n;
+    for (int i = 0; i < LIFT_FAST_STEPS; ++i)
+        for (int k = 0; k < WL_MAX_NCOEF; ++k) a.c[i][k] = (i < sc.nsteps) ? sc.step[i].c[k] : (T)0;
+    a.norm1 = sc.norm1; a.norm2 = sc.norm2;
+    switch (id) {
+    case 1: return launch_tile2_inv_id<T, 1>(st, a);
+    case 3: return launch_tile2_inv_id<T, 3>(st, a);
+    case 5: return launch_tile2_inv_id<T, 5>(st, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+template hipError_t lift2d_tile2_inv_launch<float>(int, hipStream_t, const LiftScheme<float> &, const float *, int64_t, float *, int64_t, const float *, int64_t,
+                                                   int64_t);
+template hipError_t lift2d_tile2_inv_launch<double>(int, hipStream_t, const LiftScheme<double> &, const double *, int64_t, double *, int64_t, const double *,
+                                                    int64_t, int64_t);
 
 // ll: destination of the level-2 approximation (dense, leading dimension ldl) or nullptr (-> the top-left corner of y)
 template <typename T>

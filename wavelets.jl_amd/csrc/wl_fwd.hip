@@ -1354,7 +1354,9 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                 int NL = L - l + 1;
                 if (NL > 3) NL = 3;
                 const int64_t nmax = n[0] > n[1] ? n[0] : n[1];
-                if (NL == 3 && (nmax > env_int("WL_TILE_NL3_MAX", 0) || sizeof(T) == 8)) NL = 2;
+                // three levels per tile launch from 512^2 down (round 5, with the approximation handed over through L2: 2048^2 full depth 34.7 -> 32.2 us,
+                // 512^2 20.1 -> 17.7, 8192^2 -2 %; round 4 measured it 4 % slower and kept two)
+                if (NL == 3 && (nmax > env_int("WL_TILE_NL3_MAX", 512) || sizeof(T) == 8)) NL = 2;
                 while (NL > 1 && !fwd2d_tile_ok(F, NL, n[0], n[1])) --NL;
                 if (fwd2d_tile_ok(F, NL, n[0], n[1])) {
                     const bool lastt = (l + NL - 1 == L);

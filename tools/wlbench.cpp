@@ -14,6 +14,7 @@
 //     dwtc=1                 batched column-wise transform of n1 signals of length n0 (wl_dwtc_filter)
 //     rot=1                  number of distinct input arrays the calls rotate over (bench.py rotates 3 x 256 MiB for C3)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -182,6 +183,27 @@ int main(int argc, char **argv)
            "\"avg_us\": %.2f, \"med_us\": %.2f, \"min_us\": %.2f, \"alg_TBps\": %.3f, \"frac8\": %.4f, \"kernel\": \"%s\", \"opt\": \"%s\", \"sum\": %.9g}\n",
            (long long)dims[0], (long long)dims[1], (long long)dims[2], nd, L, kv["filt"].c_str(), kv["dtype"].c_str(), fw, kv["mode"].c_str(), reps,
            avg * 1e3, med * 1e3, mn * 1e3, alg / (avg * 1e-3) / 1e12, alg / (avg * 1e-3) / 8e12, wl_last_kernel(ctx), kv["opt"].c_str(), sum);
+    // wgtime=DIR: experiment builds with -DWL_WGTIME export per-workgroup stamps of the last launch of each instrumented kernel family
+    // (8 words per workgroup) -> DIR/<family>.txt
+    if (kv.count("wgtime")) {
+        typedef int (*fn_t)(unsigned long long *, size_t);
+        for (const char *fam : {"pair", "tileB", "tile", "tail"}) {
+            const std::string sym = std::string("wl_debug_wgtimes_") + fam;
+            fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, sym.c_str());
+            if (!fn) continue;
+            std::vector<unsigned long long> t(8 * 8192);
+            if (fn(t.data(), t.size())) { fprintf(stderr, "%s failed\n", sym.c_str()); return 3; }
+            FILE *f = fopen((kv["wgtime"] + "/" + fam + ".txt").c_str(), "w");
+            if (!f) { fprintf(stderr, "cannot write to %s\n", kv["wgtime"].c_str()); return 3; }
+            for (size_t i = 0; i < 8192; ++i) {
+                if (!t[8 * i]) continue;
+                fprintf(f, "%zu", i);
+                for (int k = 0; k < 8; ++k) fprintf(f, " %llu", t[8 * i + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     wl_ctx_destroy(ctx);
     return 0;
 }

@@ -118,6 +118,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ... and one that also drains this wave's global loads (after staging HBM data into LDS)
 __device__ __forceinline__ void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Experiment builds only (tools/mkvariant.sh NAME "-DWL_WGTIME" file.hip): eight 100 MHz stamps per workgroup of the LAST launch of a
+// kernel family, read back through wl_debug_wgtimes_<family> (tools/wlbench.cpp wgtime=FILE wgsym=<family>; tools/wgtime_stats.py).
+#ifdef WL_WGTIME
+#define WL_STAMP_DECL(NAME)                                                                                              \
+    __device__ unsigned long long wl_dbg_##NAME[8 * 8192];                                                               \
+    extern "C" __attribute__((visibility("default"))) int wl_debug_wgtimes_##NAME(unsigned long long *host, size_t n)   \
+    {                                                                                                                    \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(wl_dbg_##NAME), n * sizeof(unsigned long long));               \
+    }
+#define WL_STAMP_AT(NAME, wg, k) do { if ((threadIdx.x & 63) == 0 && (wg) < 8192) wl_dbg_##NAME[8 * (wg) + (k)] = wall_clock64(); } while (0)
+#else
+#define WL_STAMP_DECL(NAME)
+#define WL_STAMP_AT(NAME, wg, k) do { } while (0)
+#endif
+
 constexpr __host__ __device__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // Whole-wave lane shifts on the VALU (DPP wave_shl:1 / wave_shr:1 -- gfx9-family controls, valid
@@ -277,6 +292,9 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 #ifndef WL_P_PAIR_ST2
 #define WL_P_PAIR_ST2 1     // ... level-(l+1) detail stores
 #endif
+#ifndef WL_P_PAIR_LL
+#define WL_P_PAIR_LL 2      // ... the level-(l+1) approximation (the next launch's input): write-through, see store_pol (r06)
+#endif
 #ifndef WL_P_LDS_LD
 #define WL_P_LDS_LD 1       // k_fwd2d_lds (Float32): column loads
 #endif
@@ -296,7 +314,14 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 #define WL_P_TILE_LD 0      // k_fwd2d_tileB: window loads
 #endif
 #ifndef WL_P_TILE_ST
-#define WL_P_TILE_ST 0      // ... detail stores
+#define WL_P_TILE_ST 2      // ... detail stores: write-through (r06: 2048^2 two levels 14.6 -> 12.7 us; with the approximation stores and the
+                            //     pair's, 8192^2 L = 13 133.7 -> 131.2: the dependent launch no longer waits for 16 MB of dirty lines)
+#endif
+#ifndef WL_P_TILE_LL
+#define WL_P_TILE_LL 2      // ... its approximation stores (k_fwd2d_tileB and k_fwd2d_tile)
+#endif
+#ifndef WL_P_TILE3_ST
+#define WL_P_TILE3_ST 2     // k_fwd2d_tile: detail stores
 #endif
 #ifndef WL_P_M1D_LD
 #define WL_P_M1D_LD 0       // k_fwd1d_multi: staging loads of the input tile
@@ -368,10 +393,14 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 #ifndef WL_P_LONG_ST
 #define WL_P_LONG_ST 1      // k_fwd2d_lds_long: detail stores (sym8 dwt 291.2 -> 286.1 us)
 #endif
-template <bool NT, typename V>
+// POL: 0 plain, 1 non-temporal, 2 write-through (`sc1`: the bytes leave the XCD's L2 at once and the line is dropped -- nothing of it
+// is left dirty for the end-of-kernel write-back that the next dependent launch waits for; 16-byte and 8-byte vectors only)
+template <int POL, typename V>
 __device__ __forceinline__ void store_pol(V *p, const V v)
 {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    if constexpr (POL == 2 && sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 2 && sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 template <bool NT, typename V>

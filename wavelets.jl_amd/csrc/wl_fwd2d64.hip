@@ -139,10 +139,10 @@ __global__ void __launch_bounds__(320, 3) k_fwd2d_lds64(Lds2DArgs64<F> a)
         T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy, *const cl = llb + k * ldl;      // (uniform)
         if (!odd) {
             *reinterpret_cast<T2 *>(cl + ko) = T2{P.x, rP};
-            store_pol<WL_P_LDS64_ST != 0>(reinterpret_cast<T2 *>(ck + (hmi + kod)), T2{Q.x, rQ});
+            store_pol<WL_P_LDS64_ST>(reinterpret_cast<T2 *>(ck + (hmi + kod)), T2{Q.x, rQ});
         } else {
-            store_pol<WL_P_LDS64_ST != 0>(reinterpret_cast<T2 *>(ckd + (ko - 1)), T2{rP, P.y});
-            store_pol<WL_P_LDS64_ST != 0>(reinterpret_cast<T2 *>(ckd + (hmi + kod - 1)), T2{rQ, Q.y});
+            store_pol<WL_P_LDS64_ST>(reinterpret_cast<T2 *>(ckd + (ko - 1)), T2{rP, P.y});
+            store_pol<WL_P_LDS64_ST>(reinterpret_cast<T2 *>(ckd + (hmi + kod - 1)), T2{rQ, Q.y});
         }
     };
 

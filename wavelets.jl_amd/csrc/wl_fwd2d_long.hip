@@ -184,10 +184,10 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
         T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy, *const cl = llb + k * ldl;      // (uniform)
         if (!odd) {
             *reinterpret_cast<T4 *>(cl + ko) = T4{P[0].x, P[1].x, rP[0], rP[1]};
-            store_pol<WL_P_LONG_ST != 0>(reinterpret_cast<T4 *>(ck + (hmi + kod)), T4{Q[0].x, Q[1].x, rQ[0], rQ[1]});
+            store_pol<WL_P_LONG_ST>(reinterpret_cast<T4 *>(ck + (hmi + kod)), T4{Q[0].x, Q[1].x, rQ[0], rQ[1]});
         } else {
-            store_pol<WL_P_LONG_ST != 0>(reinterpret_cast<T4 *>(ckd + (ko - 2)), T4{rP[0], rP[1], P[0].y, P[1].y});
-            store_pol<WL_P_LONG_ST != 0>(reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)), T4{rQ[0], rQ[1], Q[0].y, Q[1].y});
+            store_pol<WL_P_LONG_ST>(reinterpret_cast<T4 *>(ckd + (ko - 2)), T4{rP[0], rP[1], P[0].y, P[1].y});
+            store_pol<WL_P_LONG_ST>(reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)), T4{rQ[0], rQ[1], Q[0].y, Q[1].y});
         }
     };
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ void store4(T *p, const T (&v)[4])
         V t;
 #pragma unroll
         for (int i = 0; i < C; ++i) t[i] = v[c * C + i];
-        store_pol<(WL_P_ILONG_ST != 0 && sizeof(T) == 4)>(reinterpret_cast<V *>(p + c * C), t);
+        store_pol<((WL_P_ILONG_ST != 0 && sizeof(T) == 4) ? 1 : 0)>(reinterpret_cast<V *>(p + c * C), t);
     }
 }
 

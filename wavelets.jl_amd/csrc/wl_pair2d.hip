@@ -29,6 +29,9 @@
 #include "wl_fast.h"
 #include "wl_dev.h"
 
+WL_STAMP_DECL(pair)
+#define WL_STAMP(k) WL_STAMP_AT(pair, logical, k)
+
 namespace wl {
 
 template <int F>
@@ -40,7 +43,8 @@ struct Pair2DArgs {
     int TJ;                           // owned input columns per chunk (multiple of 32)
     int nstrips, nchunks;
     int rev;
-    int prio;                         // 1: the single-wave roles (helper, level-(l+1) wave) run at a raised priority
+    int prio;                         // 1: the single-wave roles (helper, level-(l+1) wave) run at a raised priority;  2, 3: see rr_div
+    int rr_div;                       // prio >= 2: issue priority rotates over the co-resident workgroups, rank = blockIdx / rr_div
     // BT instances (the planes of a translation-invariant denoise batch over blockIdx.y): plane strides, the virtual shift of
     // level 1 (plane p reads copy (spin0 + p) % src_mod with its columns rotated by (spin0 + p) / src_mod, as k_fwd2d_lds) and the
     // hard threshold applied to every final coefficient as it is stored (th < 0: none)
@@ -105,7 +109,20 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     // and a single-wave role that loses the VALU to the two main waves of four co-resident workgroups is what the others wait
     // for (measured r04, 8192^2: db4 115.1-115.3 -> 112.2-112.4 us, sym5 125.3 -> 123.9; main waves first: +1 %; rotating the
     // roles over the wave slots by workgroup: neutral or -4 %, the default placement is already the balanced one).
-    if (a.prio && wv >= W) __builtin_amdgcn_s_setprio(2);
+    if (a.prio == 1 && wv >= W) __builtin_amdgcn_s_setprio(2);
+    // prio >= 2: the CU arbitrates issue by priority, then AGE -- the first workgroup a CU received wins every conflict and finishes
+    // its chunk ~30 % earlier than the three dispatched after it, which then run on a CU that is a quarter empty (r06, per-workgroup
+    // stamps).  Rotating the priority over the workgroups (rank = dispatch round of the workgroup) every 8 steps equalises them.
+    const int rank = (a.prio >= 2 && a.rr_div > 0) ? (int)(b / (uint32_t)a.rr_div) : 0;
+    auto rot_prio = [&](const int i) __attribute__((always_inline)) {
+        switch ((rank + i) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
+    const int psh = (a.prio == 3) ? 4 : 3;
     if (wv == W + 1) {
         // =============================== the level-(l+1) wave ===============================
         const int j = (int)(threadIdx.x & 63);
@@ -115,7 +132,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         T2 *const xw = x2 + RW * j;
         const int64_t kbase2 = j0 >> 2;
         for (int t = 0; t < F; ++t) wg_lds_sync(true);
+        WL_STAMP(4);
         for (int t = F; t < S; t += 2) {
+            if (a.prio >= 2 && (t & 7) == 0) rot_prio(t >> psh);
             wg_lds_sync(true);                                               // barrier t (even): ring columns <= t-1 are visible
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -182,18 +201,19 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     }
                 }
                 if constexpr (HS == 4) {
-                    *reinterpret_cast<T4 *>(cl + s2row) = T4{P[0].x, P[1].x, P[2].x, P[3].x};
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ck + (hm2i + d2row)), T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x});
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ckd + s2row), T4{P[0].y, P[1].y, P[2].y, P[3].y});
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T4 *>(ckd + (hm2i + d2row)), T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y});
+                    store_pol<WL_P_PAIR_LL>(reinterpret_cast<T4 *>(cl + s2row), T4{P[0].x, P[1].x, P[2].x, P[3].x});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ck + (hm2i + d2row)), T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ckd + s2row), T4{P[0].y, P[1].y, P[2].y, P[3].y});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ckd + (hm2i + d2row)), T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y});
                 } else {
-                    *reinterpret_cast<T2 *>(cl + s2row) = T2{P[0].x, P[1].x};
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
-                    store_pol<WL_P_PAIR_ST2 != 0>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
+                    store_pol<WL_P_PAIR_LL>(reinterpret_cast<T2 *>(cl + s2row), T2{P[0].x, P[1].x});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
+                    store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
                 }
             }
         }
+        WL_STAMP(5);
         return;
     }
 
@@ -281,6 +301,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         };
         int t0 = 0;
         for (; t0 < S_own; t0 += U) {
+            if (a.prio >= 2) rot_prio(t0 >> psh);
 #pragma unroll
             for (int u = 0; u < U; ++u) hstep(t0 + u, u, true, true, true);
         }
@@ -301,6 +322,14 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     const T *base = srcp + row;
     const int64_t kbase = j0 >> 1;
 
+    if (wv == 0) WL_STAMP(0);
+#ifdef WL_WGTIME
+    if (threadIdx.x == 0 && logical < 8192) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hwid));
+        wl_dbg_pair[8 * logical + 7] = ((unsigned long long)blockIdx.x << 32) | ((xcc & 0xf) << 16) | (hwid & 0xffff);
+    }
+#endif
     T4 ring[R];
 #pragma unroll
     for (int c = 0; c < R; ++c) ring[c] = T4{0.f, 0.f, 0.f, 0.f};
@@ -431,24 +460,29 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
         }
         T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy;      // (uniform)
         if (!odd) {
-            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ck + (hmi + kod)), T4{Q[0].x, Q[1].x, rA[0], rA[1]});
+            store_pol<WL_P_PAIR_ST1>(reinterpret_cast<T4 *>(ck + (hmi + kod)), T4{Q[0].x, Q[1].x, rA[0], rA[1]});
         } else {
-            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ckd + (ko - 2)), T4{rA[0], rA[1], P[0].y, P[1].y});
-            store_pol<WL_P_PAIR_ST1 != 0>(reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)), T4{rB[0], rB[1], Q[0].y, Q[1].y});
+            store_pol<WL_P_PAIR_ST1>(reinterpret_cast<T4 *>(ckd + (ko - 2)), T4{rA[0], rA[1], P[0].y, P[1].y});
+            store_pol<WL_P_PAIR_ST1>(reinterpret_cast<T4 *>(ckd + (hmi + kod - 2)), T4{rB[0], rB[1], Q[0].y, Q[1].y});
         }
     };
 
+    if (wv == 0) WL_STAMP(1);
     int t0 = 0;
     for (; t0 < S_own; t0 += U) {
+        if (a.prio >= 2) rot_prio(t0 >> psh);
 #pragma unroll
         for (int u = 0; u < U; ++u) step(t0 + u, u, true, true, true);
+        if (wv == 0 && t0 == S_own / 2 - U) WL_STAMP(6);
     }
+    if (wv == 0) WL_STAMP(2);
     // F steps past the chunk: columns S_own .. S_own+F-3 of the approximation feed the last level-(l+1) columns; loads are needed
     // up to step S_own + F - 3 (requested PFD steps ahead).  2 taps: none of these steps waits for a load, yet the last PFD
     // steps' prefetches (columns nobody needs) are still on their way -- they must not land in registers the compiler reuses
     if constexpr (F == 2) drain_ring(ring);
 #pragma unroll
     for (int u = 0; u < F; ++u) step(t0 + u, u, u + PFD < F - 2, false, u < F - 2);
+    if (wv == 0) WL_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -484,7 +518,9 @@ static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool l
     a.TJ = TJ;
     a.nchunks = (int)((ns + TJ - 1) / TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
-    a.prio = opt("WL_PAIR_PRIO", 1) != 0 ? 1 : 0;
+    a.prio = (int)opt("WL_PAIR_PRIO", 1);
+    if (a.prio < 0 || a.prio > 3) a.prio = 1;
+    a.rr_div = cu_count > 0 ? cu_count : 256;
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     if (pb) {

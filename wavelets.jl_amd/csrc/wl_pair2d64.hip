@@ -118,9 +118,9 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
                 T *const ck = yb + k2 * a.ldy, *const ckd = yb + (nxj2 + kd2) * a.ldy, *const cl = llb + k2 * ldl;   // (uniform)
                 if constexpr (HS == 2) {
                     *reinterpret_cast<T2 *>(cl + s2row) = T2{P[0].x, P[1].x};
-                    store_pol<WL_P_PAIR64_ST2 != 0>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
-                    store_pol<WL_P_PAIR64_ST2 != 0>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
-                    store_pol<WL_P_PAIR64_ST2 != 0>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
+                    store_pol<WL_P_PAIR64_ST2>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
+                    store_pol<WL_P_PAIR64_ST2>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
+                    store_pol<WL_P_PAIR64_ST2>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
                 } else {
                     cl[s2row] = P[0].x;
                     ck[hm2i + d2row] = Q[0].x;
@@ -235,10 +235,10 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair64(Pair2DArgs64<F
         const T rB = from_partner(Q.y);
         T *const ck = yb + k * a.ldy, *const ckd = yb + (nxj + kd) * a.ldy;      // (uniform)
         if (!odd) {
-            store_pol<WL_P_PAIR64_ST1 != 0>(reinterpret_cast<T2 *>(ck + (hmi + kod)), T2{Q.x, rA});
+            store_pol<WL_P_PAIR64_ST1>(reinterpret_cast<T2 *>(ck + (hmi + kod)), T2{Q.x, rA});
         } else {
-            store_pol<WL_P_PAIR64_ST1 != 0>(reinterpret_cast<T2 *>(ckd + (ko - 1)), T2{rA, P.y});
-            store_pol<WL_P_PAIR64_ST1 != 0>(reinterpret_cast<T2 *>(ckd + (hmi + kod - 1)), T2{rB, Q.y});
+            store_pol<WL_P_PAIR64_ST1>(reinterpret_cast<T2 *>(ckd + (ko - 1)), T2{rA, P.y});
+            store_pol<WL_P_PAIR64_ST1>(reinterpret_cast<T2 *>(ckd + (hmi + kod - 1)), T2{rB, Q.y});
         }
     };
 

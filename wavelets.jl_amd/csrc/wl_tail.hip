@@ -14,6 +14,8 @@
 #include "wl_fast.h"
 #include "wl_dev.h"
 
+WL_STAMP_DECL(tail)
+
 namespace wl {
 
 template <typename T, int F>
@@ -53,6 +55,7 @@ __global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
     T *B = A + (size_t)ld * m1 + 8;
     const T *src = a.src + (int64_t)blockIdx.x * a.src_item;
     T *y = a.y + (int64_t)blockIdx.x * a.y_item;
+    if (tid == 0) WL_STAMP_AT(tail, 0, 0);
 
     // ---- stage the block (16-byte loads when the layout allows, all of a thread's loads in flight together) ----
     {
@@ -84,9 +87,11 @@ __global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
         }
     }
     if (multi) lds_barrier_vm(); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (tid == 0) WL_STAMP_AT(tail, 0, 1);
 
     for (int lev = 0; lev < a.nlev; ++lev) {
         const bool last = (lev == a.nlev - 1);
+        if (tid == 0 && lev >= 1 && lev <= 5) WL_STAMP_AT(tail, 0, 1 + lev);
         const int lgn0 = a.lg0 - lev, n0 = 1 << lgn0, h0 = n0 >> 1;
         if (a.nt == 2) {
             const int lgn1 = a.lg1 - lev, n1 = 1 << lgn1, h1 = n1 >> 1;
@@ -139,6 +144,7 @@ __global__ void __launch_bounds__(512) k_tail2_fwd(Tail2Args<T, F> a)
             T *t = A; A = B; B = t;
         }
     }
+    if (tid == 0) WL_STAMP_AT(tail, 0, 7);
 }
 
 template <typename T>

@@ -14,6 +14,9 @@
 #include "wl_fast.h"
 #include "wl_dev.h"
 
+WL_STAMP_DECL(tile)
+WL_STAMP_DECL(tileB)
+
 namespace wl {
 
 template <typename T, int F>
@@ -118,7 +121,7 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
         // approximation of an s-column: next level's input (all RN rows), or global when this is the launch's last level
         if (is_s) {
             if (!LAST) *reinterpret_cast<F4t *>(XN + 4 * q + c * ldN) = so;
-            else if (c < OWN && 4 * q < OWN) *reinterpret_cast<F4t *>(ll + (r0h + 4 * q) + (int64_t)(c0h + c) * ldll) = so;
+            else if (c < OWN && 4 * q < OWN) store_pol<WL_P_TILE_LL>(reinterpret_cast<F4t *>(ll + (r0h + 4 * q) + (int64_t)(c0h + c) * ldll), so);
         }
         // details: owned rows / columns only
         const int cc = is_s ? c : c - CN;
@@ -129,8 +132,8 @@ __device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT,
             int rd = r0h + 4 * q + DS;
             if (rd >= hm) rd -= hm;
             TT *yc = y + col * ldy;
-            *reinterpret_cast<F4t *>(yc + hm + rd) = dO;                // ds or dd
-            if (!is_s) *reinterpret_cast<F4t *>(yc + (r0h + 4 * q)) = so;  // sd
+            store_pol<WL_P_TILE3_ST>(reinterpret_cast<F4t *>(yc + hm + rd), dO);                // ds or dd
+            if (!is_s) store_pol<WL_P_TILE3_ST>(reinterpret_cast<F4t *>(yc + (r0h + 4 * q)), so);  // sd
         }
     }
     lds_barrier();
@@ -147,6 +150,8 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     constexpr int ld0 = L::ldx(L::R0), ld1 = L::ldx(L::R1), ld2 = L::ldx(L::R2);
+    [[maybe_unused]] const int wgid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    if (tid == 0) WL_STAMP_AT(tile, wgid, 0);
     // ---- stage X0[i + c*ld0] = src[(r0 + i) mod M, (c0 + c) mod N], 16-byte loads along dim 1 ----
     {
         constexpr int RQ0 = (L::R0 + 3) / 4;
@@ -159,6 +164,7 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
         }
     }
     lds_barrier_vm();
+    if (tid == 0) WL_STAMP_AT(tile, wgid, 1);
     const int hm = a.M >> 1, hn = a.N >> 1;
     if constexpr (NL == 1) {
         tile_level<T, F, L::R0, L::C0, 32, 32, 32, true>(S + L::X0, ld0, S + L::T, ld0, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 1,
@@ -166,16 +172,19 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
     } else {
         tile_level<T, F, L::R0, L::C0, L::R1, L::C1, 32, false>(S + L::X0, ld0, S + L::T, ld0, S + L::X1, ld1, a.tp, a.y, a.ldy, a.ll, a.ldll,
                                                              r0 >> 1, c0 >> 1, hm, hn, tid, nthr);
+        if (tid == 0) WL_STAMP_AT(tile, wgid, 2);
         if constexpr (NL == 2) {
             tile_level<T, F, L::R1, L::C1, 16, 16, 16, true>(S + L::X1, ld1, S + L::T, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2,
                                                           c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
         } else {
             tile_level<T, F, L::R1, L::C1, L::R2, L::C2, 16, false>(S + L::X1, ld1, S + L::T, ld1, S + L::X2, ld2, a.tp, a.y, a.ldy, a.ll,
                                                                  a.ldll, r0 >> 2, c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
+            if (tid == 0) WL_STAMP_AT(tile, wgid, 3);
             tile_level<T, F, L::R2, L::C2, 8, 8, 8, true>(S + L::X2, ld2, S + L::T, ld2, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 3,
                                                        c0 >> 3, hm >> 2, hn >> 2, tid, nthr);
         }
     }
+    if (tid == 0) WL_STAMP_AT(tile, wgid, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -186,6 +195,9 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
 // 62 KB and 1024.  Four workgroups per CU stay resident -- all 1024 tiles of a 2048^2 block at once -- where the staging
 // kernel kept two, each waiting on its own loads, barriers and partially idle passes (PMC, 2048^2: 64 % of the wave cycles
 // waiting, 41 % of the LDS cycles bank conflicts).
+#ifndef WL_TILEB_REMAP
+#define WL_TILEB_REMAP 1      // (r06: 2048^2 two levels 14.6 -> 13.7 us)
+#endif
 template <int F>
 __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
 {
@@ -198,8 +210,20 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
     __shared__ __attribute__((aligned(16))) T Ts[ldT * (C1 + 32)];
     __shared__ __attribute__((aligned(16))) T X1s[ld1 * C1 + 16];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int wgid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    // XCD-aware tile map (workgroup w runs on XCD w % 8): each XCD owns a compact gx/2 x gy/4 block of tiles, so that the halo rows /
+    // columns a tile shares with its neighbours are hits in the XCD's own L2 instead of a second fetch over the fabric
+    int tbx = (int)blockIdx.x, tby = (int)blockIdx.y;
+#if WL_TILEB_REMAP
+    if ((gridDim.x & 1) == 0 && (gridDim.y & 3) == 0) {
+        const int xcd = wgid & 7, i = wgid >> 3, rx = (int)gridDim.x >> 1;
+        tbx = (xcd & 1) * rx + i % rx;
+        tby = (xcd >> 1) * ((int)gridDim.y >> 2) + i / rx;
+    }
+#endif
+    const int r0 = tbx * 64, c0 = tby * 64;
     const int hm = a.M >> 1, hn = a.N >> 1;
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 0);
     // ---- level 1, dim-2 pass from global: T columns [0, C1) = s (window columns 2k .. 2k+F-1), [C1, C1+32) = d[k + SH] ----
     // A thread owns four rows and KG = 4 consecutive output columns: F + 6 column loads (all in flight together) instead of 4 F,
     // and the whole pass is one round of the workgroup (22 row quads x 10 column groups = 220 of 256 threads).
@@ -232,7 +256,9 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
             }
         }
     }
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 1);
     lds_barrier();
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 2);
     // ---- level 1, dim-1 pass (the second half of tile_level) ----
     {
         constexpr int SH = (F - 2) / 2;
@@ -268,15 +294,17 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
                 int rd = r0h + 4 * q + 4;
                 if (rd >= hm) rd -= hm;
                 T *yc = a.y + col * a.ldy;
-                store_pol<WL_P_TILE_ST != 0>(reinterpret_cast<F4t *>(yc + hm + rd), dO);                  // ds or dd
-                if (!is_s) store_pol<WL_P_TILE_ST != 0>(reinterpret_cast<F4t *>(yc + (r0h + 4 * q)), so);  // sd
+                store_pol<WL_P_TILE_ST>(reinterpret_cast<F4t *>(yc + hm + rd), dO);                  // ds or dd
+                if (!is_s) store_pol<WL_P_TILE_ST>(reinterpret_cast<F4t *>(yc + (r0h + 4 * q)), so);  // sd
             }
         }
     }
     lds_barrier();
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 3);
     // ---- level 2: LDS -> LDS as in the staging kernel ----
     tile_level<T, F, L::R1, L::C1, 16, 16, 16, true>(X1s, ld1, Ts, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2, c0 >> 2, hm >> 1,
                                                   hn >> 1, tid, nthr);
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 4);
 }
 
 template <int F>

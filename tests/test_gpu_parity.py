@@ -335,6 +335,56 @@ def test_fused_pair_2d_kernel(gpu, W, oracle, wmain, tj):
         assert np.array_equal(y, oracle.dwt_filter(x, wt.qmf, 2)), shape
 
 
+@pytest.mark.parametrize("tj", [32, 64, 128])
+def test_fused_pair_tile_launch(gpu, W, oracle, tj):
+    """WL_FUSE4 = 1 (opt-in, round 6): levels l .. l+3 in ONE launch -- the fused pair plus, behind in-launch hand-over words, the
+    64 x 64 two-level tiles of its approximation (fused_tile_role, wl_pair2d.hip: write-through stores, per-chunk progress words,
+    sc1 loads, the last tile zeroes the words).  Every chunk length (a tile then depends on 3 .. 11 chunks), every filter length,
+    depths that end inside / right after / well after the fused launch, non-square blocks; every call twice (the second call finds
+    the hand-over words as the first one left them) -- bit for bit against the oracle."""
+    W.set_option("WL_FUSE4", 1)
+    W.set_option("WL_LDS_PAIR_MIN", 0)
+    W.set_option("WL_TILEB_MIN", 0)
+    W.set_option("WL_TJ2", tj)
+    W.set_option("WL_PAIR_WG_PER_CU", 0)  # (keep the requested chunk length)
+    W.set_option("WL_TILE", 0)            # (the cache-resident tiers would take these small blocks before the pair does)
+    W.set_option("WL_M2D_MAX", 64)
+    shapes = (((2048, 1024), (4, 5, 10)), ((1024, 2048), (4, 6)), ((512, 512), (4, 9)), ((1536, 768), (4, 5, 8)), ((4096, 512), (4, 7)))
+    for shape, Ls in shapes:
+        W.set_option("WL_TILEB_MAX", max(shape) // 4)
+        x = rng_array(shape, np.float32, sum(shape) + tj)
+        xd = dev(W, x)
+        for fname in ("db4", "haar", "db2", "db3", "sym5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            for L in Ls:
+                ye = oracle.dwt_filter(x, wt.qmf, L)
+                for rep in range(2):
+                    y = host(W, W.dwt(xd, wt, L))
+                    assert W.last_kernel() == "k_fwd2d_pair_tile", (shape, L, W.last_kernel())
+                    if not np.array_equal(y, ye):
+                        bad = np.argwhere(y != ye)
+                        raise AssertionError((shape, fname, L, tj, rep, len(bad), bad.min(axis=0).tolist(), bad.max(axis=0).tolist(),
+                                              float(np.abs(y - ye).max())))
+    # the headline shape: 30 back-to-back calls into the same output, compared with the two-launch chain of the default dispatch
+    W.set_option("WL_LDS_PAIR_MIN", 1 << 24)
+    W.set_option("WL_TILEB_MIN", 1 << 21)
+    W.set_option("WL_TILEB_MAX", 2048)
+    W.set_option("WL_TILE", 1)
+    W.set_option("WL_M2D_MAX", 1024)
+    W.set_option("WL_TJ2", 128)
+    W.set_option("WL_PAIR_WG_PER_CU", 4)
+    x = dev(W, rng_array((8192, 8192), np.float32, 77))
+    wt = W.wavelet(W.WT.db4)
+    W.set_option("WL_FUSE4", 0)
+    yref = host(W, W.dwt(x, wt, 13))
+    assert W.last_kernel() == "k_fwd2d_pair"
+    W.set_option("WL_FUSE4", 1)
+    for rep in range(30):
+        y = W.dwt(x, wt, 13)
+    assert W.last_kernel() == "k_fwd2d_pair_tile"
+    assert np.array_equal(host(W, y), yref)
+
+
 @pytest.mark.parametrize("tj", [16, 50, 128])
 @pytest.mark.parametrize("wmain", [1, 2, 4])
 def test_long_filter_single_pass_2d_kernel(gpu, W, oracle, wmain, tj):

@@ -187,7 +187,7 @@ int main(int argc, char **argv)
     // (8 words per workgroup) -> DIR/<family>.txt
     if (kv.count("wgtime")) {
         typedef int (*fn_t)(unsigned long long *, size_t);
-        for (const char *fam : {"pair", "tileB", "tile", "tail"}) {
+        for (const char *fam : {"pair", "tileB", "tile", "tail", "ftile"}) {
             const std::string sym = std::string("wl_debug_wgtimes_") + fam;
             fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, sym.c_str());
             if (!fn) continue;

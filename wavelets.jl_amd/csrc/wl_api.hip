@@ -14,6 +14,7 @@ using namespace wl;
 #include "wl_ctx.h"
 
 thread_local const wl::Opts *wl::tl_opts = nullptr;
+thread_local unsigned *wl::tl_sync = nullptr;
 
 int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st, bool ordered)
 {
@@ -387,6 +388,22 @@ int wl_ctx_create(int device, wl_ctx **out)
     if (!c) return WL_ENOMEM;
     c->device = device;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // the hand-over block of the launches whose workgroups signal one another: zeroed once here, left zero by every launch
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t e = (prev == device) ? hipSuccess : hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc(&c->sync, wl::kSyncWords * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(c->sync, 0, wl::kSyncWords * sizeof(unsigned));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        if (e != hipSuccess) {
+            if (c->sync) (void)hipFree(c->sync);
+            delete c;
+            (void)hipGetLastError();
+            return WL_ENOMEM;
+        }
+    }
     *out = c;
     return WL_OK;
 }
@@ -396,9 +413,10 @@ int wl_ctx_destroy(wl_ctx *ctx)
     if (!ctx) return WL_EINVAL_ARG;
     {
         CallScope scope(ctx);                  // free on the context's device, leave the caller's device current
-        if (ctx->ws || ctx->aux || ctx->stage_ev[0]) (void)hipDeviceSynchronize();
+        (void)hipDeviceSynchronize();
         if (ctx->ws) { if (ctx->ws_pooled) { (void)hipFreeAsync(ctx->ws, nullptr); (void)hipStreamSynchronize(nullptr); } else (void)hipFree(ctx->ws); }
         if (ctx->aux) (void)hipFree(ctx->aux);
+        if (ctx->sync) (void)hipFree(ctx->sync);
         for (int k = 0; k < wl_ctx::kStage; ++k) {
             if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
             if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);

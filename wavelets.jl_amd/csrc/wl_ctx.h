@@ -9,6 +9,7 @@ struct wl_ctx {
     size_t ws_bytes = 0;
     bool ws_pooled = false;             // allocated from the stream-ordered pool (hipMallocAsync): released with hipFreeAsync
     void *aux = nullptr;                // small persistent block: order-statistic selection state (wl_ext.hip)
+    void *sync = nullptr;               // wl::kSyncWords zeroed words: in-launch hand-over flags (wl::tl_sync)
     int last_hip = 0;
     int path = 0;                       // 0 auto, 1 generic only
     const char *last_kernel = "none";
@@ -34,9 +35,11 @@ struct CallScope {
     bool switched = false;
     hipError_t err = hipSuccess;
     const wl::Opts *prev_opts;
-    explicit CallScope(wl_ctx *ctx) : prev_opts(wl::tl_opts)
+    unsigned *prev_sync;
+    explicit CallScope(wl_ctx *ctx) : prev_opts(wl::tl_opts), prev_sync(wl::tl_sync)
     {
         wl::tl_opts = &ctx->opts;
+        wl::tl_sync = static_cast<unsigned *>(ctx->sync);
         err = hipGetDevice(&prev);
         if (err == hipSuccess && prev != ctx->device) {
             err = hipSetDevice(ctx->device);
@@ -46,6 +49,7 @@ struct CallScope {
     ~CallScope()
     {
         wl::tl_opts = prev_opts;
+        wl::tl_sync = prev_sync;
         if (switched) (void)hipSetDevice(prev);
     }
     CallScope(const CallScope &) = delete;

@@ -417,6 +417,14 @@ __device__ __forceinline__ void gload16(V &dst, const T *p)
     if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// ... with `sc1`: the vector L1 is bypassed and the line is served coherently at agent scope -- for data that workgroups of the SAME
+// launch published with write-through (`sc1`) stores (the consumer side of store_pol<2>; guide: "sc1 stores AND sc1 loads")
+template <typename V, typename T>
+__device__ __forceinline__ void gload16_sc1(V &dst, const T *p)
+{
+    static_assert(sizeof(V) == 16, "one global_load_dwordx4");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
 // one row per lane (the halo wave of the fused pair kernel)
 template <bool NT = false, typename T>
 __device__ __forceinline__ void gload4(float &dst, const T *p)

@@ -86,6 +86,10 @@ hipError_t fwd2d_pair_launch(hipStream_t st, const Taps<float> &taps, bool lvl1,
 
 // Tile kernel for the cache-resident 2-D levels (wl_tile.hip): NL = 1..3 fused forward levels per launch, Float32, even F <= 10.
 bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N);
+// four levels per launch: the fused pair + the 64 x 64 two-level tiles of its approximation behind in-launch hand-over flags (wl_pair2d.hip)
+bool fwd2d_pair_tile_ok(int F, int64_t ms, int64_t ns, int cu_count);
+hipError_t fwd2d_pair_tile_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                                  float *ll2, int64_t ldll2, float *ll4, int64_t ldll4, int64_t ms, int64_t ns, int cu_count, unsigned *prog);
 template <typename T>
 hipError_t fwd2d_tile_launch(hipStream_t st, const Taps<T> &taps, int NL, const T *src, int64_t lds, T *y, int64_t ldy, T *ll,
                              int64_t ldll, int M, int N);

@@ -1508,6 +1508,26 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
                     nlev = 2;
                 else if (fwd2d_lds_ok(F, 1, n[0], n[1]))
                     nlev = 1;
+                // ... and FOUR on request (WL_FUSE4 = 1) when the two levels after the pair would be the tiles of k_fwd2d_tileB: the same tiles run
+                //     inside the pair's launch, each as soon as the pair workgroups it reads from have published their columns.  Built and
+                //     measured in round 6 (profiles/r06_c3_timeline.md): the tile work does hide under the pair (the tiles end 5-7 us after
+                //     the last pair workgroup instead of 19-20), but the pair is HBM-bound and its own end slips by as much -- 8192^2 L = 13
+                //     within +-1 us of the two-launch chain in five interleaved A/B runs.  Off by default: no gain to pay for in-launch hand-over.
+                if (nlev == 2 && (L - l + 1) >= 4 && opt("WL_FUSE4", 0) != 0 && tl_sync != nullptr && env_int("WL_TILEB", 1) &&
+                    (n[0] >> 2) <= env_int("WL_TILEB_MAX", 2048) && (n[1] >> 2) <= env_int("WL_TILEB_MAX", 2048) &&
+                    (n[0] >> 2) * (n[1] >> 2) >= (int64_t)env_int_raw("WL_TILEB_MIN", 1 << 21) && fwd2d_pair_tile_ok(F, n[0], n[1], cu_count)) {
+                    const bool last4 = (l + 3 == L);
+                    T *ll2buf = llbuf, *ll4buf = pp ? w.A : w.B;
+                    if (aligned16(ll4buf)) {
+                        WL_TRY(fwd2d_pair_tile_launch(st, taps, l == 1, cur, cur_st.s[1], y, b.full.s[1], ll2buf, n[0] >> 2, last4 ? (T *)nullptr : ll4buf,
+                                                      n[0] >> 4, n[0], n[1], cu_count, tl_sync));
+                        if (!dominant) dominant = "k_fwd2d_pair_tile";
+                        lstep = 4;
+                        int64_t hn4[3] = {n[0] >> 4, n[1] >> 4, n[2]};
+                        cur = ll4buf; cur_st = dense_strides(hn4);
+                        continue;
+                    }
+                }
                 if (nlev) {
                     const bool lastp = (l + nlev - 1 == L);
                     T *lld = lastp ? y : llbuf;

@@ -38,6 +38,10 @@ struct Opts {
     long long val[kMax];
 };
 extern thread_local const Opts *tl_opts;
+// The calling context's hand-over block (wl_ctx::sync): kSyncWords zero-initialised 32-bit words in device memory for launches whose
+// workgroups hand data to one another (the fused pair + tile launch, wl_pair2d.hip).  Every such launch leaves the block all zero.
+enum { kSyncWords = 16384 };
+extern thread_local unsigned *tl_sync;
 inline long long opt(const char *name, long long dflt)
 {
     const Opts *o = tl_opts;

@@ -30,7 +30,10 @@
 #include "wl_dev.h"
 
 WL_STAMP_DECL(pair)
+WL_STAMP_DECL(ftile)
 #define WL_STAMP(k) WL_STAMP_AT(pair, logical, k)
+#define WL_TB_STAMP(wg, k) WL_STAMP_AT(ftile, wg, k)
+#include "wl_tile_dev.h"
 
 namespace wl {
 
@@ -51,10 +54,91 @@ struct Pair2DArgs {
     int64_t bs_src, bs_y, bs_ll;
     int src_mod; int64_t spin0;
     int th; double t_unit, sigma_host; const double *mad_dev;
+    // FUSE instances (levels l .. l+3 in ONE launch, see k_fwd2d_pair below): workgroups [0, npair) are the pair, the rest tiles
+    unsigned *prog;                   // npair progress words + a completion counter at prog[npair] (all zero between launches)
+    int npair;
+    int tprio;                        // issue priority of the tile workgroups (0 .. 3)
+    float *ll4; int64_t ldll4;        // approximation after levels l+2, l+3 (next stage's input buffer, or y itself)
     TapsF<float, F> tp;
 };
 
-template <int F, int W, int LVL1, int BT = 0>
+// ---- the tile role of the FUSE instances ------------------------------------------------------------------------------------
+// Workgroup `ti` of the tiles: levels l+2, l+3 of one 64 x 64 piece (+ one-sided halo) of the level-(l+1) approximation, exactly
+// k_fwd2d_tileB's work (tileB_body, wl_tile_dev.h) -- but inside the launch that produces that approximation.  The pair's
+// level-(l+1) waves publish it with write-through stores and count the columns they have completed in prog[pair workgroup]
+// (release: every storing wave drains vmcnt, one lane stores the word at agent scope); a tile polls the words of the <= 8 pair
+// workgroups it reads from, then loads with `sc1` (coherent) loads.  No dispatch-order assumption is needed for CORRECTNESS beyond
+// "a workgroup with a lower index has been placed before one with a higher index is" (tiles have the highest indices and pair
+// workgroups never wait), which keeps the spin deadlock-free; the tile ORDER below only decides how much of the tile work hides
+// under the pair: the CU arbitrates issue by age, so the pair workgroups of dispatch round r (the r-th workgroup each CU received)
+// finish in that order, ~30 % of the launch apart (r06 stamps) -- tiles are numbered so that those fed by round 0 come first.
+template <int F, int W>
+__device__ __forceinline__ void fused_tile_role(const Pair2DArgs<F> &a, float *smem, const uint32_t ti)
+{
+    typedef TileLds<F, 2> L;
+    constexpr int R0 = L::R0, C0 = L::C0;
+    constexpr int SR = 64 * W;                         // level-(l+1) rows per strip
+    const int tid = (int)threadIdx.x;
+    switch (a.tprio) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+    }
+    const int M2 = (int)(a.ms >> 2), N2 = (int)(a.ns >> 2), gx = M2 >> 6, gy = N2 >> 6, ntiles = gx * gy;
+    const int TJq = a.TJ >> 2;                         // level-(l+1) columns per chunk
+    int bi, bj;
+    if ((gy & 31) == 0) {
+        // column block bj lies in XCD (bj / (gy/8))'s span of the pair's chunks, in the part its dispatch round (bj % (gy/8)) / (gy/32) owns
+        const int nb = ntiles >> 2, kq = gy >> 5;
+        int band = (int)ti / nb;
+        const int idx = (int)ti - band * nb, xq = idx & 7, rest = idx >> 3;
+        if (a.rev) band = 3 - band;
+        bi = rest % gx;
+        bj = (gy >> 3) * xq + kq * band + rest / gx;
+    } else {
+        bi = (int)ti % gx;
+        bj = (int)ti / gx;
+    }
+    // ---- wait for the pair workgroups that produce rows [64 bi, 64 bi + R0) x columns [64 bj, 64 bj + C0) (periodic) ----
+    const int r0 = 64 * bi, c0 = 64 * bj;
+    const int s_lo = r0 / SR, nsd = (r0 + R0 - 1) / SR - s_lo + 1;
+    const int c_lo = c0 / TJq, ncd = (c0 + C0 - 1) / TJq - c_lo + 1;
+    if (tid < 64) {
+        const int si = tid % nsd, ci = tid / nsd;
+        const bool active = ci < ncd;
+        const int ch = c_lo + ci;
+        int need = c0 + C0 - ch * TJq;
+        if (need > TJq) need = TJq;
+        const int word = (ch % a.nchunks) * a.nstrips + (s_lo + si) % a.nstrips;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned v = active ? __hip_atomic_load(a.prog + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)need;
+            if (__all((int)(v >= (unsigned)need))) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) {                // (seconds: never on a healthy launch; leaves a mark instead of hanging the device)
+                if (tid == 0) __hip_atomic_store(a.prog + a.npair + 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    TileArgs<float, F> ta;
+    ta.src = a.ll; ta.lds = a.ldll; ta.y = a.y; ta.ldy = a.ldy; ta.ll = a.ll4 ? a.ll4 : a.y; ta.ldll = a.ll4 ? a.ldll4 : a.ldy;
+    ta.M = M2; ta.N = N2;                              // (ta.tp stays unset: the taps are read from the kernel argument)
+    float *Ts = smem, *X1s = smem + L::ldx(L::R0) * (L::C1 + 32);
+    tileB_body<F, 2>(ta, a.tp, Ts, X1s, bi, bj, tid, 256, (int)ti);
+    // ---- the last tile to finish zeroes the hand-over words for the next launch ----
+    __shared__ int last_tile;
+    if (tid == 0) last_tile = (__hip_atomic_fetch_add(a.prog + a.npair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ntiles - 1));
+    __syncthreads();
+    if (last_tile) {
+        for (int i = tid; i <= a.npair; i += 256) __hip_atomic_store(a.prog + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// FUSE = 1 (W = 2, BT = 0): FOUR levels in one launch -- workgroups >= a.npair run fused_tile_role above.
+template <int F, int W, int LVL1, int BT = 0, int FUSE = 0>
 __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
 {
     typedef float T;
@@ -69,13 +153,24 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     constexpr int NSLOT = 16;
     constexpr int RW = 2 * W;                         // approximation rows per lane of the level-(l+1) wave
     constexpr int HS = W;                             // its s2 (and d2) rows per lane
-    __shared__ __attribute__((aligned(16))) T2 x1[2 * ROWS1];
-    __shared__ __attribute__((aligned(16))) T ll1[NSLOT * RL];
-    __shared__ __attribute__((aligned(16))) T2 x2[RL];
+    // one block of LDS, carved: x1 (level-l exchange, two slots) | ll1 (approximation column ring) | x2 (level-(l+1) exchange); the tile
+    // role of the FUSE instances lays its own two arrays over the same block
+    constexpr int SM_PAIR = 4 * ROWS1 + NSLOT * RL + 2 * RL;
+    constexpr int SM_TILE = FUSE ? (TileLds<F, 2>::ldx(TileLds<F, 2>::R0) * (TileLds<F, 2>::C1 + 32) + TileLds<F, 2>::ldx(TileLds<F, 2>::R1) * TileLds<F, 2>::C1 + 16) : 0;
+    __shared__ __attribute__((aligned(16))) T smem[SM_PAIR > SM_TILE ? SM_PAIR : SM_TILE];
+    if constexpr (FUSE != 0) {
+        if (blockIdx.x >= (uint32_t)a.npair) {
+            fused_tile_role<F, W>(a, smem, blockIdx.x - (uint32_t)a.npair);
+            return;
+        }
+    }
+    T2 *const x1 = reinterpret_cast<T2 *>(smem);
+    T *const ll1 = smem + 4 * ROWS1;
+    T2 *const x2 = reinterpret_cast<T2 *>(smem + 4 * ROWS1 + NSLOT * RL);
 
     // g[m] = (-1)^m h[m] exactly: only the scaling taps occupy SGPRs, a detail term multiplies by the negated tap (a source modifier)
     auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
-    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    const uint32_t b = blockIdx.x, nwg = FUSE ? (uint32_t)a.npair : gridDim.x;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
     const uint32_t first = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1u : 0u);
@@ -201,15 +296,25 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
                     }
                 }
                 if constexpr (HS == 4) {
-                    store_pol<WL_P_PAIR_LL>(reinterpret_cast<T4 *>(cl + s2row), T4{P[0].x, P[1].x, P[2].x, P[3].x});
+                    store_pol<(FUSE ? 2 : WL_P_PAIR_LL)>(reinterpret_cast<T4 *>(cl + s2row), T4{P[0].x, P[1].x, P[2].x, P[3].x});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ck + (hm2i + d2row)), T4{Q[0].x, Q[1].x, Q[2].x, Q[3].x});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ckd + s2row), T4{P[0].y, P[1].y, P[2].y, P[3].y});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T4 *>(ckd + (hm2i + d2row)), T4{Q[0].y, Q[1].y, Q[2].y, Q[3].y});
                 } else {
-                    store_pol<WL_P_PAIR_LL>(reinterpret_cast<T2 *>(cl + s2row), T2{P[0].x, P[1].x});
+                    store_pol<(FUSE ? 2 : WL_P_PAIR_LL)>(reinterpret_cast<T2 *>(cl + s2row), T2{P[0].x, P[1].x});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ck + (hm2i + d2row)), T2{Q[0].x, Q[1].x});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ckd + s2row), T2{P[0].y, P[1].y});
                     store_pol<WL_P_PAIR_ST2>(reinterpret_cast<T2 *>(ckd + (hm2i + d2row)), T2{Q[0].y, Q[1].y});
+                }
+                if constexpr (FUSE != 0) {
+                    // publish: this wave is the only writer of the chunk's level-(l+1) approximation columns (write-through stores);
+                    // once they have left (vmcnt drained), one lane counts them for the tiles -- after the head columns a neighbouring
+                    // tile column needs, and at the end of the chunk
+                    const int kl = (t - F) >> 1;
+                    if (kl == TileLds<F, 2>::C0 - 64 - 1 || kl == (S_own >> 1) - 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (j == 0) __hip_atomic_store(a.prog + logical, (unsigned)(kl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
@@ -495,10 +600,23 @@ bool fwd2d_pair_ok(int F, int64_t ms, int64_t ns)
 }
 
 struct PairBatch { int64_t nbatch, bs_src, bs_y, bs_ll; int src_mod; int64_t spin0; const SrcView *thresh; };
+struct PairFuse { float *ll4; int64_t ldll4; unsigned *prog; };       // levels l+2, l+3 in the same launch (FUSE instances)
+
+static int pair_chunk_len(int64_t nstrips, int64_t ns, int64_t nbatch, int cu_count)
+{
+    int TJ = (int)opt("WL_TJ2", 128);
+    if (TJ < 32) TJ = 32;
+    TJ &= ~31;
+    // one resident round of workgroups (W = 2: four 4-wave workgroups per CU): shorter chunks pay 3 (F - 2) halo columns each,
+    // but a chip that is not full is latency-bound (8192^2: 1024 workgroups 116 us, 512 workgroups 129 us; 4096^2: 34.5 vs 39 us)
+    auto nwgs = [&](int tj) { return nstrips * ((ns + tj - 1) / tj) * nbatch; };
+    while (TJ > 32 && (TJ % 64) == 0 && nwgs(TJ) < (int64_t)cu_count * opt("WL_PAIR_WG_PER_CU", 4)) TJ >>= 1;
+    return TJ;
+}
 
 template <int F, int W>
 static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
-                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, const PairBatch *pb)
+                                 float *ll, int64_t ldll, int64_t ms, int64_t ns, int cu_count, const PairBatch *pb, const PairFuse *pf = nullptr)
 {
     Pair2DArgs<F> a;
     a.src = src; a.lds = lds; a.y = y; a.ldy = ldy; a.ll = ll; a.ldll = ldll; a.ms = ms; a.ns = ns;
@@ -508,22 +626,27 @@ static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool l
     a.sigma_host = (pb && pb->thresh) ? pb->thresh->sigma_host : 0.0; a.mad_dev = (pb && pb->thresh) ? pb->thresh->mad_dev : nullptr;
     const int64_t nbatch = pb ? pb->nbatch : 1;
     a.nstrips = (int)(ms / (256 * W));
-    int TJ = (int)opt("WL_TJ2", 128);
-    if (TJ < 32) TJ = 32;
-    TJ &= ~31;
-    // one resident round of workgroups (W = 2: four 4-wave workgroups per CU): shorter chunks pay 3 (F - 2) halo columns each,
-    // but a chip that is not full is latency-bound (8192^2: 1024 workgroups 116 us, 512 workgroups 129 us; 4096^2: 34.5 vs 39 us)
-    auto nwgs = [&](int tj) { return (int64_t)a.nstrips * ((ns + tj - 1) / tj) * nbatch; };
-    while (TJ > 32 && (TJ % 64) == 0 && nwgs(TJ) < (int64_t)cu_count * opt("WL_PAIR_WG_PER_CU", 4)) TJ >>= 1;
-    a.TJ = TJ;
-    a.nchunks = (int)((ns + TJ - 1) / TJ);
+    a.TJ = pair_chunk_len(a.nstrips, ns, nbatch, cu_count);
+    a.nchunks = (int)((ns + a.TJ - 1) / a.TJ);
     a.rev = (!lvl1 && opt("WL_REVERSE", 1)) ? 1 : 0;
-    a.prio = (int)opt("WL_PAIR_PRIO", 1);
-    if (a.prio < 0 || a.prio > 3) a.prio = 1;
+    // 3: issue priority rotates over the co-resident workgroups every 16 steps (r06: 8192^2 L = 13 -1.5 .. -2.5 us against 1 = raised
+    // single-wave roles, in four interleaved A/B runs on three boxes; 2 = every 8 steps: neutral; 0 = none: +5 us)
+    a.prio = (int)opt("WL_PAIR_PRIO", 3);
+    if (a.prio < 0 || a.prio > 3) a.prio = 3;
     a.rr_div = cu_count > 0 ? cu_count : 256;
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
-    if (pb) {
+    a.tprio = (int)opt("WL_FUSE_TPRIO", 0) & 3;
+    a.prog = pf ? pf->prog : nullptr; a.npair = (int)nwg; a.ll4 = pf ? pf->ll4 : nullptr; a.ldll4 = pf ? pf->ldll4 : 0;
+    if (pf) {
+        if constexpr (W == 2) {
+            const unsigned ntiles = (unsigned)((ms >> 8) * (ns >> 8));          // 64 x 64 pieces of the level-(l+1) approximation
+            if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 1, 0, 1>), dim3(nwg + ntiles), dim3(64 * (W + 2)), 0, st, a);
+            else hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 0, 0, 1>), dim3(nwg + ntiles), dim3(64 * (W + 2)), 0, st, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (pb) {
         if constexpr (W == 2) {          // (the batched instances exist for the default strip shape only)
             if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 1, 1>), dim3(nwg, (unsigned)nbatch), dim3(64 * (W + 2)), 0, st, a);
             else hipLaunchKernelGGL((k_fwd2d_pair<F, 2, 0, 1>), dim3(nwg, (unsigned)nbatch), dim3(64 * (W + 2)), 0, st, a);
@@ -561,6 +684,34 @@ hipError_t fwd2d_pair_launch(hipStream_t st, const Taps<float> &taps, bool lvl1,
     case 6: return launch_pair_f<6>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
     case 8: return launch_pair_f<8>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
     case 10: return launch_pair_f<10>(st, taps, lvl1, src, lds, y, ldy, ll, ldll, ms, ns, cu_count, pb);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- levels l .. l+3 in one launch: the pair (levels l, l+1) and, behind in-launch hand-over flags, the 64 x 64 tiles of levels
+//      l+2, l+3 (fused_tile_role).  `prog`: the context's zeroed hand-over block (wl::tl_sync). ----
+bool fwd2d_pair_tile_ok(int F, int64_t ms, int64_t ns, int cu_count)
+{
+    if (!fwd2d_pair_ok(F, ms, ns) || !fwd2d_tile_ok(F, 2, ms >> 2, ns >> 2)) return false;
+    if ((ms % 256) != 0 || (ns % 256) != 0) return false;
+    const int64_t nstrips = ms / 512;
+    const int TJ = pair_chunk_len(nstrips, ns, 1, cu_count);
+    if ((ns % TJ) != 0) return false;                                        // whole chunks only: a chunk publishes TJ / 4 columns
+    const int64_t npair = nstrips * (ns / TJ), ntiles = (ms >> 8) * (ns >> 8);
+    return npair + 2 <= (int64_t)kSyncWords && npair + ntiles < ((int64_t)1 << 31);
+}
+
+hipError_t fwd2d_pair_tile_launch(hipStream_t st, const Taps<float> &taps, bool lvl1, const float *src, int64_t lds, float *y, int64_t ldy,
+                                  float *ll2, int64_t ldll2, float *ll4, int64_t ldll4, int64_t ms, int64_t ns, int cu_count, unsigned *prog)
+{
+    if (!prog || !ll2) return hipErrorInvalidValue;
+    PairFuse pf = {ll4, ldll4, prog};
+    switch (taps.F) {
+    case 2: return launch_pair_fw<2, 2>(st, taps, lvl1, src, lds, y, ldy, ll2, ldll2, ms, ns, cu_count, nullptr, &pf);
+    case 4: return launch_pair_fw<4, 2>(st, taps, lvl1, src, lds, y, ldy, ll2, ldll2, ms, ns, cu_count, nullptr, &pf);
+    case 6: return launch_pair_fw<6, 2>(st, taps, lvl1, src, lds, y, ldy, ll2, ldll2, ms, ns, cu_count, nullptr, &pf);
+    case 8: return launch_pair_fw<8, 2>(st, taps, lvl1, src, lds, y, ldy, ll2, ldll2, ms, ns, cu_count, nullptr, &pf);
+    case 10: return launch_pair_fw<10, 2>(st, taps, lvl1, src, lds, y, ldy, ll2, ldll2, ms, ns, cu_count, nullptr, &pf);
     default: return hipErrorInvalidValue;
     }
 }

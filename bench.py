@@ -93,6 +93,49 @@ def respawn_command(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# host placement: one rank process per GPU; the host leg of a step (a few ctypes calls, ~30x longer than nothing but far shorter than the
+# 7 ms C5 shard) should not migrate between sockets -- pin the rank to the cores next to its GPU when sysfs says which they are
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/bus/pci/devices/*/local_cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def local_cpulist_file(domain, bus, dev, sysfs="/sys"):
+    return os.path.join(sysfs, "bus", "pci", "devices", f"{domain:04x}:{bus:02x}:{dev:02x}.0", "local_cpulist")
+
+
+def pin_rank_to_gpu_cores(pci, sysfs="/sys", apply=True):
+    """pci = (domain, bus, device) of this rank's GPU.  Returns what was done, for the JSON line."""
+    info = {"pinned": False}
+    try:
+        path = local_cpulist_file(pci[0], pci[1], pci[2], sysfs)
+        with open(path) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cpus
+        cpus = [c for c in cpus if c in allowed]
+        info["source"] = path
+        if cpus and len(cpus) < len(allowed):
+            if apply:
+                os.sched_setaffinity(0, cpus)
+            info.update({"pinned": True, "cpus": len(cpus), "first": cpus[0], "last": cpus[-1]})
+        else:
+            info["reason"] = "local_cpulist does not narrow the allowed set"
+    except (OSError, ValueError, AttributeError, IndexError) as e:
+        info["reason"] = type(e).__name__
+    return info
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # timing helpers (device side: HIP events on the launch stream = torch's current stream, which is the stream the library
 # launches on)
 def _event_train_ms(fns, reps, chunk=10):
@@ -434,6 +477,10 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} HIP devices are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    affinity = None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(local_rank)
+        affinity = pin_rank_to_gpu_cores((getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0)))
     dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -458,6 +505,8 @@ def main():
                              steps=(args.steps if world > 1 else min(args.steps, 60)), nested=(args.workload is None))
         if rank == 0 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_leg(W, "c5", W.wavelet(W.WT.db4), 16)
+        if affinity is not None:
+            out["rank0_cpu_affinity"] = affinity
         finish(out, rank, dist)
         return
 
@@ -521,7 +570,7 @@ def main():
                    "gpus_requested": args.gpus, "untimed_precondition_steps": precondition},
         "gpus_requested": args.gpus,
         "achieved_hbm_GBps_algorithmic": round(gbps, 1), "hbm_frac_whole_transform": round(gbps / HBM_PEAK_GBPS, 4),
-        "precondition_steps": precondition, "checksum_all_ranks": checksum,
+        "precondition_steps": precondition, "untimed_steps_before_timing": args.warmup + precondition, "checksum_all_ranks": checksum,
         "device_ms_per_step": round(dev_ms_per_step, 5),
         "rccl": rccl_info(dist, device, "hip"),
     }
@@ -553,6 +602,70 @@ def main():
     finish(out, rank, dist)
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def slim_line(out, limit=6000):
+    """The LAST stdout line, short enough for a reader that keeps only a few KB of the tail (round-5 review: the 25 KB line lost
+    `by_depth`, `fused_mode`, `c5_batched` and the C1/C2/C4 rows): the contract keys and every measured number, without the prose.
+    The complete objects (protocol notes, every secondary row's fields) are printed on the line BEFORE it and written to
+    bench_full.json."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "gpus_requested", "achieved_hbm_GBps_algorithmic", "hbm_frac_whole_transform",
+            "hbm_frac_whole_transform_per_gpu", "untimed_steps_before_timing", "checksum_all_ranks", "device_ms_per_step", "rccl",
+            "pipelined", "c5_signals_covered"]
+    s = _pick(out, keep)
+    if "config" in s:
+        s["config"] = {k: v for k, v in s["config"].items() if k not in ("parallelism", "collectives")}
+    if "roofline" in out:
+        r = out["roofline"]
+        s["roofline"] = _pick(r, ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                  "avg_launch_ms", "launches_timed", "frac_of_measured_copy_6290GBps"])
+        if isinstance(r.get("isolated_launch_ms"), dict):
+            s["roofline"]["isolated_launch_ms"] = _pick(r["isolated_launch_ms"], ["median", "min"])
+        if isinstance(r.get("rocprof"), dict):
+            s["roofline"]["rocprof"] = _pick(r["rocprof"], ["file", "calls", "avg_launch_ms", "frac"])
+    if "cpu_baseline" in out:
+        c = out["cpu_baseline"]
+        s["cpu_baseline"] = _pick(c, ["value", "unit", "cores", "kind", "seconds", "host_cores_available"])
+        s["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:150]
+        if isinstance(c.get("all_cores"), dict):
+            s["cpu_baseline"]["all_cores"] = _pick(c["all_cores"], ["value", "cores", "seconds"])
+    if "by_depth" in out:
+        s["by_depth"] = {k: _pick(v, ["ms_per_step", "frac", "launches"]) for k, v in out["by_depth"].items()}
+    if "isolated_call_ms" in out:
+        s["isolated_call_ms"] = _pick(out["isolated_call_ms"], ["first_call_of_the_process", "median_of_idle_started_calls", "min", "max", "calls"])
+    if "fused_mode" in out:
+        s["fused_mode"] = _pick(out["fused_mode"], ["library", "ms_per_step", "value", "hbm_frac_whole_transform", "inverse_ms_per_step",
+                                                     "exact_same_protocol", "gain"])
+    if "c5_batched" in out:
+        c5 = out["c5_batched"]
+        s["c5_batched"] = _pick(c5, ["value", "unit", "ms_per_step", "steps", "warmup", "scaling", "hbm_frac_whole_transform_per_gpu"])
+        if isinstance(c5.get("roofline"), dict):
+            s["c5_batched"]["roofline"] = _pick(c5["roofline"], ["kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"])
+    for nested in ("c3_weak_scaling", "single_gpu_same_batch"):
+        if isinstance(out.get(nested), dict):
+            s[nested] = _pick(out[nested], ["value", "unit", "ms_per_step", "n_gpus", "scaling", "hbm_frac_whole_transform",
+                                            "hbm_frac_whole_transform_per_gpu", "note"])
+    if "secondary_configs" in out:
+        # one short row per secondary configuration: [workload, L, ms_per_step, fraction of 8 TB/s (algorithmic bytes), kernel, bound]
+        rows = []
+        for r in out["secondary_configs"]:
+            rf = r.get("roofline") if isinstance(r.get("roofline"), dict) else {}
+            rows.append([r.get("workload"), r.get("L"), r.get("ms_per_step"), r.get("frac"), r.get("kernel"), rf.get("bound", "hbm"), rf.get("frac")])
+        s["secondary_configs"] = {"columns": ["workload", "L", "ms_per_step", "hbm_frac_algorithmic", "kernel", "bound", "frac_of_bound"], "rows": rows}
+    s["full_line"] = "the line before this one, and bench_full.json"
+    text = json.dumps(s, separators=(",", ":"))
+    # still too long (it should not be): drop the least important tables first
+    for k in ("pipelined", "rccl", "secondary_configs", "c5_batched", "fused_mode"):
+        if len(text) <= limit:
+            break
+        s.pop(k, None)
+        text = json.dumps(s, separators=(",", ":"))
+    return text
+
+
 def finish(out, rank, dist):
     if dist is not None:
         dist.barrier()
@@ -566,7 +679,14 @@ def finish(out, rank, dist):
         except OSError:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        full = json.dumps(out)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_full.json"), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+        print(full, flush=True)
+        print(slim_line(out), flush=True)
 
 
 def isolated_call_leg(fn, xs, n=7, idle_s=0.05):
@@ -829,7 +949,7 @@ def _measure_traffic_live(tag):
     rp = os.path.join(ROOT, "tools", "rp.sh")
     if not (os.path.exists(harness) and os.path.exists(rp)):
         return None
-    cases = {"c3": (["L=2"], "k_fwd2d_pair<8, 2, 1, 0>"),
+    cases = {"c3": (["L=2"], "k_fwd2d_pair<8, 2, 1, 0"),
              "c2": (["n0=16777216", "n1=1", "L=4"], "k_fwd1d_multi<float, 8, 1>"),
              "c5": (["dwtc=1", "n0=65536", "n1=8192", "L=4"], "k_fwd1d_multi<float, 8, 1>")}
     if tag not in cases:

@@ -176,3 +176,33 @@ def test_util_helpers(W):
     assert W.testfunction(4, "Doppler")[0] == 0.0 and abs(W.testfunction(1024, "Blocks").max() - 5.2) < 1e-12
     with pytest.raises(ValueError):
         W.testfunction(8, "nope")
+
+
+def test_set_arithmetic_leaves_the_mode_alone_when_the_target_library_is_missing(monkeypatch, tmp_path):
+    """set_arithmetic() binds the target library before it retires anything (round-5 review): a missing or stale fused library
+    raises and the process stays in the mode it was in."""
+    import wavelets_jl_amd as W
+    from wavelets_jl_amd import _lib
+    assert W.get_arithmetic() == "exact"
+    monkeypatch.setitem(_lib.LIB_PATHS, "fused", str(tmp_path / "libwavelets_mi355x_fma.so"))
+    monkeypatch.delitem(_lib._libs, "fused", raising=False)
+    with pytest.raises(_lib.WaveletsLibraryError):
+        W.set_arithmetic("fused")
+    assert W.get_arithmetic() == "exact"
+    with pytest.raises(_lib.WaveletsLibraryError):
+        with W.arithmetic("fused"):
+            pass
+    assert W.get_arithmetic() == "exact"
+
+
+def test_makefile_keeps_the_arithmetic_contract_under_a_cxxflags_override():
+    """`make FMA=1 CXXFLAGS=...` must still compile with -DWL_FMA -ffp-contract=fast, and the default build with -ffp-contract=off:
+    the contract flags are appended outside the overridable variable."""
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavelets.jl_amd", "csrc")
+    fma = subprocess.run(["make", "-n", "-B", "-C", csrc, "FMA=1", "CXXFLAGS=-O1"], capture_output=True, text=True, check=True).stdout
+    lines = [l for l in fma.splitlines() if " -c " in l]
+    assert lines and all("-DWL_FMA" in l and "-ffp-contract=fast" in l and " -O1 " in l for l in lines)
+    exact = subprocess.run(["make", "-n", "-B", "-C", csrc, "CXXFLAGS=-O1"], capture_output=True, text=True, check=True).stdout
+    lines = [l for l in exact.splitlines() if " -c " in l]
+    assert lines and all("-ffp-contract=off" in l and "WL_FMA" not in l for l in lines)

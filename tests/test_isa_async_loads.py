@@ -125,7 +125,7 @@ def test_instruction_mix_tool_reports_the_headline_kernels():
     for line in out.splitlines()[2:]:
         cells = [c.strip() for c in line.strip().strip("|").split("|")]
         rows[cells[0].strip("`")] = [int(v) for v in cells[1:]]
-    assert any(k.startswith("k_fwd2d_pair<8, 2, 1, 0>") for k in rows) and any(k.startswith("k_fwd2d_lds<8, 1, 0>") for k in rows)
+    assert any(k.startswith("k_fwd2d_pair<8, 2, 1, 0, 0>") for k in rows) and any(k.startswith("k_fwd2d_lds<8, 1, 0>") for k in rows)
     for k, v in rows.items():
         # columns: instructions, VALU, packed, DPP, lane moves, SALU, LDS, vmem, barriers, waitcnt, VGPRs, SGPR spills, scratch
         if k.startswith("k_inv2d_lds_long<float, 16"):

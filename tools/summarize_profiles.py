@@ -7,7 +7,7 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
-HEAD = "k_fwd2d_pair<8, 2, 1, 0>"        # first launch of the 8192 x 8192 f32 db4 transform: levels 1-2 fused (its own template instance)
+HEAD = "k_fwd2d_pair<8, 2, 1, 0"        # first launch of the 8192 x 8192 f32 db4 transform: levels 1-2 fused (its own template instance)
 
 
 def find(sub, pat):

@@ -91,22 +91,26 @@ SIGNATURES = {
 }
 
 
-def load():
-    """Load the shared library (no GPU needed for this step) and bind every ABI symbol."""
-    lib = _libs.get(_mode)
+def load(mode=None):
+    """Load the shared library of `mode` (default: the selected one; no GPU needed for this step) and bind every ABI symbol."""
+    mode = _mode if mode is None else mode
+    lib = _libs.get(mode)
     if lib is not None:
         return lib
-    path = LIB_PATHS[_mode]
+    path = LIB_PATHS[mode]
     if not os.path.exists(path):
         raise WaveletsLibraryError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            f"(or `make -C wavelets.jl_amd/csrc{' FMA=1' if _mode == 'fused' else ''}`).  There is no CPU fallback.")
+            f"(or `make -C wavelets.jl_amd/csrc{' FMA=1' if mode == 'fused' else ''}`).  There is no CPU fallback.")
     lib = C.CDLL(path)
-    for nm, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, nm)          # AttributeError if the symbol is missing -> loud
-        fn.restype = res
-        fn.argtypes = args
-    _libs[_mode] = lib
+    try:
+        for nm, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, nm)          # AttributeError if the symbol is missing -> loud
+            fn.restype = res
+            fn.argtypes = args
+    except AttributeError as e:
+        raise WaveletsLibraryError(f"{path} is out of date (no symbol {e}): rebuild it") from e
+    _libs[mode] = lib
     return lib
 
 

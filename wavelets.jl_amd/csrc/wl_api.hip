@@ -31,8 +31,19 @@ int wl_ensure_ws(wl_ctx *ctx, size_t bytes, hipStream_t st, bool ordered)
     if (ordered) {
         // A growth while the call's stream is being captured into a hipGraph would record alloc / free nodes and leave the context
         // pointing at graph-owned memory that later eager calls use: refuse (reserve wl_workspace_bytes_full before capturing).
+        // A query that itself fails (e.g. hipErrorStreamCaptureImplicit: the legacy stream while another stream captures) is treated as
+        // "capturing", and its error is cleared so that a later launch's hipGetLastError() cannot report it.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { ctx->last_hip = (int)hipErrorStreamCaptureUnsupported; return WL_EHIP; }
+        const hipError_t qe = hipStreamIsCapturing(st, &cs);
+        if (qe != hipSuccess) (void)hipGetLastError();
+        if (qe != hipSuccess || cs != hipStreamCaptureStatusNone) { ctx->last_hip = (int)hipErrorStreamCaptureUnsupported; return WL_EHIP; }
+    } else {
+        // wl_ctx_reserve (no stream argument): it synchronises the device, which is illegal while ANY stream of this thread's capture
+        // mode is capturing -- refuse before touching anything (the legacy-stream query reports an ongoing capture as an error)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const hipError_t qe = hipStreamIsCapturing(nullptr, &cs);
+        if (qe != hipSuccess) (void)hipGetLastError();
+        if (qe != hipSuccess || cs != hipStreamCaptureStatusNone) { ctx->last_hip = (int)hipErrorStreamCaptureUnsupported; return WL_EHIP; }
     }
     if (ordered && pool && (ctx->ws == nullptr || ctx->ws_pooled)) {
         if (ctx->ws) { WL_HIP(ctx, hipFreeAsync(ctx->ws, st)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
@@ -703,7 +714,8 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
     // the packet kernels (k_wpt_fwd_multi / _inv_multi / _tail) move 16-byte vectors straight on x, y and the work buffer: a view that
     // starts 4 or 8 bytes off the grid (buf[1:1+n]) takes the per-depth kernels, which gate on alignment themselves
     auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool fast = (ctx->path == 0) && opt("WL_WPT_FAST", 1) != 0 && al16(x) && al16(y) && al16(w.T0);
+    const bool fast_any = (ctx->path == 0) && opt("WL_WPT_FAST", 1) != 0;          // the lifting line kernels check alignment themselves
+    const bool fast = fast_any && al16(x) && al16(y) && al16(w.T0);              // the filter-bank packet kernels
 
     if (lifting) {
         // wpt!(y, scheme, ...) is in place for the caller.  A fused lifting level cannot run in place (its [s ; d] outputs land
@@ -715,7 +727,7 @@ static int wpt_impl(wl_ctx *ctx, hipStream_t st, T *y, const T *x, int64_t n,
             const int d = depths[i];
             const int64_t nj = n >> d, nseg = (int64_t)1 << d;
             // fully split depth: one lifting level (all steps fused) of nseg lines of length nj
-            if (kind[i] == 2 && fast) {
+            if (kind[i] == 2 && fast_any) {
                 int handled = 0, herr = 0;
                 const char *kn = nullptr;
                 T *out = (cur == y) ? w.T0 : y;

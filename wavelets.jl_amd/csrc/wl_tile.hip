@@ -76,15 +76,24 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
 // 62 KB and 1024.  Four workgroups per CU stay resident -- all 1024 tiles of a 2048^2 block at once -- where the staging
 // kernel kept two, each waiting on its own loads, barriers and partially idle passes (PMC, 2048^2: 64 % of the wave cycles
 // waiting, 41 % of the LDS cycles bank conflicts).
+// (The body below is repeated as tileB_body in wl_tile_dev.h for the fused pair + tile launch of wl_pair2d.hip.  Routing THIS kernel
+//  through that function -- the taps reached through a reference to a reference -- made hipcc park them in scratch (32 B per lane,
+//  94 VGPRs instead of 70); the two copies are pinned to each other by tests/test_gpu_parity.py::test_fused_pair_tile_launch.)
 #ifndef WL_TILEB_REMAP
 #define WL_TILEB_REMAP 1      // (r06: 2048^2 two levels 14.6 -> 13.7 us)
 #endif
 template <int F>
 __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
 {
+    typedef float T;
     typedef TileLds<F, 2> L;
-    __shared__ __attribute__((aligned(16))) float Ts[L::ldx(L::R0) * (L::C1 + 32)];
-    __shared__ __attribute__((aligned(16))) float X1s[L::ldx(L::R1) * L::C1 + 16];
+    typedef T F4t __attribute__((ext_vector_type(4)));
+    constexpr int ldT = L::ldx(L::R0), ld1 = L::ldx(L::R1);
+    constexpr int R0 = L::R0, R1 = L::R1, C1 = L::C1;
+    constexpr int RQ = (R0 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) T Ts[ldT * (C1 + 32)];
+    __shared__ __attribute__((aligned(16))) T X1s[ld1 * C1 + 16];
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int wgid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
     // XCD-aware tile map (workgroup w runs on XCD w % 8): each XCD owns a compact gx/2 x gy/4 block of tiles, so that the halo rows /
     // columns a tile shares with its neighbours are hits in the XCD's own L2 instead of a second fetch over the fabric
@@ -96,7 +105,90 @@ __global__ void __launch_bounds__(256, 4) k_fwd2d_tileB(TileArgs<float, F> a)
         tby = (xcd >> 1) * ((int)gridDim.y >> 2) + i / rx;
     }
 #endif
-    tileB_body<F, 0>(a, a.tp, Ts, X1s, tbx, tby, (int)threadIdx.x, (int)blockDim.x, wgid);
+    const int r0 = tbx * 64, c0 = tby * 64;
+    const int hm = a.M >> 1, hn = a.N >> 1;
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 0);
+    // ---- level 1, dim-2 pass from global: T columns [0, C1) = s (window columns 2k .. 2k+F-1), [C1, C1+32) = d[k + SH] ----
+    // A thread owns four rows and KG = 4 consecutive output columns: F + 6 column loads (all in flight together) instead of 4 F,
+    // and the whole pass is one round of the workgroup (22 row quads x 10 column groups = 220 of 256 threads).
+    {
+        constexpr int KG = 4, NG = (C1 + KG - 1) / KG, NC = F + 2 * (KG - 1);
+        for (int it = tid; it < RQ * NG; it += nthr) {
+            const int iq = it % RQ, k0 = (it / RQ) * KG;
+            int gr = r0 + 4 * iq;
+            if (gr >= a.M) gr -= a.M;
+            int gc = c0 + 2 * k0;
+            if (gc >= a.N) gc -= a.N;
+            F4t xw[NC];
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                int c = gc + m;
+                if (c >= a.N) c -= a.N;
+                xw[m] = load_pol<WL_P_TILE_LD != 0>(reinterpret_cast<const F4t *>(a.src + gr + (int64_t)c * a.lds));
+            }
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                const int k = k0 + kk;
+                F4t sv = a.tp.h[0] * xw[2 * kk], dv = a.tp.g[F - 1] * xw[2 * kk];
+#pragma unroll
+                for (int m = 1; m < F; ++m) {
+                    sv = sv + a.tp.h[m] * xw[2 * kk + m];
+                    dv = dv + a.tp.g[F - 1 - m] * xw[2 * kk + m];
+                }
+                if (k < C1) *reinterpret_cast<F4t *>(Ts + 4 * iq + k * ldT) = sv;
+                if (k < 32) *reinterpret_cast<F4t *>(Ts + 4 * iq + (C1 + k) * ldT) = dv;
+            }
+        }
+    }
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 1);
+    lds_barrier();
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 2);
+    // ---- level 1, dim-1 pass (the second half of tile_level) ----
+    {
+        constexpr int SH = (F - 2) / 2;
+        constexpr int QG = (R1 + 3) / 4, OWN = 32;
+        const int r0h = r0 >> 1, c0h = c0 >> 1;
+        for (int it = tid; it < QG * (C1 + OWN); it += nthr) {
+            const int q = it % QG, c = it / QG;
+            const T *p = Ts + 8 * q + c * ldT;
+            T E[16];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const F4t t = *reinterpret_cast<const F4t *>(p + 4 * v);
+                E[4 * v] = t.x; E[4 * v + 1] = t.y; E[4 * v + 2] = t.z; E[4 * v + 3] = t.w;
+            }
+            F4t so, dO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T sv = a.tp.h[0] * E[2 * j];
+#pragma unroll
+                for (int m = 1; m < F; ++m) sv = sv + a.tp.h[m] * E[2 * j + m];
+                T dv = a.tp.g[F - 1] * E[2 * j + 10 - F];
+#pragma unroll
+                for (int m = F - 2; m >= 0; --m) dv = dv + a.tp.g[m] * E[2 * j + 9 - m];
+                so[j] = sv; dO[j] = dv;
+            }
+            const bool is_s = c < C1;
+            if (is_s) *reinterpret_cast<F4t *>(X1s + 4 * q + c * ld1) = so;
+            const int cc = is_s ? c : c - C1;
+            if (cc < OWN && 4 * q < OWN) {
+                int64_t col;
+                if (is_s) col = c0h + cc;
+                else { int kd = c0h + cc + SH; if (kd >= hn) kd -= hn; col = hn + kd; }
+                int rd = r0h + 4 * q + 4;
+                if (rd >= hm) rd -= hm;
+                T *yc = a.y + col * a.ldy;
+                store_pol<WL_P_TILE_ST>(reinterpret_cast<F4t *>(yc + hm + rd), dO);                  // ds or dd
+                if (!is_s) store_pol<WL_P_TILE_ST>(reinterpret_cast<F4t *>(yc + (r0h + 4 * q)), so);  // sd
+            }
+        }
+    }
+    lds_barrier();
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 3);
+    // ---- level 2: LDS -> LDS as in the staging kernel ----
+    tile_level<T, F, L::R1, L::C1, 16, 16, 16, true>(X1s, ld1, Ts, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2, c0 >> 2, hm >> 1,
+                                                  hn >> 1, tid, nthr);
+    if (tid == 0) WL_STAMP_AT(tileB, wgid, 4);
 }
 
 template <int F>

@@ -110,6 +110,9 @@ def set_arithmetic(mode: str):
         return
     if mode not in _lib.LIB_PATHS:
         raise ValueError(f"arithmetic mode must be one of {sorted(_lib.LIB_PATHS)}, got {mode!r}")
+    # resolve and bind the target library FIRST: a missing or stale libwavelets_mi355x_fma.so must leave the process in the mode
+    # it was in, with its contexts alive (round-5 review)
+    _lib.load(mode)
     if _CTX:
         destroy_contexts()
     _lib._select(mode)

@@ -853,7 +853,62 @@ def secondary_leg(W, device, reps=20):
     del xd
     W.destroy_contexts()
     torch.cuda.empty_cache()
+    annotate_secondary(res)
     return res
+
+
+# un-fused Float32 VALU peak: 256 CUs x 4 SIMDs x 32 lanes per cycle x 2.4 GHz, ONE multiply or add per lane-cycle (the exact mode
+# never contracts them); Float64 runs at half that rate.  (The 157.3 TFLOP/s of MI355X_MICROARCH.md counts an FMA as two.)
+VALU_PEAK_F32_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+SECONDARY_PMC = os.path.join(ROOT, "profiles", "r06_secondary_pmc.json")
+
+
+def annotate_secondary(rows):
+    """Every secondary row gets a `roofline` object {bound, frac, peak, unit, traffic, counters} (round-5 review item 3).  `bound` is
+    "valu" where the arithmetic intensity says so (>= 16 taps, the 59-tap batt6, modwt's Float64-rate taps): frac = algorithmic flops
+    (2F - 1 per output and pass, un-fused) / time / the un-fused VALU peak; "hbm" otherwise: frac = algorithmic bytes / time / 8 TB/s.
+    `traffic` and `counters` (VALU busy, HBM rate, LDS conflicts of the dominant kernel) come from the committed rocprofv3 PMC
+    collection profiles/r06_secondary_pmc.json (tools/r06_secondary_pmc.sh); `counters_read_as` says what they point at when that is
+    not the stated bound."""
+    pmc = {}
+    try:
+        for r in json.load(open(SECONDARY_PMC)):
+            pmc[r["case"]] = r
+    except (OSError, ValueError):
+        pass
+    taps = {"sym8": 16, "batt6": 59, "sym5": 10, "db4": 8}
+    case_of = [("C2", "c2"), ("1-D dwt db4 filter 2^24", "c2"), ("1-D dwt cdf9/7", "c4"), ("3-D dwt db4", "dwt3d"), ("2-D dwt cdf9/7", "lift2d"),
+               ("2-D idwt cdf9/7", "lift2d_inv"), ("2-D dwt sym8", "sym8_fwd"), ("2-D idwt sym8", "sym8_inv"), ("1-D modwt", "modwt"),
+               ("2-D dwt batt6", "batt6")]
+    for row in rows:
+        if isinstance(row.get("roofline"), dict) and "bound" in row["roofline"]:
+            continue
+        lab = row["workload"]
+        case = next((c for pre, c in case_of if lab.startswith(pre)), None)
+        p = pmc.get(case, {})
+        n = {"8192x8192": 8192 * 8192, "512^3": 512 ** 3, "2^24": 1 << 24, "2048x2048": 2048 * 2048}
+        nsamp = next((v for k, v in n.items() if k in lab), None)
+        F = next((v for k, v in taps.items() if k in lab), None)
+        rf = {"bound": "hbm", "frac": row["frac"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": row["algorithmic_GBps"]}
+        valu_case = (F is not None and F >= 16 and "filter" in lab) or lab.startswith("1-D modwt")
+        if valu_case and nsamp:
+            if lab.startswith("1-D modwt"):
+                flops = nsamp * row["L"] * 2 * (2 * 8 - 1)               # every level: s and d for every sample, 8 taps, Float64 arithmetic
+                peak = VALU_PEAK_F32_TFLOPS / 2
+            else:
+                flops = nsamp * 2 * (2 * F - 1) * (4.0 / 3.0)              # 2 passes per level, levels shrink by 4
+                peak = VALU_PEAK_F32_TFLOPS
+            ach = flops / (row["ms_per_step"] * 1e-3) / 1e12
+            rf = {"bound": "valu", "frac": round(ach / peak, 4), "peak": round(peak, 1), "unit": "TFLOP/s (un-fused mul + add)", "achieved": round(ach, 2)}
+        if p:
+            rf["traffic"] = p.get("traffic_bytes")
+            rf["traffic_kernel"] = p.get("kernel")
+            rf["counters"] = {k: p[k] for k in ("valu_busy", "hbm_TBps_under_pmc", "issue_stall", "lds_conflict", "traffic_over_algorithmic") if k in p}
+            if p.get("bound") and p["bound"] != rf["bound"]:
+                rf["counters_read_as"] = p["bound"]
+        else:
+            rf["traffic"] = None
+        row["roofline"] = rf
 
 
 def reference_shapes_leg(W, device, reps=20):

@@ -70,6 +70,11 @@ elif case == "dwt3d":
     x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
     y = W.similar(x)
     fn = lambda: W.dwt_oop_(y, x, db4, 9)
+elif case == "batt6":                        # 59 taps: the two-pass line kernels of wl_vlong.hip (k_vl_lines)
+    x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
+    y = W.similar(x)
+    wt = W.wavelet(W.WT.batt6)
+    fn = lambda: W.dwt_oop_(y, x, wt, 13)
 elif case == "modwt":
     x = torch.randn(1 << 24, generator=g, dtype=torch.float32).cuda()
     fn = lambda: W.modwt(x, db4, 8)

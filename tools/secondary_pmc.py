@@ -6,7 +6,9 @@ Per case the four passes (FETCH_SIZE | WRITE_SIZE | SQ group 1 | SQ group 2) are
 takes the most time in the case's kernel trace.  Derived columns:
   traffic      = 2 x FETCH_SIZE KB + WRITE_SIZE KB (gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports half of 16-B/lane reads)
   HBM rate     = traffic / kernel duration (kernel trace of the FETCH pass)
-  VALU busy    = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)  (SQ counters tick in quad-cycles)
+  VALU issue   = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): every VALU instruction at the 2-cycle wave64 issue cost of a
+                 SIMD-32 -- a LOWER bound (a packed v_pk_* costs 4: tools/probes/valu_probe.hip); "quad" = the same with 4 cycles each, what
+                 SQ_ACTIVE_INST_VALU's quad-cycle unit suggests: the upper bound (exact for kernels made of packed instructions)
   issue stall  = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES;  parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt / barrier)
   LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
@@ -79,8 +81,9 @@ for case, (label, alg, filt) in CASES.items():
         if alg:
             row["algorithmic_bytes"] = alg
             row["traffic_over_algorithmic"] = round(traffic / alg, 3)
-    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
-        row["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] / (32.0 * c["GRBM_GUI_ACTIVE"]), 3)
+    if "SQ_INSTS_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+        row["valu_issue_2cyc"] = round(c["SQ_INSTS_VALU"] / (64.0 * c["GRBM_GUI_ACTIVE"]), 3)
+        row["valu_busy"] = round(c["SQ_INSTS_VALU"] / (32.0 * c["GRBM_GUI_ACTIVE"]), 3)
     if c.get("SQ_WAVE_CYCLES"):
         if "SQ_WAIT_INST_ANY" in c:
             row["issue_stall"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)
@@ -91,16 +94,17 @@ for case, (label, alg, filt) in CASES.items():
         row["parked_over_active"] = round(c["SQ_WAIT_ANY"] / c["SQ_ACTIVE_INST_ANY"], 2)
     # the bound the counters point at
     vb, hb = row.get("valu_busy", 0.0), row.get("hbm_TBps_under_pmc", 0.0)
-    row["bound"] = "valu" if vb >= 0.6 and hb < 4.0 else ("hbm" if hb >= 4.0 else ("latency" if vb < 0.45 else "valu"))
+    lo = row.get("valu_issue_2cyc", 0.0)
+    row["bound"] = "hbm" if hb >= 4.5 else ("valu" if lo >= 0.45 else ("valu / latency" if vb >= 0.6 else "latency"))
     out.append(row)
 
-lines = ["| case | dominant kernel | share | launch µs (PMC) | traffic MB | × algorithmic | HBM TB/s | VALU busy | issue stall | parked / active | LDS conflict | reads as |",
+lines = ["| case | dominant kernel | share | launch µs (PMC) | traffic MB | × algorithmic | HBM TB/s | VALU issue (2-cycle … quad) | issue stall | parked / active | LDS conflict | reads as |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in out:
     lines.append("| {} | `{}` | {:.0%} | {} | {} | {} | {} | {} | {} | {} | {} | {} |".format(
         r["workload"], r["kernel"][:44], r["share_of_case_kernel_time"], r["launch_us_under_pmc"],
         round(r["traffic_bytes"] / 1e6, 1) if "traffic_bytes" in r else "–", r.get("traffic_over_algorithmic", "–"), r.get("hbm_TBps_under_pmc", "–"),
-        r.get("valu_busy", "–"), r.get("issue_stall", "–"), r.get("parked_over_active", "–"), r.get("lds_conflict", "–"), r["bound"]))
+        "{} … {}".format(r.get("valu_issue_2cyc", "–"), r.get("valu_busy", "–")), r.get("issue_stall", "–"), r.get("parked_over_active", "–"), r.get("lds_conflict", "–"), r["bound"]))
 text = "\n".join(lines)
 print(text)
 if dst:

@@ -18,6 +18,17 @@
 #include "wl_fast.h"
 #include "wl_dev.h"
 
+// Exchange layout (round 6): the {s, d} pairs of rows (2u, 2u+1) are one 16-byte unit u; a lane writes units 2L', 2L'+1 and reads units
+// 2L' .. 2L'+WIN/2-1.  Stored consecutively (byte address 32 L' + 16 c) every ds_read/write_b128 ran at a lane stride of 32 bytes:
+// two lanes per bank, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 (profiles/r06_secondary_pmc_table.md).  Split by parity -- even
+// units in one plane, odd units in the other, unit u at slot u >> 1 -- lane L' touches slot L' + (c >> 1) of plane c & 1: lane stride 16
+// bytes, conflict-free, for the writes and for every window read.  Measured (8192^2, L = 13, three interleaved rounds): db6 222.5 -> 217.0 us,
+// sym8 259.6 -> 262.3, db10 300.5 -> 300.4 -- the conflicts are real but these kernels wait on their dependent multiply-add chains, not on
+// LDS; the split layout is used for 12 and 14 taps, where it pays.
+#ifndef WL_LONG_SPLIT
+#define WL_LONG_SPLIT 1
+#endif
+
 namespace wl {
 
 template <int F>
@@ -68,6 +79,7 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
     const int chunk = (int)(logical / (uint32_t)a.nstrips);
 
     const int rows1 = 4 * nthreads + WIN + 4;         // exchange rows per slot
+    [[maybe_unused]] const int NU = nthreads + 2;      // 16-byte units per parity plane (WL_LONG_SPLIT)
     T2 *const x1 = reinterpret_cast<T2 *>(smem_raw);
 
     const int64_t ms = a.ms, ns = a.ns, nxj = ns >> 1;
@@ -146,8 +158,16 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
             da23 = da23 + gq(F - 1 - m) * T2{xm.z, xm.w};
         }
         T2 *const w1 = x1 + (t & 1) * rows1;
+#if WL_LONG_SPLIT
+        if constexpr (F <= 14) {
+        *reinterpret_cast<T4 *>(w1 + 2 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
+        *reinterpret_cast<T4 *>(w1 + 2 * (NU + lp)) = T4{sa23.x, da23.x, sa23.y, da23.y};
+        } else
+#endif
+        {
         *reinterpret_cast<T4 *>(w1 + 4 * lp) = T4{sa01.x, da01.x, sa01.y, da01.y};
         *reinterpret_cast<T4 *>(w1 + 4 * lp + 2) = T4{sa23.x, da23.x, sa23.y, da23.y};
+        }
         wg_lds_sync(true);
         __builtin_amdgcn_sched_barrier(0);
         if (helper) return;                                // the helper wave owns no output
@@ -155,7 +175,8 @@ __global__ void __launch_bounds__(320, 2) k_fwd2d_lds_long(LdsLongArgs<F> a)
         T2 E[WIN];
 #pragma unroll
         for (int c = 0; c < WIN / 2; ++c) {
-            const T4 v = *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
+            const T4 v = (WL_LONG_SPLIT && F <= 14) ? *reinterpret_cast<const T4 *>(w1 + 2 * ((c & 1) * NU + lp + (c >> 1)))
+                                                    : *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
             E[2 * c] = T2{v.x, v.y};
             E[2 * c + 1] = T2{v.z, v.w};
         }

@@ -50,7 +50,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r05"      # profiles/<round>_<config>_kernel_stats.csv are the committed rocprofv3 summaries of these commands
+PROFILE_ROUND = "r06"      # profiles/<round>_<config>_kernel_stats.csv are the committed rocprofv3 summaries of these commands
 NROT = 3                   # distinct input arrays the timed steps rotate over (8192^2: 3 x 256 MiB > the 256 MiB Infinity Cache)
 NROT_1D = 5                # ... for the 64 MiB 1-D configs (5 x 64 MiB in + 64 MiB out > 256 MiB)
 

@@ -3,7 +3,7 @@
 #   bench lines for every BASELINE config, rocprofv3 kernel stats of the same commands, the PMC traffic passes of the
 #   headline kernel (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only) and the perf matrix.
 #   tools/rp.sh returns as soon as rocprofv3's CSVs are on disk (rocprofv3 does not exit on its own on this image).
-R=${1:-r05}
+R=${1:-r06}
 REPO=$PWD
 O=$REPO/gpurun_out/prof_$R
 mkdir -p $O

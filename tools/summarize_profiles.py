@@ -3,7 +3,7 @@ under profiles/: per-config bench lines, rocprofv3 kernel-stats CSVs, the PMC co
 profiles/pmc_latest.json (bytes per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 note) and the perf matrix."""
 import csv, glob, json, os, shutil, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")

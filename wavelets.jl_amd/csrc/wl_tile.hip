@@ -21,15 +21,17 @@ WL_STAMP_DECL(tileB)
 namespace wl {
 
 // (12..20 taps: 512 threads -- with 1024 the 128-VGPR budget spilled 28 registers of the 24- / 32-row dim-1 window to scratch)
-template <typename T, int F, int NL>
+// OT = 32 (round 6): a 512^2 block is 64 tiles of 64^2 -- a quarter of the CUs, each running two-round passes (1500 / 1148 work items on
+// 1024 threads); 256 tiles of 32^2 carry 2.1x the halo work in total but 0.51x per workgroup, on every CU
+template <typename T, int F, int NL, int OT = 64>
 __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T, F> a)
 {
-    typedef TileLds<F, NL> L;
+    typedef TileLds<F, NL, OT> L;
     typedef T F4t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
     T *S = reinterpret_cast<T *>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int r0 = blockIdx.x * OT, c0 = blockIdx.y * OT;
     constexpr int ld0 = L::ldx(L::R0), ld1 = L::ldx(L::R1), ld2 = L::ldx(L::R2);
     [[maybe_unused]] const int wgid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
     if (tid == 0) WL_STAMP_AT(tile, wgid, 0);
@@ -48,20 +50,20 @@ __global__ void __launch_bounds__((F > 10) ? 512 : 1024) k_fwd2d_tile(TileArgs<T
     if (tid == 0) WL_STAMP_AT(tile, wgid, 1);
     const int hm = a.M >> 1, hn = a.N >> 1;
     if constexpr (NL == 1) {
-        tile_level<T, F, L::R0, L::C0, 32, 32, 32, true>(S + L::X0, ld0, S + L::T, ld0, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 1,
+        tile_level<T, F, L::R0, L::C0, OT / 2, OT / 2, OT / 2, true>(S + L::X0, ld0, S + L::T, ld0, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 1,
                                                       c0 >> 1, hm, hn, tid, nthr);
     } else {
-        tile_level<T, F, L::R0, L::C0, L::R1, L::C1, 32, false>(S + L::X0, ld0, S + L::T, ld0, S + L::X1, ld1, a.tp, a.y, a.ldy, a.ll, a.ldll,
+        tile_level<T, F, L::R0, L::C0, L::R1, L::C1, OT / 2, false>(S + L::X0, ld0, S + L::T, ld0, S + L::X1, ld1, a.tp, a.y, a.ldy, a.ll, a.ldll,
                                                              r0 >> 1, c0 >> 1, hm, hn, tid, nthr);
         if (tid == 0) WL_STAMP_AT(tile, wgid, 2);
         if constexpr (NL == 2) {
-            tile_level<T, F, L::R1, L::C1, 16, 16, 16, true>(S + L::X1, ld1, S + L::T, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2,
+            tile_level<T, F, L::R1, L::C1, OT / 4, OT / 4, OT / 4, true>(S + L::X1, ld1, S + L::T, ld1, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 2,
                                                           c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
         } else {
-            tile_level<T, F, L::R1, L::C1, L::R2, L::C2, 16, false>(S + L::X1, ld1, S + L::T, ld1, S + L::X2, ld2, a.tp, a.y, a.ldy, a.ll,
+            tile_level<T, F, L::R1, L::C1, L::R2, L::C2, OT / 4, false>(S + L::X1, ld1, S + L::T, ld1, S + L::X2, ld2, a.tp, a.y, a.ldy, a.ll,
                                                                  a.ldll, r0 >> 2, c0 >> 2, hm >> 1, hn >> 1, tid, nthr);
             if (tid == 0) WL_STAMP_AT(tile, wgid, 3);
-            tile_level<T, F, L::R2, L::C2, 8, 8, 8, true>(S + L::X2, ld2, S + L::T, ld2, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 3,
+            tile_level<T, F, L::R2, L::C2, OT / 8, OT / 8, OT / 8, true>(S + L::X2, ld2, S + L::T, ld2, nullptr, 0, a.tp, a.y, a.ldy, a.ll, a.ldll, r0 >> 3,
                                                        c0 >> 3, hm >> 2, hn >> 2, tid, nthr);
         }
     }
@@ -223,22 +225,22 @@ bool fwd2d_tile_ok(int F, int NL, int64_t M, int64_t N)
     return M >= 128 && N >= 128 && (M % 64) == 0 && (N % 64) == 0 && M <= 4096 && N <= 4096 && (M >> NL) % 4 == 0 && (N >> NL) >= 1;
 }
 
-template <typename T, int F, int NL>
+template <typename T, int F, int NL, int OT = 64>
 static hipError_t launch_tile_fn(hipStream_t st, const TileArgs<T, F> &a)
 {
-    constexpr size_t shmem = (size_t)TileLds<F, NL>::TOTAL * sizeof(T);
+    constexpr size_t shmem = (size_t)TileLds<F, NL, OT>::TOTAL * sizeof(T);
     static thread_local int done_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (done_dev != dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_tile<T, F, NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2d_tile<T, F, NL, OT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) return e;
         done_dev = dev;
     }
-    unsigned nthr = (unsigned)opt("WL_TILE_THREADS", 1024);
+    unsigned nthr = (unsigned)opt("WL_TILE_THREADS", OT == 32 ? 512 : 1024);
     if (F > 10 && nthr > 512) nthr = 512;
-    hipLaunchKernelGGL((k_fwd2d_tile<T, F, NL>), dim3((unsigned)(a.M / 64), (unsigned)(a.N / 64)), dim3(nthr), shmem, st, a);
+    hipLaunchKernelGGL((k_fwd2d_tile<T, F, NL, OT>), dim3((unsigned)(a.M / OT), (unsigned)(a.N / OT)), dim3(nthr), shmem, st, a);
     return hipGetLastError();
 }
 
@@ -253,7 +255,12 @@ static hipError_t launch_tile_f(hipStream_t st, const Taps<T> &taps, int NL, con
     case 1: return launch_tile_fn<T, F, 1>(st, a);
     case 2: return launch_tile_fn<T, F, 2>(st, a);
     default:
-        if constexpr (sizeof(T) == 4 && F <= 10) return launch_tile_fn<T, F, 3>(st, a);
+        if constexpr (sizeof(T) == 4 && F <= 10) {
+            // three levels: tiles of 32 x 32 while 64 x 64 ones would leave CUs idle (a 512^2 block: 64 tiles) -- (M >> 3) % 4 == 0 holds
+            // for them as for the 64-sample tiles (fwd2d_tile_ok)
+            if ((int64_t)(M / 64) * (N / 64) < (int64_t)opt("WL_TILE32_BELOW", 128) && (M % 32) == 0 && (N % 32) == 0) return launch_tile_fn<T, F, 3, 32>(st, a);
+            return launch_tile_fn<T, F, 3>(st, a);
+        }
         else return hipErrorInvalidValue;          // (three levels of Float64 / of a long filter do not fit the 160 KiB of LDS)
     }
 }

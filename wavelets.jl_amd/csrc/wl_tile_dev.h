@@ -31,28 +31,29 @@ struct TileGeomF {
     static constexpr int WINR = (((F + 6 > 2 * DS + 8) ? F + 6 : 2 * DS + 8) + 3) & ~3;
     static constexpr int HR = WINR - 8;
 };
-// extents of the tile at level l (l = 0: the launch's input), OT = 64 owned input samples per side
-template <int F, int NL, int l>
+// extents of the tile at level l (l = 0: the launch's input), OT owned input samples per side (64; 32 for the three-level tiles of
+// blocks with too few 64-sample tiles to fill the chip, round 6)
+template <int F, int NL, int l, int OT = 64>
 struct TileDim {
     static constexpr int HR = TileGeomF<F>::HR, HC = F - 2;        // one-sided halos per level: rows (d rows shifted by DS), columns
-    static constexpr int R = 2 * TileDim<F, NL, l + 1>::R + HR;    // rows / columns of this level's input that the tile needs
-    static constexpr int C = 2 * TileDim<F, NL, l + 1>::C + HC;
+    static constexpr int R = 2 * TileDim<F, NL, l + 1, OT>::R + HR;    // rows / columns of this level's input that the tile needs
+    static constexpr int C = 2 * TileDim<F, NL, l + 1, OT>::C + HC;
 };
-template <int F, int NL>
-struct TileDim<F, NL, NL> {
-    static constexpr int R = 64 >> NL, C = 64 >> NL;
+template <int F, int NL, int OT>
+struct TileDim<F, NL, NL, OT> {
+    static constexpr int R = OT >> NL, C = OT >> NL;
 };
 
-template <int F, int NL>
+template <int F, int NL, int OT = 64>
 struct TileLds {
     // X0 | T | X1 | X2 (float offsets); leading dimensions padded to a multiple of 4 rows plus 4 (bank spread, 16-byte aligned)
     static constexpr int ldx(int r) { return ((r + 3) & ~3) + 4; }
-    static constexpr int R0 = TileDim<F, NL, 0>::R, C0 = TileDim<F, NL, 0>::C;
-    static constexpr int R1 = TileDim<F, NL, (NL >= 1 ? 1 : 0)>::R, C1 = TileDim<F, NL, (NL >= 1 ? 1 : 0)>::C;
-    static constexpr int R2 = TileDim<F, NL, (NL >= 2 ? 2 : NL)>::R, C2 = TileDim<F, NL, (NL >= 2 ? 2 : NL)>::C;
+    static constexpr int R0 = TileDim<F, NL, 0, OT>::R, C0 = TileDim<F, NL, 0, OT>::C;
+    static constexpr int R1 = TileDim<F, NL, (NL >= 1 ? 1 : 0), OT>::R, C1 = TileDim<F, NL, (NL >= 1 ? 1 : 0), OT>::C;
+    static constexpr int R2 = TileDim<F, NL, (NL >= 2 ? 2 : NL), OT>::R, C2 = TileDim<F, NL, (NL >= 2 ? 2 : NL), OT>::C;
     static constexpr int X0 = 0;
     static constexpr int T = X0 + ldx(R0) * C0;
-    static constexpr int X1 = T + ldx(R0) * (C1 + 32);             // T: R0 rows x (C1 s-columns + 32 owned d-columns)
+    static constexpr int X1 = T + ldx(R0) * (C1 + OT / 2);         // T: R0 rows x (C1 s-columns + OT / 2 owned d-columns)
     static constexpr int X2 = X1 + ldx(R1) * C1;
     static constexpr int TOTAL = X2 + ldx(R2) * C2 + 16;
 };

@@ -33,16 +33,16 @@ CASES = collections.OrderedDict([
 
 def trace_rows(d):
     hits = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
-    return [r for h in hits for r in csv.DictReader(open(h)) if "wl::" in r["Kernel_Name"]]
+    return [r for h in hits for r in csv.DictReader(open(h)) if ("wl::" in r["Kernel_Name"] or "k_modwt" in r["Kernel_Name"] or "anonymous namespace" in r["Kernel_Name"])]
 
 
 def counter_rows(d):
     hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    return [r for h in hits for r in csv.DictReader(open(h)) if "wl::" in r["Kernel_Name"]]
+    return [r for h in hits for r in csv.DictReader(open(h)) if ("wl::" in r["Kernel_Name"] or "k_modwt" in r["Kernel_Name"] or "anonymous namespace" in r["Kernel_Name"])]
 
 
 def short(name):
-    return name.replace("void wl::", "").split("(")[0]
+    return name.replace("void wl::", "").replace("void (anonymous namespace)::", "").split("(")[0]
 
 
 out = []

@@ -58,6 +58,7 @@ struct Pair2DArgs {
     unsigned *prog;                   // npair progress words + a completion counter at prog[npair] (all zero between launches)
     int npair;
     int tprio;                        // issue priority of the tile workgroups (0 .. 3)
+    int chunk0;                       // first chunk of this launch (WL_PAIR_BANDS experiment: the column chunks in K launches)
     float *ll4; int64_t ldll4;        // approximation after levels l+2, l+3 (next stage's input buffer, or y itself)
     TapsF<float, F> tp;
 };
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(64 * (W + 2), 3) k_fwd2d_pair(Pair2DArgs<F> a)
     uint32_t logical = first + (b >> 3);
     if (a.rev) logical = first + (cnt - 1 - (logical - first));
     const int strip = (int)(logical % (uint32_t)a.nstrips);
-    const int chunk = (int)(logical / (uint32_t)a.nstrips);
+    const int chunk = (int)(logical / (uint32_t)a.nstrips) + a.chunk0;
 
     const int64_t ms = a.ms, ns = a.ns, nxj = ns >> 1, nxj2 = ns >> 2;
     const int msi = (int)ms, hmi = msi >> 1, hm2i = msi >> 2;
@@ -637,6 +638,7 @@ static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool l
     a.tp = shrink<float, F>(taps);
     const unsigned nwg = (unsigned)(a.nstrips * a.nchunks);
     a.tprio = (int)opt("WL_FUSE_TPRIO", 0) & 3;
+    a.chunk0 = 0;
     a.prog = pf ? pf->prog : nullptr; a.npair = (int)nwg; a.ll4 = pf ? pf->ll4 : nullptr; a.ldll4 = pf ? pf->ldll4 : 0;
     if (pf) {
         if constexpr (W == 2) {
@@ -653,8 +655,19 @@ static hipError_t launch_pair_fw(hipStream_t st, const Taps<float> &taps, bool l
         } else {
             return hipErrorInvalidValue;
         }
-    } else if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, W, 1>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
-    else hipLaunchKernelGGL((k_fwd2d_pair<F, W, 0>), dim3(nwg), dim3(64 * (W + 2)), 0, st, a);
+    } else {
+        // WL_PAIR_BANDS = K > 1 (measurement only, r06): the column chunks in K launches of nchunks / K chunks each, back to back on the
+        // call's stream -- what splitting the launch into bands costs before any overlap with the tiles could pay it back
+        int K = (int)opt("WL_PAIR_BANDS", 1);
+        if (K < 1 || (a.nchunks % K) != 0) K = 1;
+        const int per = a.nchunks / K;
+        for (int k = 0; k < K; ++k) {
+            a.chunk0 = k * per;
+            const unsigned g = (unsigned)(a.nstrips * per);
+            if (lvl1) hipLaunchKernelGGL((k_fwd2d_pair<F, W, 1>), dim3(g), dim3(64 * (W + 2)), 0, st, a);
+            else hipLaunchKernelGGL((k_fwd2d_pair<F, W, 0>), dim3(g), dim3(64 * (W + 2)), 0, st, a);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -18,7 +18,9 @@ def find(sub, pat):
 for c in ("c1", "c2", "c3", "c4", "c5"):
     p = os.path.join(SRC, f"bench_{c}.json")
     if os.path.exists(p) and os.path.getsize(p) > 10:
-        line = open(p).read().strip().splitlines()[-1]
+        # bench.py prints the complete objects on the line before its short final line (round 6): keep the complete one
+        lines = [l for l in open(p).read().strip().splitlines() if l.startswith("{")]
+        line = max(lines[-2:], key=len)
         json.loads(line)
         open(os.path.join(DST, f"{R}_bench_{c}.json"), "w").write(line + "\n")
 for k in ("c2", "c3", "c4", "c5", "idwt2d", "idwt2d_sym8", "idwt2d_sym5", "idwt2d_f64", "lift2d", "lift2d_inv", "lift3d", "dwt3d", "modwt", "denoise",

@@ -383,6 +383,29 @@ def test_fused_pair_tile_launch(gpu, W, oracle, tj):
         y = W.dwt(x, wt, 13)
     assert W.last_kernel() == "k_fwd2d_pair_tile"
     assert np.array_equal(host(W, y), yref)
+    # ... and the fused launch replays from a hipGraph (its hand-over words are reset by the launch itself, not by the host)
+    import torch
+    s = torch.cuda.Stream()
+    xin = [rng_array((4096, 2048), np.float32, 90 + k) for k in range(3)]
+    xg = dev(W, xin[0])
+    yg = W.similar(xg)
+    with torch.cuda.stream(s):
+        for key, val in (("WL_FUSE4", 1), ("WL_LDS_PAIR_MIN", 0), ("WL_TILEB_MIN", 0), ("WL_TILEB_MAX", 1024), ("WL_TILE", 0), ("WL_M2D_MAX", 64)):
+            W.set_option(key, val)                   # (options are per context = per stream)
+        W.reserve_workspace(xg, 8, full=True)
+        W.dwt_oop_(yg, xg, wt, 8)
+    torch.cuda.synchronize()
+    assert W.last_kernel() == "k_fwd2d_pair_tile"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        W.dwt_oop_(yg, xg, wt, 8)
+    for k in (1, 2, 0, 1):
+        xg.copy_(dev(W, xin[k]))
+        yg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(W.to_host(yg), oracle.dwt_filter(xin[k], wt.qmf, 8)), k
+    del graph
 
 
 @pytest.mark.parametrize("tj", [16, 50, 128])

@@ -62,8 +62,16 @@ struct TileLds {
 // One level inside the tile.  X: input R x C (leading dimension ldx), T: scratch, XN: next level's input (RN x CN) in LDS.
 // OWN = owned outputs per side at this level (32, 16, 8); (r0h, c0h) = tile origin in this level's OUTPUT coordinates;
 // hm, hn = half extents of this level's block; LAST: the approximation goes to global memory (ll) instead of XN.
+// The taps travel BY VALUE (round 6).  By reference, hipcc kept the kernel argument's tap array addressable -- the SLP vectoriser loads
+// runs of consecutive taps as vectors -- and parked it in scratch: 28-48 bytes per lane, reloaded before every pass, in every
+// k_fwd2d_tile instance (k_fwd2d_tile<float, 8, 3>: 125 VGPRs + 32 B scratch -> 68 VGPRs, none; the 20-tap instances 56 B -> 0).
+#ifdef WL_TILE_TAPS_BYREF
+#define WL_TILE_TAPS const TapsF<TT, F> &
+#else
+#define WL_TILE_TAPS const TapsF<TT, F>
+#endif
 template <typename TT, int F, int R, int C, int RN, int CN, int OWN, bool LAST>
-__device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT, TT *XN, int ldN, const TapsF<TT, F> &tp,
+__device__ __forceinline__ void tile_level(const TT *X, int ldX, TT *T, int ldT, TT *XN, int ldN, WL_TILE_TAPS tp,
                                            TT *y, int64_t ldy, TT *ll, int64_t ldll, int r0h, int c0h, int hm, int hn, int tid,
                                            int nthr)
 {

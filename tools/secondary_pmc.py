@@ -109,4 +109,13 @@ text = "\n".join(lines)
 print(text)
 if dst:
     json.dump(out, open(dst + ".json", "w"), indent=1)
-    open(dst + "_table.md", "w").write(text + "\n")
+    head = ("# r06 -- counters of the dominant kernel of the secondary configurations (tools/r06_secondary_pmc.sh)\n\n"
+            "Four rocprofv3 passes per case, `--kernel-trace` only: FETCH_SIZE | WRITE_SIZE | SQ group 1 | SQ group 2.  Per-launch averages of the kernel\n"
+            "with the largest share of the case's kernel time (for 2-D / 3-D transforms the average mixes the levels that kernel serves: level 1\n"
+            "of the 2-D cdf9/7 transform alone is 116 us, level 2 41 us).  traffic = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes; gfx950 correction of\n"
+            "MI355X_MICROARCH.md); HBM TB/s = traffic / launch time under the profiler; VALU issue = SQ_INSTS_VALU x 2 cycles (lower bound: every\n"
+            "instruction at the wave64 issue cost of a SIMD-32) ... x 4 (upper bound: exact for kernels made of packed v_pk_* instructions) over\n"
+            "1024 SIMDs x GRBM_GUI_ACTIVE / 8; issue stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; parked = SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY (s_waitcnt,\n"
+            "barriers); LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.  `reads as`: hbm from 4.5 TB/s, valu from 0.45 of the lower\n"
+            "bound, else latency.  Raw per-launch counter averages: r06_secondary_pmc.json.\n\n")
+    open(dst + "_table.md", "w").write(head + text + "\n")

@@ -364,8 +364,7 @@ static hipError_t launch_tail2_inv_f(hipStream_t st, const Taps<T> &taps, const 
     const int ld = (n1 > 1) ? (n0 + 2) : n0;
     const size_t shmem = (2 * ((size_t)ld * n1 + 8) + 16) * sizeof(T);
     const int pairs = n0 * n1 / 2;
-    // (r06: 12 waves for the 4096-element block -- 64^2 six levels 8.03 us with 512 threads, 7.50 with 768, 7.69 with 1024, 10.1 with 256)
-    int threads = pairs >= 2048 ? 768 : (pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64)));
+    int threads = pairs >= 1024 ? 512 : (pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64));
     const int to = (int)opt("WL_TAIL2_THREADS", 0);
     if (to >= 64 && to <= 512 && (to % 64) == 0) threads = to;
     hipError_t ea = tail2_lds_attr(reinterpret_cast<const void *>(&k_tail2_inv<T, F>), shmem);

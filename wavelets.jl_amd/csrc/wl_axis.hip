@@ -455,11 +455,20 @@ static hipError_t launch_axis(hipStream_t st, const Taps<T> &taps, const T *src,
 // T0/T1: dense scratch of the box size.  Returns false when the shape is not eligible.
 template <typename T>
 bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
-                      T *ll, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err)
+                      T *ll, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err, const char **kname)
 {
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
+    if (kname) *kname = "k_fwd_axis_stream";
+    // round 6: the whole level in one pass over HBM where the one-pass kernel takes the shape (wl_fwd3d.hip)
+    if constexpr (sizeof(T) == 4) {
+        if (fwd3d_one_ok(F, cur, c1, c2, y, y1, y2, ll, n)) {
+            *err = fwd3d_one_launch(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+            if (kname) *kname = "k_fwd3d_one";
+            return true;
+        }
+    }
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||
         (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || !a_al16(cur) || !a_al16(y) || !a_al16(T0) || !a_al16(T1) ||
@@ -661,9 +670,9 @@ WL_INST_LONG(float)
 WL_INST_LONG(double)
 
 template bool fast3d_fwd_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, float *, int64_t, int64_t,
-                                      float *, const int64_t[3], float *, float *, int, hipError_t *);
+                                      float *, const int64_t[3], float *, float *, int, hipError_t *, const char **);
 template bool fast3d_fwd_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t,
-                                       double *, const int64_t[3], double *, double *, int, hipError_t *);
+                                       double *, const int64_t[3], double *, double *, int, hipError_t *, const char **);
 template bool fast3d_inv_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *,
                                       int64_t, int64_t, const int64_t[3], float *, float *, int, hipError_t *);
 template bool fast3d_inv_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *,

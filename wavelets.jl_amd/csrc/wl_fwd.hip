@@ -1657,11 +1657,12 @@ int filter_fwd_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         // ---- 3-D level from three single-axis streaming passes (wl_axis.hip) ----
         if (!done && fastF && b.nd == 3 && b.nt == 3 && env_int("WL_NO_FAST3D", 0) == 0 && cur_st.s[0] == 1 && b.full.s[0] == 1) {
             hipError_t e3 = hipSuccess;
+            const char *k3 = "k_fwd_axis_stream";
             if (!w.T0) return WL_RETRY_GEN;
             done = fast3d_fwd_level<T>(st, taps, cur, cur_st.s[1], cur_st.s[2], y, b.full.s[1], b.full.s[2],
-                                       last ? (T *)nullptr : llbuf, n, w.T0, w.T1, cu_count, &e3);
+                                       last ? (T *)nullptr : llbuf, n, w.T0, w.T1, cu_count, &e3, &k3);
             WL_TRY(e3);
-            if (done && !dominant) dominant = "k_fwd_axis_stream";
+            if (done && !dominant) dominant = k3;
         }
         // ---- 2-D level of any even extents, F <= 10: one LDS-tile launch instead of two generic passes (wl_gtile.hip) ----
         if (!done && fastF && two_d && path == 0 && env_int("WL_GTILE", 1) && b.full.s[0] == 1 && cur_st.s[0] == 1 && gtile_ok(F, n[0], n[1])) {

@@ -71,6 +71,22 @@ def test_checker_flags_read_before_wait_and_copies():
     assert _check([LOAD_A, ("v_add_u32_e32", "v11, s2, v1", 0x68000000), _waitcnt(0), END])                # register reused
 
 
+def test_checker_flags_a_reloaded_sgpr_base_without_wait_states():
+    """Round 6 (wl_fwd3d.hip: scalar-base loads and stores from inline asm): 5 wait states between a VALU write of an SGPR and a
+    vector-memory instruction that reads it as its base."""
+    m = _mod()
+    rl0 = ("v_readlane_b32", "s2, v255, 3", 0xD2890002)
+    rl1 = ("v_readlane_b32", "s3, v255, 4", 0xD2890003)
+    ld = ("global_load_dwordx4", "v[10:13], v1, s[2:3]", 0xDC5C8000)
+    nop4 = ("s_nop", "4", 0xBF800004)
+    salu = ("s_add_u32", "s2, s4, s6", 0x80020604)
+    f = lambda body: m.check_sgpr_base_hazard(m.parse_functions(_listing(body))["k_test"])
+    assert f([rl0, rl1, ld, _waitcnt(0), END])
+    assert f([rl0, rl1, nop4, ld, _waitcnt(0), END]) == []
+    assert f([rl0, rl1, salu, ("s_addc_u32", "s3, s5, s7", 0x82030705), ld, _waitcnt(0), END]) == []     # the base is SALU-made
+    assert f([rl0, rl1, ("global_load_dwordx4", "v[10:13], v[2:3], off", 0xDC5C8000), _waitcnt(0), END]) == []
+
+
 def test_checker_does_not_count_stores_in_strict_mode():
     body = [LOAD_A, STORE, _waitcnt(1), USE_A, END]
     assert _check(body, strict=True)            # the store may be acknowledged first: vmcnt(1) proves nothing about the load

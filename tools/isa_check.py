@@ -36,7 +36,7 @@ _re_vreg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD_PREFIXES = ("global_load_", "buffer_load_", "flat_load_", "scratch_load_", "tbuffer_load_")
 VMEM_PREFIXES = ("global_", "buffer_", "flat_", "scratch_", "tbuffer_")
 # kernels whose loads are issued from inline asm and guarded by hand-counted waits: the strict rule applies
-HAND_PLACED = ("k_fwd2d_lds", "k_fwd2d_pair")
+HAND_PLACED = ("k_fwd2d_lds", "k_fwd2d_pair", "k_fwd3d_one")
 
 
 def extract_code_objects(so_path, workdir):
@@ -357,6 +357,47 @@ def check_function(insts, strict=True, max_report=5):
     return bad
 
 
+_re_spair_last = re.compile(r"s\[(\d+):(\d+)\]")
+
+
+def check_sgpr_base_hazard(insts, max_report=5):
+    """Vector-memory instructions that take their base from an SGPR pair (`global_load_dwordx4 v[..], v1, s[2:3]`: the scalar-base
+    forms of wl_fwd3d.hip, issued from inline asm where hipcc's hazard recogniser does not look): gfx9-family parts need 5 wait
+    states between a VALU write of an SGPR (v_readlane_b32 / v_readfirstlane_b32 -- the reload of a spilled SGPR) and a
+    vector-memory instruction reading it.  -> list of violation strings.  (Straight-line look-back; s_nop N counts N + 1.)"""
+    bad = []
+    for k, ins in enumerate(insts):
+        if not ins.mn.startswith(("global_load", "global_store", "global_atomic")):
+            continue
+        parts = [x.strip() for x in ins.ops.split(",")]
+        base = None
+        for x in parts[1:]:
+            m = _re_spair_last.match(x.split()[0]) if x else None
+            if m:
+                base = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        if not base:
+            continue
+        states, j, pending = 0, k - 1, set(base)
+        while j >= 0 and states < 5 and pending:
+            p = insts[j]
+            if p.mn.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                break
+            w = pending & set(_sdst(p))
+            pending -= w                                  # (the youngest writer of each register is the one that matters)
+            if p.mn.startswith(("v_readlane", "v_readfirstlane")) and w:
+                bad.append("%s %s at 0x%x reads an SGPR base written by %s %s %d wait state(s) earlier (5 required)"
+                           % (ins.mn, ins.ops, ins.addr, p.mn, p.ops, states))
+                break
+            if p.mn == "s_nop":
+                states += (p.enc & 0xF) + 1
+            else:
+                states += 1
+            j -= 1
+        if len(bad) >= max_report:
+            break
+    return bad
+
+
 def trace_path(insts, load_addr, strict=True):
     """debugging aid: the branch decisions of the first violating path from the load at load_addr"""
     li = [k for k, i in enumerate(insts) if i.addr == load_addr][0]
@@ -396,7 +437,7 @@ def _check_code_object(args):
         hand = any(f in name for f in HAND_PLACED)
         if hand:
             stats["hand_placed_kernels"] += 1
-        v = check_function(insts, strict=hand)
+        v = check_function(insts, strict=hand) + check_sgpr_base_hazard(insts)
         if v:
             report[name] = v
     return stats, report

@@ -105,7 +105,7 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 xd = dev(W, x)
                 y = host(W, W.dwt(xd, wt, L))
                 kf = W.last_kernel()
-                k1 = "k_fwd3d_one" if (n >= 256 and dtype == np.float32 and len(wt.qmf) <= 8) else "k_fwd_axis_stream"
+                k1 = "k_fwd3d_one" if (n >= 128 and len(wt.qmf) <= 8) else "k_fwd_axis_stream"     # (round 6: lines of 128 ... 1024)
                 assert (kf == ("k_tail3" if n ** 3 <= 4096 else k1)) == (len(wt.qmf) <= 10), (n, fname, kf)
                 if n <= 128:
                     ye = oracle.dwt_filter(x, wt.qmf, L)
@@ -1958,6 +1958,7 @@ def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
         for fname in ("db4", "haar", "db2", "db5"):
             wt = W.wavelet(getattr(W.WT, fname))
             W.set_option("WL_3D_SLAB", 0)
+            W.set_option("WL_3D_ONE", 0)                                # (round 6: the one-pass level would take these boxes)
             y0 = host(W, W.dwt(xd, wt, L))
             assert W.last_kernel() == "k_fwd_axis_stream"
             for slab in (8, 16):
@@ -1970,14 +1971,17 @@ def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
                 assert np.array_equal(y0, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname)
 
 
-def test_3d_one_pass_level(gpu, W, oracle):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_3d_one_pass_level(gpu, W, oracle, dtype):
     """Round 6: one forward 3-D level in ONE pass over HBM (k_fwd3d_one, wl_fwd3d.hip: whole dim-1 lines per workgroup, tiles of 4 raw
     planes along dim 3, a march along dim 2) instead of the axis-3 pass + the plane kernel.  Bit for bit against the oracle and
-    against the two-pass tier: every filter length it takes (2 .. 8 taps), the three line lengths (1 / 2 / 4 waves per workgroup),
-    the tile whose raw planes wrap around the end of dim 3, segments of 8 .. 64 columns, both prefetch depths, 1 / 2 / 4 tiles per workgroup, with and without a
-    deeper level behind it (approximation corner to the ping-pong buffer or into y) (transforms_filter.jl:246-263)."""
-    for shape, L in (((256, 16, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3), ((512, 64, 16), 1)):
-        x = rng_array(shape, np.float32, shape[1] + shape[2])
+    against the two-pass tier: both element types, every filter length it takes (2 .. 8 taps), every line length (128 .. 1024: 1 .. 8
+    waves per workgroup, 16- and 8-byte lanes), the tile whose raw planes wrap around the end of dim 3, segments of 8 .. 64 columns,
+    with and without a deeper level behind it (approximation corner to the ping-pong buffer or into y)
+    (transforms_filter.jl:246-263)."""
+    for shape, L in (((256, 16, 16), 1), ((128, 32, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3),
+                     ((512, 64, 16), 1), ((128, 64, 64), 2)):
+        x = rng_array(shape, dtype, shape[1] + shape[2])
         xd = dev(W, x)
         for fname in ("db4", "haar", "db2", "db3", "db5"):
             wt = W.wavelet(getattr(W.WT, fname))
@@ -1988,27 +1992,26 @@ def test_3d_one_pass_level(gpu, W, oracle):
             W.clear_options()
             if fname == "db4":
                 assert np.array_equal(y0, oracle.dwt_filter(x, wt.qmf, L)), (shape, fname)
-            for tj, pd, g in ((64, 1, 1), (8, 1, 2), (16, 2, 1), (32, 1, 4)):
+            for tj in (64, 8, 16, 32):
                 W.set_option("WL_3D_ONE_MIN", 0)
-                W.set_option("WL_3D_ONE_G", g)
                 W.set_option("WL_3D_ONE_WAVES", 0)                      # (keep the requested segment length on these small boxes)
                 W.set_option("WL_3D_ONE_TJ", tj)
-                W.set_option("WL_3D_ONE_PD", pd)
                 y1 = host(W, W.dwt(xd, wt, L))
                 k = W.last_kernel()
                 W.clear_options()
                 assert k == ("k_fwd3d_one" if len(wt.qmf) <= 8 else k0), (shape, fname, k)
-                assert np.array_equal(y0, y1), (shape, L, fname, tj, pd, g, int((y0 != y1).sum()))
-    # the default gate: 256^3 and up take it without options
-    x = rng_array((256, 256, 256), np.float32, 77)
-    xd = dev(W, x)
-    wt = W.wavelet(W.WT.db4)
-    y1 = host(W, W.dwt(xd, wt, 2))
-    assert W.last_kernel() == "k_fwd3d_one", W.last_kernel()
-    W.set_option("WL_3D_ONE", 0)
-    y0 = host(W, W.dwt(xd, wt, 2))
-    W.clear_options()
-    assert np.array_equal(y0, y1), int((y0 != y1).sum())
+                assert np.array_equal(y0, y1), (shape, L, fname, tj, int((y0 != y1).sum()))
+    # the default gate: 128^3 and up take it without options
+    for n in (128, 256):
+        x = rng_array((n, n, n), dtype, 77)
+        xd = dev(W, x)
+        wt = W.wavelet(W.WT.db4)
+        y1 = host(W, W.dwt(xd, wt, 2))
+        assert W.last_kernel() == "k_fwd3d_one", W.last_kernel()
+        W.set_option("WL_3D_ONE", 0)
+        y0 = host(W, W.dwt(xd, wt, 2))
+        W.clear_options()
+        assert np.array_equal(y0, y1), (n, int((y0 != y1).sum()))
 
 
 def test_long_filter_tiles_bitexact(gpu, W, oracle):

@@ -462,12 +462,10 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
     *err = hipSuccess;
     if (kname) *kname = "k_fwd_axis_stream";
     // round 6: the whole level in one pass over HBM where the one-pass kernel takes the shape (wl_fwd3d.hip)
-    if constexpr (sizeof(T) == 4) {
-        if (fwd3d_one_ok(F, cur, c1, c2, y, y1, y2, ll, n)) {
-            *err = fwd3d_one_launch(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
-            if (kname) *kname = "k_fwd3d_one";
-            return true;
-        }
+    if (fwd3d_one_ok<T>(F, cur, c1, c2, y, y1, y2, ll, n)) {
+        *err = fwd3d_one_launch<T>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+        if (kname) *kname = "k_fwd3d_one";
+        return true;
     }
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||

@@ -189,10 +189,12 @@ template <typename T>
 int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, const T *x,
                     const LiftScheme<T> &sc, int L, int fw, int *handled, const char **kernel_name, int *hip_err);
 
-// One forward 3-D level in one pass over HBM (wl_fwd3d.hip): Float32, even F <= 8, lines of 256 / 512 / 1024.
-bool fwd3d_one_ok(int F, const float *cur, int64_t c1, int64_t c2, const float *y, int64_t y1, int64_t y2, const float *ll, const int64_t n[3]);
-hipError_t fwd3d_one_launch(hipStream_t st, const Taps<float> &taps, const float *cur, int64_t c1, int64_t c2, float *y, int64_t y1, int64_t y2,
-                            float *ll, const int64_t n[3], int cu_count);
+// One forward 3-D level in one pass over HBM (wl_fwd3d.hip): even F <= 8, lines of 128 ... 1024, both element types.
+template <typename T>
+bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3]);
+template <typename T>
+hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
+                            T *ll, const int64_t n[3], int cu_count);
 
 // One 3-D filter-bank level assembled from single-axis streaming passes (wl_axis.hip); false = not eligible.
 template <typename T>

@@ -1,12 +1,13 @@
-// wl_fwd3d.hip -- one forward 3-D filter-bank level in ONE pass over HBM (Float32, even F <= 8, lines of 256 / 512 / 1024).
+// wl_fwd3d.hip -- one forward 3-D filter-bank level in ONE pass over HBM (both element types, even F <= 8, lines of 128 ... 1024).
 //
-//   k_fwd3d_one<F, PD>    reference: planes -> rows -> columns of one level, transforms_filter.jl:246-263
+//   k_fwd3d_one<T, RPL, F, NW>    reference: planes -> rows -> columns of one level, transforms_filter.jl:246-263
 //
 // The three-launch / two-launch levels of wl_axis.hip read and write the box twice (dim 3 into a scratch box, then dims 2 + 1 per
 // plane).  Here the level-l box is read once and the level's coefficients are written once:
 //
-//   * a workgroup owns WHOLE dim-1 lines (n0 = 256 W rows, W waves, 4 rows per lane: every global access is a 16-byte vector and
-//     the dim-1 window of the topmost lanes wraps inside the workgroup's own LDS exchange -- no halo rows, no helper wave),
+//   * a workgroup owns WHOLE dim-1 lines (n0 = 64 RPL NW rows: NW waves, RPL rows per lane -- 4 Float32 or 2 Float64 rows, every
+//     global access a 16-byte vector; 2 Float32 rows (8 bytes) for lines of 128 -- and the dim-1 window of the topmost lanes wraps
+//     inside the workgroup's own LDS exchange: no halo rows, no helper wave),
 //     a TILE of 4 raw planes along dim 3 (two scaling + two detail planes of the level) and a SEGMENT of TJ columns along dim 2;
 //   * it marches along dim 2.  Per column the F + 2 raw planes the tile's windows cover arrive in a landing ring of VGPRs
 //     (hand-placed global_load_dwordx4 + named s_waitcnt, as in wl_fwd2d.hip) and are folded into the four dim-3 sums as they
@@ -35,24 +36,36 @@
 
 namespace wl {
 
-template <int F>
+template <typename T, int F>
 struct Fwd3DArgs {
-    const float *src; int64_t c1, c2;      // level-l box, strides 1, c1, c2
-    float *y; int64_t y1, y2;              // full array, strides 1, y1, y2
-    float *ll;                             // approximation corner: dense (h0, h1, h2), or nullptr = into y
+    const T *src; int64_t c1, c2;          // level-l box, strides 1, c1, c2
+    T *y; int64_t y1, y2;                  // full array, strides 1, y1, y2
+    T *ll;                                 // approximation corner: dense (h0, h1, h2), or nullptr = into y
     int n0, n1, n2;
     int TJ;                                // owned dim-2 columns per segment (multiple of 8)
     int nseg, ntile;
-    TapsF<float, F> tp;
+    TapsF<T, F> tp;
 };
 
 // element-wise forms (this file is built with -fno-slp-vectorize: scalar v_mul / v_add take a tap straight from its SGPR, the packed
-// forms wanted the taps duplicated into aligned SGPR pairs and their operands in aligned VGPR pairs)
-typedef float F2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ F4 smul(float h, const F4 x) { return F4{h * x.x, h * x.y, h * x.z, h * x.w}; }
-__device__ __forceinline__ F4 smad(const F4 acc, float h, const F4 x) { return F4{acc.x + h * x.x, acc.y + h * x.y, acc.z + h * x.z, acc.w + h * x.w}; }
-__device__ __forceinline__ F2 smul(float h, const F2 x) { return F2{h * x.x, h * x.y}; }
-__device__ __forceinline__ F2 smad(const F2 acc, float h, const F2 x) { return F2{acc.x + h * x.x, acc.y + h * x.y}; }
+// Float32 forms wanted the taps duplicated into aligned SGPR pairs and their operands in aligned VGPR pairs)
+template <typename T, int N> struct Vx { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T, typename V, int N>
+__device__ __forceinline__ V smul(T h, const V x)
+{
+    V o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = h * x[i];
+    return o;
+}
+template <typename T, typename V, int N>
+__device__ __forceinline__ V smad(const V acc, T h, const V x)
+{
+    V o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = acc[i] + h * x[i];
+    return o;
+}
 
 template <int N, typename V>
 __device__ __forceinline__ void wait_vm1(V &a)
@@ -60,23 +73,33 @@ __device__ __forceinline__ void wait_vm1(V &a)
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
 }
 
-// 16 bytes per lane from (64-bit scalar base) + (32-bit unsigned per-lane byte offset)
+// 16 (8) bytes per lane from (64-bit scalar base) + (32-bit unsigned per-lane byte offset)
 template <bool NT, typename V, typename T>
-__device__ __forceinline__ void gload16_s(V &dst, const T *sbase, uint32_t voff)
+__device__ __forceinline__ void gload_s(V &dst, const T *sbase, uint32_t voff)
 {
-    static_assert(sizeof(V) == 16, "one global_load_dwordx4");
-    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8, "global_load_dwordx4 / x2");
+    if constexpr (sizeof(V) == 16) {
+        if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    } else {
+        if constexpr (NT) asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+        else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    }
 }
 
 // POL: 0 plain, 1 non-temporal, 2 write-through (store_pol, wl_dev.h)
 template <int POL, typename V, typename T>
-__device__ __forceinline__ void gstore16_s(T *sbase, uint32_t voff, const V v)
+__device__ __forceinline__ void gstore_s(T *sbase, uint32_t voff, const V v)
 {
-    static_assert(sizeof(V) == 16, "one global_store_dwordx4");
-    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
-    else if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8, "global_store_dwordx4 / x2");
+    if constexpr (sizeof(V) == 16) {
+        if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+        else if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+    } else {
+        if constexpr (POL == 1) asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+        else asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+    }
 }
 
 // The same load tied to the four running sums ("+v"): everything that feeds them -- every product of the plane that just left `dst` --
@@ -84,43 +107,47 @@ __device__ __forceinline__ void gstore16_s(T *sbase, uint32_t voff, const V v)
 // hipcc sank the products below the following loads and the landing ring took twice its registers: spills, and a compiler-placed
 // vmcnt(0) per scratch reload)
 template <bool NT, typename V, typename T>
-__device__ __forceinline__ void gload16_s_tied(V &dst, const T *sbase, uint32_t voff, V &t0, V &t1, V &t2, V &t3)
+__device__ __forceinline__ void gload_s_tied(V &dst, const T *sbase, uint32_t voff, V &t0, V &t1, V &t2, V &t3)
 {
-    static_assert(sizeof(V) == 16, "one global_load_dwordx4");
-    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %5, %6 nt" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %5, %6" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8, "global_load_dwordx4 / x2");
+    if constexpr (sizeof(V) == 16) {
+        if constexpr (NT) asm volatile("global_load_dwordx4 %0, %5, %6 nt" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %5, %6" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
+    } else {
+        if constexpr (NT) asm volatile("global_load_dwordx2 %0, %5, %6 nt" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
+        else asm volatile("global_load_dwordx2 %0, %5, %6" : "=v"(dst), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(voff), "s"(sbase) : "memory");
+    }
 }
 
-template <int F, int PD, int NW, int G>
-__global__ void __launch_bounds__(64 * NW * G, 2) k_fwd3d_one(Fwd3DArgs<F> a)
+template <typename T, int RPL, int F, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
 {
-    typedef float T;
-    typedef float T2 __attribute__((ext_vector_type(2)));
-    typedef float T4 __attribute__((ext_vector_type(4)));
-    constexpr int SH = (F - 2) / 2, KR = F + 2, RS = 8, U = 4, D = PD * KR;
+    typedef typename Vx<T, 2>::type T2;                        // {scaling, detail} of one row in the exchange
+    typedef typename Vx<T, RPL>::type V;                       // the lane's RPL rows
+    typedef typename Vx<T, 4>::type X4;                        // two exchange rows: one 16- / 32-byte LDS access
+    constexpr int SH = (F - 2) / 2, KR = F + 2, RS = 8, U = 4, D = KR;
+    constexpr int NQ = RPL / 2, NE = 10 + 2 * (NQ - 1);        // scaling (and detail) rows a lane produces; its dim-1 window in rows
     static_assert(F >= 2 && F <= 8 && (F % 2) == 0, "8-slot column ring");
+    static_assert(RPL == 2 || RPL == 4, "two or four rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     auto gq = [&](const int m) __attribute__((always_inline)) { return (m & 1) ? -a.tp.h[m] : a.tp.h[m]; };
-    constexpr bool multi = NW * G > 1;
-    // G tiles (neighbours along dim 3) per workgroup: their waves meet at the step barrier, so the planes two tiles share are
-    // requested within a fraction of a step of each other -- L2 hits by construction, not by luck of the dispatch order
-    const int lp = (G == 1) ? (int)threadIdx.x : (int)(threadIdx.x % (64 * NW));
-    const int grp = (G == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / (64 * NW)));
+    constexpr bool multi = NW > 1;
+    const int lp = (int)threadIdx.x;
     // XCD b & 7 owns a contiguous range of tiles (all their segments): tiles that share raw planes share an L2
     const uint32_t b = blockIdx.x, nwg = gridDim.x;
     const uint32_t q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
     const uint32_t first = xcd * q8 + (xcd < r8 ? xcd : r8);
     const uint32_t logical = first + (b >> 3);
-    const int tile = (int)(logical / (uint32_t)a.nseg) * G + grp;
+    const int tile = (int)(logical / (uint32_t)a.nseg);
     const int seg = (int)(logical % (uint32_t)a.nseg);
 
-    constexpr int n0 = 256 * NW, h0 = n0 >> 1;
+    constexpr int n0 = 64 * RPL * NW, h0 = n0 >> 1;
     const int n1 = a.n1, n2 = a.n2, h1 = n1 >> 1, h2 = n2 >> 1;
-    constexpr int rows1 = n0 + 16;                                  // exchange rows per plane (T2 each): the line + a copy of its first rows
-    T2 *const x1 = reinterpret_cast<T2 *>(smem_raw) + grp * (2 * 4 * rows1);      // [G][2][4][rows1]
+    constexpr int rows1 = n0 + 16;                              // exchange rows per plane (T2 each): the line + a copy of its first 8 rows
+    T2 *const x1 = reinterpret_cast<T2 *>(smem_raw);            // [2][4][rows1]
 
-    const int ko = 2 * lp;
+    const int ko = NQ * lp;
     int kod = ko + 4;  if (kod >= h0) kod -= h0;
     const bool odd = (lp & 1) != 0;
     const int j0 = seg * a.TJ;
@@ -136,8 +163,8 @@ __global__ void __launch_bounds__(64 * NW * G, 2) k_fwd3d_one(Fwd3DArgs<F> a)
         if (p >= n2) p -= n2;
         poff[m] = (uint32_t)((int64_t)p * a.c2);
     }
-    const uint32_t rowb = 16u * (uint32_t)lp;
-    const uint32_t vo_s = 4u * (uint32_t)(odd ? ko - 2 : ko), vo_d = 4u * (uint32_t)(h0 + (odd ? kod - 2 : kod));
+    const uint32_t rowb = (uint32_t)sizeof(V) * (uint32_t)lp;
+    const uint32_t vo_s = (uint32_t)sizeof(T) * (uint32_t)(odd ? ko - NQ : ko), vo_d = (uint32_t)sizeof(T) * (uint32_t)(h0 + (odd ? kod - NQ : kod));
     auto colptr = [&](const int c) __attribute__((always_inline)) {
         int jc = j0 + c;
         if (jc >= n1) jc -= n1;
@@ -158,60 +185,60 @@ __global__ void __launch_bounds__(64 * NW * G, 2) k_fwd3d_one(Fwd3DArgs<F> a)
         ldl[z] = to_ll ? (int64_t)h0 : a.y1;
     }
 
-    T4 L[D];
-    T4 ring[RS][4];
+    V L[D];
+    V ring[RS][4];
+    {
+        const T *const cp = colptr(0);
 #pragma unroll
-    for (int c = 0; c < PD; ++c) {
-        const T *const cp = colptr(c);
-#pragma unroll
-        for (int m = 0; m < KR; ++m) gload16_s<WL_P_3D1_LD != 0>(L[c * KR + m], cp + poff[m], rowb);
+        for (int m = 0; m < KR; ++m) gload_s<WL_P_3D1_LD != 0>(L[m], cp + poff[m], rowb);
     }
 
     // One column through the dim-3 pass: plane m of the landing ring is folded into the tile's four sums the moment it has landed
-    // (D - 1 younger loads are behind it), and its register goes back out for the same plane of column c + PD.
-    auto column = [&](const int c, const int slot, const int lbase, const bool prefetch) __attribute__((always_inline)) {
-        T4 s0 = T4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-        const T *const nxt = colptr(c + PD);
+    // (D - 1 younger loads are behind it), and its register goes back out for the same plane of the next column.
+    auto column = [&](const int c, const int slot, const bool prefetch) __attribute__((always_inline)) {
+        V s0, s1, d0, d1;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { s0[i] = (T)0; s1[i] = (T)0; d0[i] = (T)0; d1[i] = (T)0; }
+        const T *const nxt = colptr(c + 1);
 #pragma unroll
         for (int m = 0; m < KR; ++m) {
-            if (prefetch) wait_vm1<D - 1>(L[lbase + m]);
-            else wait_vm1<0>(L[lbase + m]);                      // (last columns of the segment: nothing left to overlap)
-            const T4 x = L[lbase + m];
-            if (m == 0) { s0 = smul(a.tp.h[0], x); d0 = smul(gq(F - 1), x); }
-            else if (m < F) { s0 = smad(s0, a.tp.h[m], x); d0 = smad(d0, gq(F - 1 - m), x); }
-            if (m == 2) { s1 = smul(a.tp.h[0], x); d1 = smul(gq(F - 1), x); }
-            else if (m > 2) { s1 = smad(s1, a.tp.h[m - 2], x); d1 = smad(d1, gq(F + 1 - m), x); }
-            if (prefetch) gload16_s_tied<WL_P_3D1_LD != 0>(L[lbase + m], nxt + poff[m], rowb, s0, s1, d0, d1);
+            if (prefetch) wait_vm1<D - 1>(L[m]);
+            else wait_vm1<0>(L[m]);                              // (last column of the segment: nothing left to overlap)
+            const V x = L[m];
+            if (m == 0) { s0 = smul<T, V, RPL>(a.tp.h[0], x); d0 = smul<T, V, RPL>(gq(F - 1), x); }
+            else if (m < F) { s0 = smad<T, V, RPL>(s0, a.tp.h[m], x); d0 = smad<T, V, RPL>(d0, gq(F - 1 - m), x); }
+            if (m == 2) { s1 = smul<T, V, RPL>(a.tp.h[0], x); d1 = smul<T, V, RPL>(gq(F - 1), x); }
+            else if (m > 2) { s1 = smad<T, V, RPL>(s1, a.tp.h[m - 2], x); d1 = smad<T, V, RPL>(d1, gq(F + 1 - m), x); }
+            if (prefetch) gload_s_tied<WL_P_3D1_LD != 0>(L[m], nxt + poff[m], rowb, s0, s1, d0, d1);
             __builtin_amdgcn_sched_barrier(0);
         }
         ring[slot][0] = s0; ring[slot][1] = s1; ring[slot][2] = d0; ring[slot][3] = d1;
     };
 
 #pragma unroll
-    for (int c = 0; c < F - 2; ++c) column(c, c, (c % PD) * KR, true);
+    for (int c = 0; c < F - 2; ++c) column(c, c, true);
 
-    auto step = [&](const int t, const int u, const bool pfa, const bool pfb) __attribute__((always_inline)) {
-        column(2 * t + F - 2, (2 * u + F - 2) % RS, 0, pfa);
-        column(2 * t + F - 1, (2 * u + F - 1) % RS, (PD == 2) ? KR : 0, pfb);
+    auto step = [&](const int t, const int u, const bool pfb) __attribute__((always_inline)) {
+        column(2 * t + F - 2, (2 * u + F - 2) % RS, true);
+        column(2 * t + F - 1, (2 * u + F - 1) % RS, pfb);
         // ---- dim-2 pass on the column ring, per output plane; {A, B}[r] = scaling / detail (column k / kd) of row r ----
         T2 *const wbuf = x1 + (u & 1) * 4 * rows1;                 // (t and u have the same parity: groups of U = 4 steps)
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
-            T4 sa = smul(a.tp.h[0], ring[(2 * u) % RS][z]);
-            T4 da = smul(gq(F - 1), ring[(2 * u) % RS][z]);
+            V sa = smul<T, V, RPL>(a.tp.h[0], ring[(2 * u) % RS][z]);
+            V da = smul<T, V, RPL>(gq(F - 1), ring[(2 * u) % RS][z]);
 #pragma unroll
             for (int m = 1; m < F; ++m) {
-                const T4 xm = ring[(2 * u + m) % RS][z];
-                sa = smad(sa, a.tp.h[m], xm);
-                da = smad(da, gq(F - 1 - m), xm);
+                const V xm = ring[(2 * u + m) % RS][z];
+                sa = smad<T, V, RPL>(sa, a.tp.h[m], xm);
+                da = smad<T, V, RPL>(da, gq(F - 1 - m), xm);
             }
             T2 *const w1 = wbuf + z * rows1;
-            const T4 v0 = T4{sa.x, da.x, sa.y, da.y}, v1 = T4{sa.z, da.z, sa.w, da.w};
-            *reinterpret_cast<T4 *>(w1 + 4 * lp) = v0;
-            *reinterpret_cast<T4 *>(w1 + 4 * lp + 2) = v1;
-            if (lp < 4) {                                        // the line's first rows again behind its end: the top windows wrap
-                *reinterpret_cast<T4 *>(w1 + n0 + 4 * lp) = v0;
-                *reinterpret_cast<T4 *>(w1 + n0 + 4 * lp + 2) = v1;
+#pragma unroll
+            for (int r = 0; r < RPL; r += 2) {
+                const X4 v = X4{sa[r], da[r], sa[r + 1], da[r + 1]};
+                *reinterpret_cast<X4 *>(w1 + RPL * lp + r) = v;
+                if (RPL * lp < 8) *reinterpret_cast<X4 *>(w1 + n0 + RPL * lp + r) = v;   // the line's first rows again behind its end: the top windows wrap
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -220,48 +247,47 @@ __global__ void __launch_bounds__(64 * NW * G, 2) k_fwd3d_one(Fwd3DArgs<F> a)
         const int k = kbase + t;
         int kd = k + SH;
         if (kd >= h1) kd -= h1;
-        // ---- dim-1 pass: window rows 4L' .. 4L'+11 as {A, B} pairs ----
+        // ---- dim-1 pass: window rows RPL L' .. RPL L' + NE - 1 as {A, B} pairs ----
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
             const T2 *const w1 = wbuf + z * rows1;
-            T2 E[12];
+            T2 E[NE];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const T4 v = *reinterpret_cast<const T4 *>(w1 + 4 * lp + 2 * c);
+            for (int c = 0; c < NE / 2; ++c) {
+                const X4 v = *reinterpret_cast<const X4 *>(w1 + RPL * lp + 2 * c);
                 E[2 * c] = T2{v.x, v.y};
                 E[2 * c + 1] = T2{v.z, v.w};
             }
-            T2 P[2], Q[2];                                 // P[q] = {ss, sd} of row ko + q;  Q[q] = {ds, dd} of row kod + q
+            T2 P[NQ], Q[NQ];                               // P[q] = {ss, sd} of row ko + q;  Q[q] = {ds, dd} of row kod + q
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                T2 s = smul(a.tp.h[0], E[2 * q]);
+            for (int q = 0; q < NQ; ++q) {
+                T2 s = smul<T, T2, 2>(a.tp.h[0], E[2 * q]);
 #pragma unroll
-                for (int m = 1; m < F; ++m) s = smad(s, a.tp.h[m], E[2 * q + m]);
-                T2 d = smul(gq(F - 1), E[2 * q + 10 - F]);
+                for (int m = 1; m < F; ++m) s = smad<T, T2, 2>(s, a.tp.h[m], E[2 * q + m]);
+                T2 d = smul<T, T2, 2>(gq(F - 1), E[2 * q + 10 - F]);
 #pragma unroll
-                for (int m = F - 2; m >= 0; --m) d = smad(d, gq(m), E[2 * q + 9 - m]);
+                for (int m = F - 2; m >= 0; --m) d = smad<T, T2, 2>(d, gq(m), E[2 * q + 9 - m]);
                 P[q] = s;
                 Q[q] = d;
             }
-            T rP[2], rQ[2];
+            // even lane: column k (dim-2 scaling): rows ko .. ko + RPL - 1 and h0 + kod ..;  odd lane: column h1 + kd (dim-2 detail).
+            // Both lanes of a pair issue the same two store instructions: vo_s / vo_d are this lane's two row offsets for the whole
+            // march, the column bases are scalars.
+            V vs, vd;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                rP[q] = from_partner(odd ? P[q].x : P[q].y);
-                rQ[q] = from_partner(odd ? Q[q].x : Q[q].y);
+            for (int q = 0; q < NQ; ++q) {
+                const T rP = from_partner(odd ? P[q].x : P[q].y), rQ = from_partner(odd ? Q[q].x : Q[q].y);
+                vs[q] = odd ? rP : P[q].x;  vs[NQ + q] = odd ? P[q].y : rP;
+                vd[q] = odd ? rQ : Q[q].x;  vd[NQ + q] = odd ? Q[q].y : rQ;
             }
-            // even lane: column k (dim-2 scaling), rows ko..ko+3 and h0+kod..;  odd lane: column h1 + kd (dim-2 detail)
-            // (both lanes of a pair issue the same two store instructions: the column base is a select of two scalars per pair parity,
-            //  kept out of the vector registers: vo_s / vo_d are this lane's two row offsets for the whole march)
             T *const ck = yb[z] + (int64_t)k * a.y1, *const ckd = yb[z] + (int64_t)(h1 + kd) * a.y1, *const cl = lb[z] + (int64_t)k * ldl[z];
-            const T4 vs = odd ? T4{rP[0], rP[1], P[0].y, P[1].y} : T4{P[0].x, P[1].x, rP[0], rP[1]};
-            const T4 vd = odd ? T4{rQ[0], rQ[1], Q[0].y, Q[1].y} : T4{Q[0].x, Q[1].x, rQ[0], rQ[1]};
             if (!odd) {
-                if (z < 2) gstore16_s<WL_P_3D1_LL>(cl, vo_s, vs);
-                else gstore16_s<WL_P_3D1_ST>(cl, vo_s, vs);
-                gstore16_s<WL_P_3D1_ST>(ck, vo_d, vd);
+                if (z < 2) gstore_s<WL_P_3D1_LL>(cl, vo_s, vs);
+                else gstore_s<WL_P_3D1_ST>(cl, vo_s, vs);
+                gstore_s<WL_P_3D1_ST>(ck, vo_d, vd);
             } else {
-                gstore16_s<WL_P_3D1_ST>(ckd, vo_s, vs);
-                gstore16_s<WL_P_3D1_ST>(ckd, vo_d, vd);
+                gstore_s<WL_P_3D1_ST>(ckd, vo_s, vs);
+                gstore_s<WL_P_3D1_ST>(ckd, vo_d, vd);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -270,54 +296,71 @@ __global__ void __launch_bounds__(64 * NW * G, 2) k_fwd3d_one(Fwd3DArgs<F> a)
     int t0 = 0;
     for (; t0 < S - U; t0 += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) step(t0 + u, u, true, true);
+        for (int u = 0; u < U; ++u) step(t0 + u, u, true);
     }
-    // the last PD columns of the segment have no successor to request
+    // the last column of the segment has no successor to request
 #pragma unroll
-    for (int u = 0; u < U; ++u) step(t0 + u, u, (u < U - 1) || PD == 1, u < U - 1);
+    for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - 1);
 }
 
-bool fwd3d_one_ok(int F, const float *cur, int64_t c1, int64_t c2, const float *y, int64_t y1, int64_t y2, const float *ll, const int64_t n[3])
+// rows per lane for a line of n0 (0: not a shape of this kernel): 16-byte lanes where the line fills whole waves, 8-byte Float32 lanes for 128
+template <typename T>
+static int fwd3d_rpl(int64_t n0)
 {
+    if (sizeof(T) == 4) return (n0 == 256 || n0 == 512 || n0 == 1024) ? 4 : (n0 == 128 ? 2 : 0);
+    return (n0 == 128 || n0 == 256 || n0 == 512 || n0 == 1024) ? 2 : 0;
+}
+
+template <typename T>
+bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3])
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
     if (opt("WL_3D_ONE", 1) == 0) return false;
     if (F < 2 || F > 8 || (F & 1)) return false;
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2];
-    if (n0 != 256 && n0 != 512 && n0 != 1024) return false;
+    if (fwd3d_rpl<T>(n0) == 0) return false;
     if (n1 < 16 || (n1 % 16) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 4) != 0 || n2 > (1 << 20)) return false;
-    if ((c1 % 4) != 0 || (c2 % 4) != 0 || (y1 % 4) != 0 || (y2 % 4) != 0 || c1 < n0 || y1 < n0) return false;
+    if ((c1 % VEC) != 0 || (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || c1 < n0 || y1 < n0) return false;
     if (((uintptr_t)cur & 15) != 0 || ((uintptr_t)y & 15) != 0 || (ll && ((uintptr_t)ll & 15) != 0)) return false;
     if ((uint64_t)c2 * (uint64_t)n2 >= ((uint64_t)1 << 32)) return false;              // (32-bit plane offsets inside the box)
     if (cur == y) return false;                                  // (the level reads its input while its output is being written)
-    if (n0 * n1 * n2 < opt("WL_3D_ONE_MIN", (long long)1 << 24)) return false;
+    // (boxes below 2^21 elements: the three single-axis launches are as fast -- measured with half- / quarter-wave lines of 64 / 32 rows:
+    //  128^3 full depth 52.8 against 51.8 us, Float64 63.7 against 56.5 -- so the line lengths stop at 128)
+    if (n0 * n1 * n2 < opt("WL_3D_ONE_MIN", (long long)1 << 21)) return false;
     return true;
 }
+template bool fwd3d_one_ok<float>(int, const float *, int64_t, int64_t, const float *, int64_t, int64_t, const float *, const int64_t[3]);
+template bool fwd3d_one_ok<double>(int, const double *, int64_t, int64_t, const double *, int64_t, int64_t, const double *, const int64_t[3]);
 
 // (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device): once)
-template <int F, int PD, int NW, int G>
-static hipError_t launch_fwd3d_inst(hipStream_t st, unsigned nwg, size_t shmem, const Fwd3DArgs<F> &a)
+template <typename T, int RPL, int F, int NW>
+static hipError_t launch_fwd3d_inst(hipStream_t st, unsigned nwg, const Fwd3DArgs<T, F> &a)
 {
+    const size_t shmem = (size_t)2 * 4 * (64 * RPL * NW + 16) * 2 * sizeof(T);
     static thread_local int attr_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     int dev = 0;
     (void)hipGetDevice(&dev);
     bool done = false;
     for (int i = 0; i < 8; ++i) done = done || attr_dev[i] == dev;
     if (!done && shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd3d_one<F, PD, NW, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd3d_one<T, RPL, F, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         for (int i = 0; i < 8; ++i) if (attr_dev[i] < 0) { attr_dev[i] = dev; break; }
     }
-    hipLaunchKernelGGL((k_fwd3d_one<F, PD, NW, G>), dim3(nwg), dim3(64 * NW * G), shmem, st, a);
+    hipLaunchKernelGGL((k_fwd3d_one<T, RPL, F, NW>), dim3(nwg), dim3(64 * NW), shmem, st, a);
     return hipGetLastError();
 }
 
-template <int F>
-static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<float> &taps, const float *cur, int64_t c1, int64_t c2, float *y, int64_t y1,
-                                 int64_t y2, float *ll, const int64_t n[3], int cu_count)
+template <typename T, int F>
+static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1,
+                                 int64_t y2, T *ll, const int64_t n[3], int cu_count)
 {
-    Fwd3DArgs<F> a;
+    Fwd3DArgs<T, F> a;
     a.src = cur; a.c1 = c1; a.c2 = c2; a.y = y; a.y1 = y1; a.y2 = y2; a.ll = ll;
     a.n0 = (int)n[0]; a.n1 = (int)n[1]; a.n2 = (int)n[2];
-    const int W = a.n0 / 256;
+    const int rpl = fwd3d_rpl<T>(n[0]);
+    if (rpl == 0) return hipErrorInvalidValue;
+    const int W = a.n0 / (64 * rpl);
     a.ntile = a.n2 / 4;
     int TJ = (int)opt("WL_3D_ONE_TJ", 64);
     if (TJ < 8 || (TJ % 8) != 0) TJ = 64;
@@ -325,30 +368,36 @@ static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<float> &taps, const 
     if ((a.n1 % TJ) != 0) return hipErrorInvalidValue;
     a.TJ = TJ;
     a.nseg = a.n1 / TJ;
-    a.tp = shrink<float, F>(taps);
-    int Gw = (int)opt("WL_3D_ONE_G", 1);
-    if ((Gw != 2 && Gw != 4) || W * Gw > 8 || (a.ntile % Gw) != 0) Gw = 1;
-    const unsigned nwg = (unsigned)((a.ntile / Gw) * a.nseg);
-    const size_t shmem = (size_t)Gw * 2 * 4 * (a.n0 + 16) * 8;
-    const bool pd2 = opt("WL_3D_ONE_PD", 1) == 2;
-#define WL_L3(PD_, NW_, G_) return launch_fwd3d_inst<F, PD_, NW_, G_>(st, nwg, shmem, a)
-    if (pd2 && Gw == 1) { if (W == 1) WL_L3(2, 1, 1); else if (W == 2) WL_L3(2, 2, 1); else WL_L3(2, 4, 1); }
-    else if (Gw == 1) { if (W == 1) WL_L3(1, 1, 1); else if (W == 2) WL_L3(1, 2, 1); else WL_L3(1, 4, 1); }
-    else if (Gw == 2) { if (W == 1) WL_L3(1, 1, 2); else if (W == 2) WL_L3(1, 2, 2); else WL_L3(1, 4, 2); }
-    else { if (W == 1) WL_L3(1, 1, 4); else WL_L3(1, 2, 4); }
-#undef WL_L3
+    a.tp = shrink<T, F>(taps);
+    const unsigned nwg = (unsigned)(a.ntile * a.nseg);
+    if constexpr (sizeof(T) == 4) {
+        if (rpl == 2) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
+        if (W == 1) return launch_fwd3d_inst<T, 4, F, 1>(st, nwg, a);
+        if (W == 2) return launch_fwd3d_inst<T, 4, F, 2>(st, nwg, a);
+        return launch_fwd3d_inst<T, 4, F, 4>(st, nwg, a);
+    } else {
+        if (W == 1) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
+        if (W == 2) return launch_fwd3d_inst<T, 2, F, 2>(st, nwg, a);
+        if (W == 4) return launch_fwd3d_inst<T, 2, F, 4>(st, nwg, a);
+        return launch_fwd3d_inst<T, 2, F, 8>(st, nwg, a);
+    }
 }
 
-hipError_t fwd3d_one_launch(hipStream_t st, const Taps<float> &taps, const float *cur, int64_t c1, int64_t c2, float *y, int64_t y1, int64_t y2,
-                            float *ll, const int64_t n[3], int cu_count)
+template <typename T>
+hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
+                            T *ll, const int64_t n[3], int cu_count)
 {
     switch (taps.F) {
-    case 2: return launch_fwd3d_f<2>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
-    case 4: return launch_fwd3d_f<4>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
-    case 6: return launch_fwd3d_f<6>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
-    case 8: return launch_fwd3d_f<8>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+    case 2: return launch_fwd3d_f<T, 2>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+    case 4: return launch_fwd3d_f<T, 4>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+    case 6: return launch_fwd3d_f<T, 6>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+    case 8: return launch_fwd3d_f<T, 8>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
     default: return hipErrorInvalidValue;
     }
 }
+template hipError_t fwd3d_one_launch<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, float *, int64_t, int64_t, float *,
+                                            const int64_t[3], int);
+template hipError_t fwd3d_one_launch<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t, double *,
+                                             const int64_t[3], int);
 
 }  // namespace wl

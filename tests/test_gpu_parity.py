@@ -106,6 +106,8 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 y = host(W, W.dwt(xd, wt, L))
                 kf = W.last_kernel()
                 k1 = "k_fwd3d_one" if (n >= 128 and len(wt.qmf) <= 8) else "k_fwd_axis_stream"     # (round 6: lines of 128 ... 1024)
+                if 4096 < n ** 3 <= 1 << 18:
+                    k1 = "k_level3_lds"                                                            # (round 6: small levels in one launch)
                 assert (kf == ("k_tail3" if n ** 3 <= 4096 else k1)) == (len(wt.qmf) <= 10), (n, fname, kf)
                 if n <= 128:
                     ye = oracle.dwt_filter(x, wt.qmf, L)
@@ -118,7 +120,8 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 assert np.array_equal(y, ye), (n, fname, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
                 ki = W.last_kernel()
-                assert (ki == ("k_tail3" if n ** 3 <= 4096 else "k_inv_axis_stream")) == (len(wt.qmf) <= 10), (n, fname, ki)
+                ki1 = "k_level3_lds" if 4096 < n ** 3 <= 1 << 18 else "k_inv_axis_stream"
+                assert (ki == ("k_tail3" if n ** 3 <= 4096 else ki1)) == (len(wt.qmf) <= 10), (n, fname, ki)
                 if n <= 128:
                     xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
                 else:
@@ -2012,6 +2015,37 @@ def test_3d_one_pass_level(gpu, W, oracle, dtype):
         y0 = host(W, W.dwt(xd, wt, 2))
         W.clear_options()
         assert np.array_equal(y0, y1), (n, int((y0 != y1).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_3d_small_levels_in_one_launch(gpu, W, oracle, dtype):
+    """Round 6: the 3-D levels between the streaming sizes and the one-workgroup tail (4096 < elements <= 2^18) in ONE launch each,
+    forward and inverse (k_level3_lds, wl_level3.hip: LDS blocks of 4^3 / 8^3 coefficient pairs with recomputed halos) instead of
+    three single-axis launches.  Bit for bit against the oracle and against the three-launch tier: both element types, 2 .. 10
+    taps, cubes and non-cubic boxes (extents that are multiples of 8 but not of 16 take the 4^3 blocks), both block sizes forced,
+    levels whose windows wrap more than once around a short axis (transforms_filter.jl:246-287)."""
+    for shape, L in (((32, 32, 32), 1), ((64, 64, 64), 2), ((64, 32, 16), 1), ((48, 40, 24), 1), ((16, 16, 32), 1), ((32, 64, 128), 3), ((64, 64, 64), 6)):
+        x = rng_array(shape, dtype, shape[0] + shape[2])
+        xd = dev(W, x)
+        for fname in ("db4", "haar", "db2", "db3", "db5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            ye = oracle.dwt_filter(x, wt.qmf, L)
+            for opts in ({}, {"WL_LEVEL3_P8_MIN": 1}):
+                for k, v in opts.items():
+                    W.set_option(k, v)
+                y = host(W, W.dwt(xd, wt, L))
+                kf = W.last_kernel()
+                xr = host(W, W.idwt(dev(W, ye), wt, L))
+                ki = W.last_kernel()
+                W.clear_options()
+                assert kf == ki == "k_level3_lds", (shape, fname, kf, ki)
+                assert np.array_equal(y, ye), (shape, L, fname, opts, int((y != ye).sum()))
+                assert np.array_equal(xr, oracle.dwt_filter(ye, wt.qmf, L, fw=False)), (shape, L, fname, opts)
+            W.set_option("WL_LEVEL3", 0)
+            y0 = host(W, W.dwt(xd, wt, L))
+            assert W.last_kernel() != "k_level3_lds"
+            W.clear_options()
+            assert np.array_equal(y0, ye), (shape, fname)
 
 
 def test_long_filter_tiles_bitexact(gpu, W, oracle):

@@ -467,6 +467,12 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
         if (kname) *kname = "k_fwd3d_one";
         return true;
     }
+    // ... and the small levels between the streaming sizes and the one-workgroup tail in one launch each (wl_level3.hip)
+    if (level3_lds_ok<T>(F, n) && cur != y) {
+        *err = level3_lds_launch<T>(st, taps, 1, cur, c1, c2, y, y1, y2, (const T *)nullptr, ll, n);
+        if (kname) *kname = "k_level3_lds";
+        return true;
+    }
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||
         (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || !a_al16(cur) || !a_al16(y) || !a_al16(T0) || !a_al16(T1) ||
@@ -536,11 +542,17 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
 // details from x (dense full strides 1, x1, x2); result to `out` (strides 1, o1, o2 with o1 == n0).
 template <typename T>
 bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
-                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err)
+                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err, const char **kname)
 {
     constexpr int VEC = 16 / sizeof(T);
     const int F = taps.F;
     *err = hipSuccess;
+    if (kname) *kname = "k_inv_axis_stream";
+    if (level3_lds_ok<T>(F, n) && x != out && llsrc != out) {
+        *err = level3_lds_launch<T>(st, taps, 0, x, x1, x2, out, o1, o2, llsrc, (T *)nullptr, n);
+        if (kname) *kname = "k_level3_lds";
+        return true;
+    }
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || o1 != n0 ||
         (o2 % VEC) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 || !a_al16(x) || !a_al16(out) || !a_al16(T0) || !a_al16(T1) ||
@@ -672,8 +684,8 @@ template bool fast3d_fwd_level<float>(hipStream_t, const Taps<float> &, const fl
 template bool fast3d_fwd_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, double *, int64_t, int64_t,
                                        double *, const int64_t[3], double *, double *, int, hipError_t *, const char **);
 template bool fast3d_inv_level<float>(hipStream_t, const Taps<float> &, const float *, int64_t, int64_t, const float *, float *,
-                                      int64_t, int64_t, const int64_t[3], float *, float *, int, hipError_t *);
+                                      int64_t, int64_t, const int64_t[3], float *, float *, int, hipError_t *, const char **);
 template bool fast3d_inv_level<double>(hipStream_t, const Taps<double> &, const double *, int64_t, int64_t, const double *, double *,
-                                       int64_t, int64_t, const int64_t[3], double *, double *, int, hipError_t *);
+                                       int64_t, int64_t, const int64_t[3], double *, double *, int, hipError_t *, const char **);
 
 }  // namespace wl

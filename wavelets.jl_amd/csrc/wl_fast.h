@@ -196,13 +196,20 @@ template <typename T>
 hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
                             T *ll, const int64_t n[3], int cu_count);
 
+// One small 3-D level (4096 < elements <= 2^18) in one launch, forward or inverse (wl_level3.hip): LDS blocks of 4^3 / 8^3 pairs.
+template <typename T>
+bool level3_lds_ok(int F, const int64_t n[3]);
+template <typename T>
+hipError_t level3_lds_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t s1, int64_t s2, T *dst, int64_t d1, int64_t d2,
+                             const T *llr, T *llw, const int64_t n[3]);
+
 // One 3-D filter-bank level assembled from single-axis streaming passes (wl_axis.hip); false = not eligible.
 template <typename T>
 bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
                       T *ll, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err, const char **kname = nullptr);
 template <typename T>
 bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *llsrc,
-                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err);
+                      T *out, int64_t o1, int64_t o2, const int64_t n[3], T *T0, T *T1, int cu_count, hipError_t *err, const char **kname = nullptr);
 
 // one fused 2-D inverse level through an LDS exchange, 8..20 taps (wl_inv2d_long.hip: which filter lengths per element type); ll = deeper reconstruction or nullptr
 bool inv2d_long_ok(int F, int64_t n0, int64_t n1, int esize);

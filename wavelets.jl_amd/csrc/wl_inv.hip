@@ -1320,10 +1320,11 @@ int filter_inv_levels(void *ws, bool ws_gen, int cu_count, int path, hipStream_t
         if (!done && fastF && b.nd == 3 && b.nt == 3 && i_env("WL_NO_FAST3D", 0) == 0 && b.full.s[0] == 1 && res_st.s[0] == 1) {
             hipError_t e3 = hipSuccess;
             if (!w.T0) return WL_RETRY_GEN;
+            const char *k3 = "k_inv_axis_stream";
             done = fast3d_inv_level<T>(st, taps, x, b.full.s[1], b.full.s[2], llsrc, res, res_st.s[1], res_st.s[2], n,
-                                       w.T0, w.T1, cu_count, &e3);
+                                       w.T0, w.T1, cu_count, &e3, &k3);
             WL_TRYI(e3);
-            if (done) dominant = "k_inv_axis_stream";
+            if (done) dominant = k3;
         }
         // ---- 2-D level of any even extents, F <= 10: one LDS-tile launch instead of two generic passes (wl_gtile.hip) ----
         if (!done && fastF && two_d && path == 0 && i_env("WL_GTILE", 1) && b.full.s[0] == 1 && res_st.s[0] == 1 && gtile_ok(F, n[0], n[1])) {

@@ -476,8 +476,15 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||
         (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || !a_al16(cur) || !a_al16(y) || !a_al16(T0) || !a_al16(T1) ||
-        (ll && !a_al16(ll)) || n1 > 32767)
+        (ll && !a_al16(ll)) || n1 > 32767) {
+        // not a shape of the axis kernels: the LDS blocks up to a larger box before the any-extent kernels take it (wl_level3.hip)
+        if (level3_lds_ok<T>(F, n, true) && cur != y) {
+            *err = level3_lds_launch<T>(st, taps, 1, cur, c1, c2, y, y1, y2, (const T *)nullptr, ll, n);
+            if (kname) *kname = "k_level3_lds";
+            return true;
+        }
         return false;
+    }
     bool ok = false;
     WL_DISPATCH_FA(F, {
         // An option, OFF by default (round 5, measured): the level in SLABS of output plane pairs -- the axis-3 pass of a slab writes
@@ -556,8 +563,14 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2], h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || o1 != n0 ||
         (o2 % VEC) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 || !a_al16(x) || !a_al16(out) || !a_al16(T0) || !a_al16(T1) ||
-        (llsrc && !a_al16(llsrc)) || n1 > 32767 || (h0 % 4) != 0)
+        (llsrc && !a_al16(llsrc)) || n1 > 32767 || (h0 % 4) != 0) {
+        if (level3_lds_ok<T>(F, n, true) && x != out && llsrc != out) {
+            *err = level3_lds_launch<T>(st, taps, 0, x, x1, x2, out, o1, o2, llsrc, (T *)nullptr, n);
+            if (kname) *kname = "k_level3_lds";
+            return true;
+        }
         return false;
+    }
     bool ok = false;
     WL_DISPATCH_FA(F, {
         // columns + rows of every plane in ONE launch when the planes are big enough for the fused 2-D inverse kernel

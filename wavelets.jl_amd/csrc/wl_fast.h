@@ -198,7 +198,7 @@ hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, i
 
 // One small 3-D level (4096 < elements <= 2^18) in one launch, forward or inverse (wl_level3.hip): LDS blocks of 4^3 / 8^3 pairs.
 template <typename T>
-bool level3_lds_ok(int F, const int64_t n[3]);
+bool level3_lds_ok(int F, const int64_t n[3], bool any_tier = false);
 template <typename T>
 hipError_t level3_lds_launch(hipStream_t st, const Taps<T> &taps, int fw, const T *src, int64_t s1, int64_t s2, T *dst, int64_t d1, int64_t d2,
                              const T *llr, T *llw, const int64_t n[3]);

@@ -148,18 +148,21 @@ __global__ void __launch_bounds__(256) k_level3_lds(Level3Args<T, F> a)
     }
 }
 
+// any_tier: the box is not a shape of the axis / plane kernels (extents that are not powers of two: the any-extent kernels of
+// wl_anyaxis.hip would take it, three launches per level) -- there the blocks stay ahead up to about 2^20 elements (96^3 dwt L = 2
+// 32.7 -> 22.5 us, idwt 30.4 -> 24.3; 200^3 and 240 x 240 x 160 lose: 80 -> 95, 107 -> 125)
 template <typename T>
-bool level3_lds_ok(int F, const int64_t n[3])
+bool level3_lds_ok(int F, const int64_t n[3], bool any_tier)
 {
     if (opt("WL_LEVEL3", 1) == 0) return false;
     if (F < 2 || F > 10 || (F & 1)) return false;
     for (int a = 0; a < 3; ++a)
         if (n[a] < 16 || (n[a] % 8) != 0 || n[a] > 4096) return false;
     const int64_t tot = n[0] * n[1] * n[2];
-    return tot > 4096 && tot <= opt("WL_LEVEL3_MAX", (long long)1 << 18);
+    return tot > 4096 && tot <= (any_tier ? opt("WL_LEVEL3_MAX_ANY", (long long)1 << 20) : opt("WL_LEVEL3_MAX", (long long)1 << 18));
 }
-template bool level3_lds_ok<float>(int, const int64_t[3]);
-template bool level3_lds_ok<double>(int, const int64_t[3]);
+template bool level3_lds_ok<float>(int, const int64_t[3], bool);
+template bool level3_lds_ok<double>(int, const int64_t[3], bool);
 
 template <typename T, int F, int P, int FW>
 static hipError_t launch_level3_inst(hipStream_t st, const Level3Args<T, F> &a0, const int64_t n[3])

@@ -222,3 +222,46 @@ def test_lifting_3d_lds_tail_against_per_axis_launches(gpu, W, seed):
             xs.append(W.idwt(y, sch, L))
         W.clear_options()
         assert torch.equal(ys[0], ys[1]) and torch.equal(xs[0], xs[1]), (n, L, str(dt), sch.name)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
+    """Round 6: k_fwd3d_one (one forward 3-D level per pass over HBM) and k_level3_lds (small levels in one launch, both directions)
+    against the tiers they replace (WL_3D_ONE = 0, WL_LEVEL3 = 0: single-axis passes / plane kernels / any-extent kernels), random
+    boxes, both element types, 2 ... 10 taps, random depths and segment lengths; device against device, every element."""
+    import torch
+    r = np.random.default_rng(seed)
+    gen = torch.Generator(device="cpu").manual_seed(300 + seed)
+    hit1 = hit3 = 0
+    for it in range(36):
+        dt = torch.float32 if r.random() < 0.6 else torch.float64
+        if it % 2 == 0:          # streaming sizes: lines of 128 ... 1024
+            n0 = int(r.choice([128, 256, 256, 512, 1024]))
+            n1 = 16 * int(r.integers(1, 13))
+            n2 = 4 * int(r.integers(4, 25))
+            while n0 * n1 * n2 > (1 << 23):
+                n1 = max(16, n1 // 2)
+        else:                    # block sizes: extents that are multiples of 8
+            n0, n1, n2 = (8 * int(r.integers(2, 13)) for _ in range(3))
+        fname = str(r.choice(["haar", "db2", "db3", "db4", "db4", "sym4", "db5", "sym5"]))
+        wt = W.wavelet(getattr(W.WT, fname))
+        x = torch.randn(n2, n1, n0, generator=gen, dtype=dt).cuda().permute(2, 1, 0)        # Julia layout
+        L = int(r.integers(1, min(3, W.maxtransformlevels(x)) + 1))
+        W.set_option("WL_3D_ONE", 0)
+        W.set_option("WL_LEVEL3", 0)
+        y0 = W.dwt(x, wt, L)
+        x0 = W.idwt(y0, wt, L)
+        W.clear_options()
+        W.set_option("WL_3D_ONE_MIN", 0)
+        W.set_option("WL_3D_ONE_TJ", int(r.choice([8, 16, 32, 64])))
+        W.set_option("WL_3D_ONE_WAVES", int(r.choice([0, 8])))
+        y1 = W.dwt(x, wt, L)
+        kf = W.last_kernel()
+        x1 = W.idwt(y0, wt, L)
+        ki = W.last_kernel()
+        W.clear_options()
+        hit1 += int(kf == "k_fwd3d_one")
+        hit3 += int(kf == "k_level3_lds") + int(ki == "k_level3_lds")
+        assert torch.equal(y0, y1), (n0, n1, n2, fname, L, kf, str(dt))
+        assert torch.equal(x0, x1), (n0, n1, n2, fname, L, ki, str(dt))
+    assert hit1 >= 8 and hit3 >= 12, (hit1, hit3)            # (the comparison must not be vacuous)

@@ -1978,12 +1978,13 @@ def test_3d_forward_level_in_slabs(gpu, W, oracle, dtype):
 def test_3d_one_pass_level(gpu, W, oracle, dtype):
     """Round 6: one forward 3-D level in ONE pass over HBM (k_fwd3d_one, wl_fwd3d.hip: whole dim-1 lines per workgroup, tiles of 4 raw
     planes along dim 3, a march along dim 2) instead of the axis-3 pass + the plane kernel.  Bit for bit against the oracle and
-    against the two-pass tier: both element types, every filter length it takes (2 .. 8 taps), every line length (128 .. 1024: 1 .. 8
-    waves per workgroup, 16- and 8-byte lanes), the tile whose raw planes wrap around the end of dim 3, segments of 8 .. 64 columns,
+    against the two-pass tier: both element types, every filter length it takes (2 .. 8 taps), every line length (32 .. 1024 rows in multiples
+    of 8 / 4: 1 .. 8 waves per workgroup, 16- and 8-byte lanes, partly filled last waves), the tile whose raw planes wrap around the end of dim 3, segments of 8 .. 64 columns,
     with and without a deeper level behind it (approximation corner to the ping-pong buffer or into y)
     (transforms_filter.jl:246-263)."""
     for shape, L in (((256, 16, 16), 1), ((128, 32, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3),
-                     ((512, 64, 16), 1), ((128, 64, 64), 2)):
+                     ((512, 64, 16), 1), ((128, 64, 64), 2), ((200, 24, 20), 1), ((240, 40, 16), 2), ((320, 16, 16), 1), ((72, 16, 16), 1),
+                     ((1000, 16, 16), 1), ((136, 48, 24), 1)):         # (the last six: lines that do not fill the last wave, segments of 24 / 40 columns)
         x = rng_array(shape, dtype, shape[1] + shape[2])
         xd = dev(W, x)
         for fname in ("db4", "haar", "db2", "db3", "db5"):

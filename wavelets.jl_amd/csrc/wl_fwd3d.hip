@@ -142,9 +142,12 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     const int tile = (int)(logical / (uint32_t)a.nseg);
     const int seg = (int)(logical % (uint32_t)a.nseg);
 
-    constexpr int n0 = 64 * RPL * NW, h0 = n0 >> 1;
+    // the line: n0 <= 64 RPL NW rows, a multiple of 2 RPL; lanes past its end (lines that do not fill the last wave: 200, 240, 320 ...)
+    // load row 0, publish and store nothing
+    const int n0 = a.n0, h0 = n0 >> 1;
     const int n1 = a.n1, n2 = a.n2, h1 = n1 >> 1, h2 = n2 >> 1;
-    constexpr int rows1 = n0 + 16;                              // exchange rows per plane (T2 each): the line + a copy of its first 8 rows
+    constexpr int rows1 = 64 * RPL * NW + 16;                   // exchange rows per plane (T2 each): the line + a copy of its first 8 rows
+    const bool active = RPL * lp < n0;
     T2 *const x1 = reinterpret_cast<T2 *>(smem_raw);            // [2][4][rows1]
 
     const int ko = NQ * lp;
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
         if (p >= n2) p -= n2;
         poff[m] = (uint32_t)((int64_t)p * a.c2);
     }
-    const uint32_t rowb = (uint32_t)sizeof(V) * (uint32_t)lp;
+    const uint32_t rowb = active ? (uint32_t)sizeof(V) * (uint32_t)lp : 0u;
     const uint32_t vo_s = (uint32_t)sizeof(T) * (uint32_t)(odd ? ko - NQ : ko), vo_d = (uint32_t)sizeof(T) * (uint32_t)(h0 + (odd ? kod - NQ : kod));
     auto colptr = [&](const int c) __attribute__((always_inline)) {
         int jc = j0 + c;
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
 #pragma unroll
             for (int r = 0; r < RPL; r += 2) {
                 const X4 v = X4{sa[r], da[r], sa[r + 1], da[r + 1]};
-                *reinterpret_cast<X4 *>(w1 + RPL * lp + r) = v;
+                if (active) *reinterpret_cast<X4 *>(w1 + RPL * lp + r) = v;
                 if (RPL * lp < 8) *reinterpret_cast<X4 *>(w1 + n0 + RPL * lp + r) = v;   // the line's first rows again behind its end: the top windows wrap
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -281,11 +284,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
                 vd[q] = odd ? rQ : Q[q].x;  vd[NQ + q] = odd ? Q[q].y : rQ;
             }
             T *const ck = yb[z] + (int64_t)k * a.y1, *const ckd = yb[z] + (int64_t)(h1 + kd) * a.y1, *const cl = lb[z] + (int64_t)k * ldl[z];
-            if (!odd) {
+            if (active && !odd) {
                 if (z < 2) gstore_s<WL_P_3D1_LL>(cl, vo_s, vs);
                 else gstore_s<WL_P_3D1_ST>(cl, vo_s, vs);
                 gstore_s<WL_P_3D1_ST>(ck, vo_d, vd);
-            } else {
+            } else if (active) {
                 gstore_s<WL_P_3D1_ST>(ckd, vo_s, vs);
                 gstore_s<WL_P_3D1_ST>(ckd, vo_d, vd);
             }
@@ -303,12 +306,21 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     for (int u = 0; u < U; ++u) step(t0 + u, u, u < U - 1);
 }
 
-// rows per lane for a line of n0 (0: not a shape of this kernel): 16-byte lanes where the line fills whole waves, 8-byte Float32 lanes for 128
+// rows per lane for a line of n0 (0: not a shape of this kernel): 16-byte lanes for lines beyond 128 Float32 rows, 8-byte Float32 lanes
+// up to 128; the line has to be a multiple of 2 RPL rows (lane pairs store RPL consecutive rows of each half)
 template <typename T>
 static int fwd3d_rpl(int64_t n0)
 {
-    if (sizeof(T) == 4) return (n0 == 256 || n0 == 512 || n0 == 1024) ? 4 : (n0 == 128 ? 2 : 0);
-    return (n0 == 128 || n0 == 256 || n0 == 512 || n0 == 1024) ? 2 : 0;
+    if (n0 < 32 || n0 > 1024) return 0;
+    if (sizeof(T) == 4 && n0 > 128) return (n0 % 8) == 0 ? 4 : 0;
+    return (n0 % 4) == 0 ? 2 : 0;
+}
+// waves per workgroup: 1, 2, 4 (8: Float64 lines beyond 512) -- the smallest of them that holds the line
+static int fwd3d_waves(int64_t n0, int rpl)
+{
+    int w = 1;
+    while ((int64_t)64 * rpl * w < n0) w <<= 1;
+    return w;
 }
 
 template <typename T>
@@ -319,7 +331,7 @@ bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64
     if (F < 2 || F > 8 || (F & 1)) return false;
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2];
     if (fwd3d_rpl<T>(n0) == 0) return false;
-    if (n1 < 16 || (n1 % 16) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 4) != 0 || n2 > (1 << 20)) return false;
+    if (n1 < 16 || (n1 % 8) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 4) != 0 || n2 > (1 << 20)) return false;
     if ((c1 % VEC) != 0 || (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || c1 < n0 || y1 < n0) return false;
     if (((uintptr_t)cur & 15) != 0 || ((uintptr_t)y & 15) != 0 || (ll && ((uintptr_t)ll & 15) != 0)) return false;
     if ((uint64_t)c2 * (uint64_t)n2 >= ((uint64_t)1 << 32)) return false;              // (32-bit plane offsets inside the box)
@@ -360,11 +372,12 @@ static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<T> &taps, const T *c
     a.n0 = (int)n[0]; a.n1 = (int)n[1]; a.n2 = (int)n[2];
     const int rpl = fwd3d_rpl<T>(n[0]);
     if (rpl == 0) return hipErrorInvalidValue;
-    const int W = a.n0 / (64 * rpl);
+    const int W = fwd3d_waves(a.n0, rpl);
     a.ntile = a.n2 / 4;
+    // segment length: the largest multiple of 8 columns <= the requested one that divides n1 and leaves >= 8 waves per CU
     int TJ = (int)opt("WL_3D_ONE_TJ", 64);
     if (TJ < 8 || (TJ % 8) != 0) TJ = 64;
-    while (TJ > 8 && ((a.n1 % TJ) != 0 || (int64_t)a.ntile * (a.n1 / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ >>= 1;
+    while (TJ > 8 && ((a.n1 % TJ) != 0 || (int64_t)a.ntile * (a.n1 / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ -= 8;
     if ((a.n1 % TJ) != 0) return hipErrorInvalidValue;
     a.TJ = TJ;
     a.nseg = a.n1 / TJ;

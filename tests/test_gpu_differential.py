@@ -236,7 +236,7 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
     for it in range(36):
         dt = torch.float32 if r.random() < 0.6 else torch.float64
         if it % 2 == 0:          # streaming sizes: lines of 128 ... 1024
-            n0 = int(r.choice([128, 256, 256, 512, 1024])) if r.random() < 0.5 else 8 * int(r.integers(4, 129))
+            n0 = int(r.choice([128, 256, 256, 512, 1024])) if r.random() < 0.5 else 4 * int(r.integers(8, 257))
             n1 = 8 * int(r.integers(2, 25))
             n2 = 4 * int(r.integers(4, 25))
             while n0 * n1 * n2 > (1 << 23):

@@ -1984,7 +1984,7 @@ def test_3d_one_pass_level(gpu, W, oracle, dtype):
     (transforms_filter.jl:246-263)."""
     for shape, L in (((256, 16, 16), 1), ((128, 32, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3),
                      ((512, 64, 16), 1), ((128, 64, 64), 2), ((200, 24, 20), 1), ((240, 40, 16), 2), ((320, 16, 16), 1), ((72, 16, 16), 1),
-                     ((1000, 16, 16), 1), ((136, 48, 24), 1)):         # (the last six: lines that do not fill the last wave, segments of 24 / 40 columns)
+                     ((1000, 16, 16), 1), ((136, 48, 24), 1), ((300, 16, 16), 1), ((180, 24, 20), 1), ((900, 16, 16), 1)):         # (the last nine: lines that do not fill the last wave, 8-byte lanes on two to eight waves, segments of 24 / 40 columns)
         x = rng_array(shape, dtype, shape[1] + shape[2])
         xd = dev(W, x)
         for fname in ("db4", "haar", "db2", "db3", "db5"):

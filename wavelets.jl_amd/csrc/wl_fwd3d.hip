@@ -312,8 +312,8 @@ template <typename T>
 static int fwd3d_rpl(int64_t n0)
 {
     if (n0 < 32 || n0 > 1024) return 0;
-    if (sizeof(T) == 4 && n0 > 128) return (n0 % 8) == 0 ? 4 : 0;
-    return (n0 % 4) == 0 ? 2 : 0;
+    if (sizeof(T) == 4 && n0 > 128 && (n0 % 8) == 0) return 4;
+    return (n0 % 4) == 0 ? 2 : 0;                               // (Float32 lines that are multiples of 4 only: 8-byte lanes, up to 8 waves)
 }
 // waves per workgroup: 1, 2, 4 (8: Float64 lines beyond 512) -- the smallest of them that holds the line
 static int fwd3d_waves(int64_t n0, int rpl)
@@ -384,7 +384,10 @@ static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<T> &taps, const T *c
     a.tp = shrink<T, F>(taps);
     const unsigned nwg = (unsigned)(a.ntile * a.nseg);
     if constexpr (sizeof(T) == 4) {
-        if (rpl == 2) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
+        if (rpl == 2 && W == 1) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
+        if (rpl == 2 && W == 2) return launch_fwd3d_inst<T, 2, F, 2>(st, nwg, a);
+        if (rpl == 2 && W == 4) return launch_fwd3d_inst<T, 2, F, 4>(st, nwg, a);
+        if (rpl == 2) return launch_fwd3d_inst<T, 2, F, 8>(st, nwg, a);
         if (W == 1) return launch_fwd3d_inst<T, 4, F, 1>(st, nwg, a);
         if (W == 2) return launch_fwd3d_inst<T, 4, F, 2>(st, nwg, a);
         return launch_fwd3d_inst<T, 4, F, 4>(st, nwg, a);

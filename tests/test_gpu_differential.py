@@ -237,10 +237,10 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
         dt = torch.float32 if r.random() < 0.6 else torch.float64
         if it % 2 == 0:          # streaming sizes: lines of 128 ... 1024
             n0 = int(r.choice([128, 256, 256, 512, 1024])) if r.random() < 0.5 else 4 * int(r.integers(8, 257))
-            n1 = 8 * int(r.integers(2, 25))
-            n2 = 4 * int(r.integers(4, 25))
+            n1 = 2 * int(r.integers(8, 100))
+            n2 = 2 * int(r.integers(8, 50))
             while n0 * n1 * n2 > (1 << 23):
-                n1 = max(16, n1 // 2)
+                n1 = max(16, (n1 // 4) * 2)
         else:                    # block sizes: extents that are multiples of 8
             n0, n1, n2 = (8 * int(r.integers(2, 13)) for _ in range(3))
         fname = str(r.choice(["haar", "db2", "db3", "db4", "db4", "sym4", "db5", "sym5"]))

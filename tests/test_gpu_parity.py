@@ -639,7 +639,7 @@ def test_any_axis_pass_kernels(gpu, W, oracle, dtype):
             ki = W.last_kernel()
             assert np.array_equal(xr, xe), (shape, fname, L, ki, "inv")
             assert "generic" not in kf and "generic" not in ki, (shape, fname, kf, ki)
-            with W.options(WL_ANYAXIS=0, WL_LEVEL3=0):
+            with W.options(WL_ANYAXIS=0, WL_LEVEL3=0, WL_3D_ONE=0):
                 assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (shape, fname, "generic")
                 assert "generic" in W.last_kernel() or "tail" in W.last_kernel(), W.last_kernel()
                 assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), xe), (shape, fname, "generic inv")
@@ -1984,7 +1984,9 @@ def test_3d_one_pass_level(gpu, W, oracle, dtype):
     (transforms_filter.jl:246-263)."""
     for shape, L in (((256, 16, 16), 1), ((128, 32, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3),
                      ((512, 64, 16), 1), ((128, 64, 64), 2), ((200, 24, 20), 1), ((240, 40, 16), 2), ((320, 16, 16), 1), ((72, 16, 16), 1),
-                     ((1000, 16, 16), 1), ((136, 48, 24), 1), ((300, 16, 16), 1), ((180, 24, 20), 1), ((900, 16, 16), 1)):         # (the last nine: lines that do not fill the last wave, 8-byte lanes on two to eight waves, segments of 24 / 40 columns)
+                     ((1000, 16, 16), 1), ((136, 48, 24), 1), ((300, 16, 16), 1), ((180, 24, 20), 1), ((900, 16, 16), 1),
+                     ((256, 20, 18), 1), ((200, 30, 22), 1), ((304, 36, 28), 2), ((128, 70, 26), 1)):         # (from 200 x 24 x 20 on: lines that do not fill the last wave, 8-byte lanes on two to eight waves, dim-2 / dim-3 extents
+                                                                       #  that are not multiples of 8 / 4: the last segment / tile overlaps its neighbour)
         x = rng_array(shape, dtype, shape[1] + shape[2])
         xd = dev(W, x)
         for fname in ("db4", "haar", "db2", "db3", "db5"):
@@ -2033,6 +2035,7 @@ def test_3d_small_levels_in_one_launch(gpu, W, oracle, dtype):
             wt = W.wavelet(getattr(W.WT, fname))
             ye = oracle.dwt_filter(x, wt.qmf, L)
             for opts in ({}, {"WL_LEVEL3_P8_MIN": 1}):
+                W.set_option("WL_3D_ONE_MIN_ANY", 1 << 40)              # (96^3 would otherwise take the one-pass forward level)
                 for k, v in opts.items():
                     W.set_option(k, v)
                 y = host(W, W.dwt(xd, wt, L))

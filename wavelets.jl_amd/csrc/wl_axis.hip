@@ -477,7 +477,13 @@ bool fast3d_fwd_level(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || c1 != n0 ||
         (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || !a_al16(cur) || !a_al16(y) || !a_al16(T0) || !a_al16(T1) ||
         (ll && !a_al16(ll)) || n1 > 32767) {
-        // not a shape of the axis kernels: the LDS blocks up to a larger box before the any-extent kernels take it (wl_level3.hip)
+        // not a shape of the axis kernels: the one-pass level from 2^19 elements, the LDS blocks up to 2^20, before the any-extent
+        // kernels take it (three passes per level)
+        if (fwd3d_one_ok<T>(F, cur, c1, c2, y, y1, y2, ll, n, true)) {
+            *err = fwd3d_one_launch<T>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+            if (kname) *kname = "k_fwd3d_one";
+            return true;
+        }
         if (level3_lds_ok<T>(F, n, true) && cur != y) {
             *err = level3_lds_launch<T>(st, taps, 1, cur, c1, c2, y, y1, y2, (const T *)nullptr, ll, n);
             if (kname) *kname = "k_level3_lds";

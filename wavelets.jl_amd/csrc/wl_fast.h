@@ -191,7 +191,7 @@ int lifting_3d_fast(void *ws, int cu_count, hipStream_t st, int64_t n0, T *y, co
 
 // One forward 3-D level in one pass over HBM (wl_fwd3d.hip): even F <= 8, lines of 128 ... 1024, both element types.
 template <typename T>
-bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3]);
+bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3], bool any_tier = false);
 template <typename T>
 hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
                             T *ll, const int64_t n[3], int cu_count);

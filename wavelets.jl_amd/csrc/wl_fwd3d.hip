@@ -141,6 +141,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     const uint32_t logical = first + (b >> 3);
     const int tile = (int)(logical / (uint32_t)a.nseg);
     const int seg = (int)(logical % (uint32_t)a.nseg);
+    // dim 2 / dim 3 extents that are not multiples of the segment / of 4: the last segment (tile) is moved back to end at the edge and
+    // recomputes a few columns (one plane pair) of its neighbour -- the same values to the same addresses
+    const int p0 = (4 * tile + 4 <= a.n2) ? 4 * tile : a.n2 - 4;
 
     // the line: n0 <= 64 RPL NW rows, a multiple of 2 RPL; lanes past its end (lines that do not fill the last wave: 200, 240, 320 ...)
     // load row 0, publish and store nothing
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     const int ko = NQ * lp;
     int kod = ko + 4;  if (kod >= h0) kod -= h0;
     const bool odd = (lp & 1) != 0;
-    const int j0 = seg * a.TJ;
+    const int j0 = (seg * a.TJ + a.TJ <= a.n1) ? seg * a.TJ : a.n1 - a.TJ;
     const int S = a.TJ >> 1;                                    // steps (multiple of U)
     const int kbase = j0 >> 1;
 
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     uint32_t poff[KR];                                          // (elements)
 #pragma unroll
     for (int m = 0; m < KR; ++m) {
-        int p = 4 * tile + m;
+        int p = p0 + m;
         if (p >= n2) p -= n2;
         poff[m] = (uint32_t)((int64_t)p * a.c2);
     }
@@ -174,13 +177,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
         return a.src + (int64_t)jc * a.c1;
     };
 
-    // output planes: z = 0, 1 scaling planes 2 tile + z;  z = 2, 3 detail planes h2 + (2 tile + z - 2 + SH) mod h2
+    // output planes: z = 0, 1 scaling planes p0 / 2 + z;  z = 2, 3 detail planes h2 + (p0 / 2 + z - 2 + SH) mod h2
     T *yb[4];
     T *lb[4];
     int64_t ldl[4];
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
-        int pz = 2 * tile + (z & 1);
+        int pz = (p0 >> 1) + (z & 1);
         if (z >= 2) { pz += SH; if (pz >= h2) pz -= h2; pz += h2; }
         yb[z] = a.y + (int64_t)pz * a.y2;
         const bool to_ll = (a.ll != nullptr) && z < 2;
@@ -324,25 +327,27 @@ static int fwd3d_waves(int64_t n0, int rpl)
 }
 
 template <typename T>
-bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3])
+bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64_t y1, int64_t y2, const T *ll, const int64_t n[3], bool any_tier)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (opt("WL_3D_ONE", 1) == 0) return false;
     if (F < 2 || F > 8 || (F & 1)) return false;
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2];
     if (fwd3d_rpl<T>(n0) == 0) return false;
-    if (n1 < 16 || (n1 % 8) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 4) != 0 || n2 > (1 << 20)) return false;
+    if (n1 < 16 || (n1 % 2) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 2) != 0 || n2 > (1 << 20)) return false;
     if ((c1 % VEC) != 0 || (c2 % VEC) != 0 || (y1 % VEC) != 0 || (y2 % VEC) != 0 || c1 < n0 || y1 < n0) return false;
     if (((uintptr_t)cur & 15) != 0 || ((uintptr_t)y & 15) != 0 || (ll && ((uintptr_t)ll & 15) != 0)) return false;
     if ((uint64_t)c2 * (uint64_t)n2 >= ((uint64_t)1 << 32)) return false;              // (32-bit plane offsets inside the box)
     if (cur == y) return false;                                  // (the level reads its input while its output is being written)
     // (boxes below 2^21 elements: the three single-axis launches are as fast -- measured with half- / quarter-wave lines of 64 / 32 rows:
     //  128^3 full depth 52.8 against 51.8 us, Float64 63.7 against 56.5 -- so the line lengths stop at 128)
-    if (n0 * n1 * n2 < opt("WL_3D_ONE_MIN", (long long)1 << 21)) return false;
+    // any_tier: not a shape of the axis / plane kernels -- the alternative is the three any-extent passes, and the gate drops to 2^19 + 1
+    // (100^3 level 22.1 -> 14.0 us, 120^3 28.3 -> 14.9; 80^3 stays with the LDS blocks of wl_level3.hip)
+    if (n0 * n1 * n2 < (any_tier ? opt("WL_3D_ONE_MIN_ANY", ((long long)1 << 19) + 1) : opt("WL_3D_ONE_MIN", (long long)1 << 21))) return false;
     return true;
 }
-template bool fwd3d_one_ok<float>(int, const float *, int64_t, int64_t, const float *, int64_t, int64_t, const float *, const int64_t[3]);
-template bool fwd3d_one_ok<double>(int, const double *, int64_t, int64_t, const double *, int64_t, int64_t, const double *, const int64_t[3]);
+template bool fwd3d_one_ok<float>(int, const float *, int64_t, int64_t, const float *, int64_t, int64_t, const float *, const int64_t[3], bool);
+template bool fwd3d_one_ok<double>(int, const double *, int64_t, int64_t, const double *, int64_t, int64_t, const double *, const int64_t[3], bool);
 
 // (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device): once)
 template <typename T, int RPL, int F, int NW>
@@ -373,14 +378,17 @@ static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<T> &taps, const T *c
     const int rpl = fwd3d_rpl<T>(n[0]);
     if (rpl == 0) return hipErrorInvalidValue;
     const int W = fwd3d_waves(a.n0, rpl);
-    a.ntile = a.n2 / 4;
-    // segment length: the largest multiple of 8 columns <= the requested one that divides n1 and leaves >= 8 waves per CU
+    a.ntile = (a.n2 + 3) / 4;
+    // segment length: the largest multiple of 8 columns <= the requested one that leaves >= 8 waves per CU; a length that divides n1 is
+    // preferred over a longer one that does not (the last segment of a non-dividing length recomputes columns of its neighbour)
     int TJ = (int)opt("WL_3D_ONE_TJ", 64);
     if (TJ < 8 || (TJ % 8) != 0) TJ = 64;
-    while (TJ > 8 && ((a.n1 % TJ) != 0 || (int64_t)a.ntile * (a.n1 / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ -= 8;
-    if ((a.n1 % TJ) != 0) return hipErrorInvalidValue;
+    while (TJ > 8 && (TJ > a.n1 || (int64_t)a.ntile * ((a.n1 + TJ - 1) / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ -= 8;
+    if (TJ > a.n1) return hipErrorInvalidValue;
+    for (int t = TJ; t >= 8 && t >= TJ - 16; t -= 8)
+        if ((a.n1 % t) == 0) { TJ = t; break; }
     a.TJ = TJ;
-    a.nseg = a.n1 / TJ;
+    a.nseg = (a.n1 + TJ - 1) / TJ;
     a.tp = shrink<T, F>(taps);
     const unsigned nwg = (unsigned)(a.ntile * a.nseg);
     if constexpr (sizeof(T) == 4) {

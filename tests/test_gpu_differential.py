@@ -232,7 +232,7 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
     import torch
     r = np.random.default_rng(seed)
     gen = torch.Generator(device="cpu").manual_seed(300 + seed)
-    hit1 = hit3 = 0
+    hit1 = hit3 = hiti = 0
     for it in range(36):
         dt = torch.float32 if r.random() < 0.6 else torch.float64
         if it % 2 == 0:          # streaming sizes: lines of 128 ... 1024
@@ -248,6 +248,7 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
         x = torch.randn(n2, n1, n0, generator=gen, dtype=dt).cuda().permute(2, 1, 0)        # Julia layout
         L = int(r.integers(1, min(3, W.maxtransformlevels(x)) + 1))
         W.set_option("WL_3D_ONE", 0)
+        W.set_option("WL_I3D_ONE", 0)
         W.set_option("WL_LEVEL3", 0)
         y0 = W.dwt(x, wt, L)
         x0 = W.idwt(y0, wt, L)
@@ -255,13 +256,19 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
         W.set_option("WL_3D_ONE_MIN", 0)
         W.set_option("WL_3D_ONE_TJ", int(r.choice([8, 16, 32, 64])))
         W.set_option("WL_3D_ONE_WAVES", int(r.choice([0, 8])))
+        for key in ("WL_I3D_ONE_MIN", "WL_I3D_ONE_MIN_LONG", "WL_I3D_ONE_MIN_ANY"):
+            W.set_option(key, 0)
+        W.set_option("WL_I3D_ONE_F64_FMAX", 8)
+        W.set_option("WL_I3D_ONE_TK", int(r.choice([4, 8, 16, 32])))
+        W.set_option("WL_I3D_ONE_WAVES", int(r.choice([0, 8])))
         y1 = W.dwt(x, wt, L)
         kf = W.last_kernel()
         x1 = W.idwt(y0, wt, L)
         ki = W.last_kernel()
         W.clear_options()
         hit1 += int(kf == "k_fwd3d_one")
+        hiti += int(ki == "k_inv3d_one")
         hit3 += int(kf == "k_level3_lds") + int(ki == "k_level3_lds")
         assert torch.equal(y0, y1), (n0, n1, n2, fname, L, kf, str(dt))
         assert torch.equal(x0, x1), (n0, n1, n2, fname, L, ki, str(dt))
-    assert hit1 >= 8 and hit3 >= 12, (hit1, hit3)            # (the comparison must not be vacuous)
+    assert hit1 >= 8 and hit3 >= 4 and hiti >= 6, (hit1, hit3, hiti)            # (the comparison must not be vacuous)

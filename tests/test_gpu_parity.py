@@ -120,7 +120,7 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 assert np.array_equal(y, ye), (n, fname, L, np.abs(y - ye).max())
                 xr = host(W, W.idwt(dev(W, ye), wt, L))
                 ki = W.last_kernel()
-                ki1 = "k_level3_lds" if 4096 < n ** 3 <= 1 << 18 else "k_inv_axis_stream"
+                ki1 = "k_level3_lds" if 4096 < n ** 3 <= 1 << 18 else ("k_inv3d_one" if (n >= 256 and len(wt.qmf) <= 4) else "k_inv_axis_stream")
                 assert (ki == ("k_tail3" if n ** 3 <= 4096 else ki1)) == (len(wt.qmf) <= 10), (n, fname, ki)
                 if n <= 128:
                     xe = oracle.dwt_filter(ye, wt.qmf, L, fw=False)
@@ -639,7 +639,7 @@ def test_any_axis_pass_kernels(gpu, W, oracle, dtype):
             ki = W.last_kernel()
             assert np.array_equal(xr, xe), (shape, fname, L, ki, "inv")
             assert "generic" not in kf and "generic" not in ki, (shape, fname, kf, ki)
-            with W.options(WL_ANYAXIS=0, WL_LEVEL3=0, WL_3D_ONE=0):
+            with W.options(WL_ANYAXIS=0, WL_LEVEL3=0, WL_3D_ONE=0, WL_I3D_ONE=0):
                 assert np.array_equal(host(W, W.dwt(dev(W, x), wt, L)), ye), (shape, fname, "generic")
                 assert "generic" in W.last_kernel() or "tail" in W.last_kernel(), W.last_kernel()
                 assert np.array_equal(host(W, W.idwt(dev(W, ye), wt, L)), xe), (shape, fname, "generic inv")
@@ -2021,6 +2021,52 @@ def test_3d_one_pass_level(gpu, W, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_3d_inverse_one_pass_level(gpu, W, oracle, dtype):
+    """Round 6: one INVERSE 3-D level in one pass over HBM (k_inv3d_one, wl_inv3d.hip: whole dim-1 lines per workgroup, tiles of two
+    output column pairs along dim 2, a march along dim 3 with a ring of reconstructed planes) instead of the plane kernel + the axis-3
+    pass.  Bit for bit against the oracle and the two-pass tier: both element types, 2 .. 8 taps, lines of 32 .. 1024 rows (16- and
+    8-byte lanes, partly filled waves), dim-2 / dim-3 extents that are not multiples of 4 / of the segment, segments of every
+    length, with the approximation octant in the coefficient array (L = 1) and in the ping-pong buffer (L > 1)
+    (transforms_filter.jl:264-287)."""
+    for shape, L in (((256, 16, 16), 1), ((128, 32, 16), 1), ((256, 32, 48), 2), ((512, 16, 20), 1), ((1024, 16, 16), 2), ((256, 64, 32), 3),
+                     ((512, 64, 16), 1), ((128, 64, 64), 2), ((200, 24, 20), 1), ((240, 40, 16), 2), ((72, 16, 16), 1), ((1000, 16, 16), 1),
+                     ((300, 16, 16), 1), ((256, 20, 18), 1), ((200, 30, 22), 1), ((128, 70, 26), 1)):
+        if dtype == np.float64 and shape[0] > 512:
+            continue
+        x = rng_array(shape, dtype, shape[1] + shape[2] + 1)
+        for fname in ("db4", "haar", "db2", "db3", "db5"):
+            wt = W.wavelet(getattr(W.WT, fname))
+            yd = W.dwt(dev(W, x), wt, L)
+            W.set_option("WL_I3D_ONE", 0)
+            x0 = host(W, W.idwt(yd, wt, L))
+            k0 = W.last_kernel()
+            assert k0 != "k_inv3d_one", k0
+            W.clear_options()
+            if fname == "db4":
+                assert np.array_equal(x0, oracle.dwt_filter(host(W, yd), wt.qmf, L, fw=False)), (shape, fname)
+            for tk in (32, 4, 8, 16):
+                for key in ("WL_I3D_ONE_MIN", "WL_I3D_ONE_MIN_LONG", "WL_I3D_ONE_MIN_ANY", "WL_I3D_ONE_WAVES"):
+                    W.set_option(key, 0)
+                W.set_option("WL_I3D_ONE_F64_FMAX", 8)
+                W.set_option("WL_I3D_ONE_TK", tk)
+                x1 = host(W, W.idwt(yd, wt, L))
+                k = W.last_kernel()
+                W.clear_options()
+                assert k == ("k_inv3d_one" if len(wt.qmf) <= 8 else k0), (shape, fname, k)
+                assert np.array_equal(x0, x1), (shape, L, fname, tk, int((x0 != x1).sum()))
+    for n in (256,):                                   # the default gate: 2^24 elements for 2 / 4 taps (2^27 for 6 / 8 taps, Float32 only)
+        x = rng_array((n, n, n), dtype, 78)
+        wt = W.wavelet(W.WT.db2)
+        yd = W.dwt(dev(W, x), wt, 2)
+        x1 = host(W, W.idwt(yd, wt, 2))
+        assert W.last_kernel() == "k_inv3d_one", W.last_kernel()
+        W.set_option("WL_I3D_ONE", 0)
+        x0 = host(W, W.idwt(yd, wt, 2))
+        W.clear_options()
+        assert np.array_equal(x0, x1), (n, int((x0 != x1).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_3d_small_levels_in_one_launch(gpu, W, oracle, dtype):
     """Round 6: the 3-D levels between the streaming sizes and the one-workgroup tail (4096 < elements <= 2^18) in ONE launch each,
     forward and inverse (k_level3_lds, wl_level3.hip: LDS blocks of 4^3 / 8^3 coefficient pairs with recomputed halos) instead of
@@ -2035,7 +2081,8 @@ def test_3d_small_levels_in_one_launch(gpu, W, oracle, dtype):
             wt = W.wavelet(getattr(W.WT, fname))
             ye = oracle.dwt_filter(x, wt.qmf, L)
             for opts in ({}, {"WL_LEVEL3_P8_MIN": 1}):
-                W.set_option("WL_3D_ONE_MIN_ANY", 1 << 40)              # (96^3 would otherwise take the one-pass forward level)
+                W.set_option("WL_3D_ONE_MIN_ANY", 1 << 40)              # (96^3 would otherwise take the one-pass levels)
+                W.set_option("WL_I3D_ONE_MIN_ANY", 1 << 40)
                 for k, v in opts.items():
                     W.set_option(k, v)
                 y = host(W, W.dwt(xd, wt, L))
@@ -2101,7 +2148,7 @@ def test_3d_box_beyond_2_31_elements(gpu, W):
     assert torch.equal(y, yg)
     del yg
     xr = W.idwt(y, wt, 2)
-    assert W.last_kernel() == "k_inv_axis_stream", W.last_kernel()
+    assert W.last_kernel() == "k_inv3d_one", W.last_kernel()                     # (round 6: the one-pass inverse level)
     try:
         W.set_kernel_path(1)
         xg = W.idwt(y, wt, 2)

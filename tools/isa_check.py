@@ -36,7 +36,7 @@ _re_vreg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD_PREFIXES = ("global_load_", "buffer_load_", "flat_load_", "scratch_load_", "tbuffer_load_")
 VMEM_PREFIXES = ("global_", "buffer_", "flat_", "scratch_", "tbuffer_")
 # kernels whose loads are issued from inline asm and guarded by hand-counted waits: the strict rule applies
-HAND_PLACED = ("k_fwd2d_lds", "k_fwd2d_pair", "k_fwd3d_one")
+HAND_PLACED = ("k_fwd2d_lds", "k_fwd2d_pair", "k_fwd3d_one", "k_inv3d_one")
 
 
 def extract_code_objects(so_path, workdir):

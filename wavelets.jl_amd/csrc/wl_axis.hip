@@ -561,6 +561,11 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     const int F = taps.F;
     *err = hipSuccess;
     if (kname) *kname = "k_inv_axis_stream";
+    if (inv3d_one_ok<T>(F, x, x1, x2, llsrc, out, o1, o2, n)) {
+        *err = inv3d_one_launch<T>(st, taps, x, x1, x2, llsrc, out, o1, o2, n, cu_count);
+        if (kname) *kname = "k_inv3d_one";
+        return true;
+    }
     if (level3_lds_ok<T>(F, n) && x != out && llsrc != out) {
         *err = level3_lds_launch<T>(st, taps, 0, x, x1, x2, out, o1, o2, llsrc, (T *)nullptr, n);
         if (kname) *kname = "k_level3_lds";
@@ -570,6 +575,11 @@ bool fast3d_inv_level(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x
     if ((F % 2) != 0 || F > 10 || !short_ok(n0) || n1 < 16 || n2 < 16 || (n1 % 16) != 0 || (n2 % 16) != 0 || o1 != n0 ||
         (o2 % VEC) != 0 || (x1 % VEC) != 0 || (x2 % VEC) != 0 || !a_al16(x) || !a_al16(out) || !a_al16(T0) || !a_al16(T1) ||
         (llsrc && !a_al16(llsrc)) || n1 > 32767 || (h0 % 4) != 0) {
+        if (inv3d_one_ok<T>(F, x, x1, x2, llsrc, out, o1, o2, n, true)) {
+            *err = inv3d_one_launch<T>(st, taps, x, x1, x2, llsrc, out, o1, o2, n, cu_count);
+            if (kname) *kname = "k_inv3d_one";
+            return true;
+        }
         if (level3_lds_ok<T>(F, n, true) && x != out && llsrc != out) {
             *err = level3_lds_launch<T>(st, taps, 0, x, x1, x2, out, o1, o2, llsrc, (T *)nullptr, n);
             if (kname) *kname = "k_level3_lds";

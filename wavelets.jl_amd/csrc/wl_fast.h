@@ -196,6 +196,13 @@ template <typename T>
 hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, int64_t c1, int64_t c2, T *y, int64_t y1, int64_t y2,
                             T *ll, const int64_t n[3], int cu_count);
 
+// One inverse 3-D level in one pass over HBM (wl_inv3d.hip): even F <= 8, lines of 32 ... 1024, both element types.
+template <typename T>
+bool inv3d_one_ok(int F, const T *x, int64_t x1, int64_t x2, const T *ll, const T *out, int64_t o1, int64_t o2, const int64_t n[3], bool any_tier = false);
+template <typename T>
+hipError_t inv3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *x, int64_t x1, int64_t x2, const T *ll, T *out, int64_t o1, int64_t o2,
+                            const int64_t n[3], int cu_count);
+
 // One small 3-D level (4096 < elements <= 2^18) in one launch, forward or inverse (wl_level3.hip): LDS blocks of 4^3 / 8^3 pairs.
 template <typename T>
 bool level3_lds_ok(int F, const int64_t n[3], bool any_tier = false);

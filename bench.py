@@ -841,6 +841,7 @@ def secondary_leg(W, device, reps=20):
     x3 = [torch.randn(512, 512, 512, generator=g, dtype=torch.float32).to(device).permute(2, 1, 0) for _ in range(2)]   # 2 x 512 MiB
     y3 = W.similar(x3[0])
     run("3-D dwt db4 filter 512^3 f32", 9, "f32", x3, lambda t: (lambda: W.dwt_oop_(y3, t, db4, 9)), 2 * x3[0].numel() * 4)
+    run("3-D idwt db4 filter 512^3 f32", 9, "f32", x3, lambda t: (lambda: W.idwt_oop_(y3, t, db4, 9)), 2 * x3[0].numel() * 4)
     del x3, y3
     torch.cuda.empty_cache()
     x3d = [torch.randn(512, 512, 512, generator=g, dtype=torch.float64).to(device).permute(2, 1, 0) for _ in range(2)]   # 2 x 1 GiB

@@ -7,8 +7,8 @@ OUT=../../profiles/${R}_kernel_resources.md
 {
 echo "| kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | LDS B/block (static) | waves/SIMD | VGPR spill | SGPR spill |"
 echo "|---|---|---|---|---|---|---|---|---|"
-for f in wl_fwd2d wl_fwd3d wl_level3 wl_pair2d wl_fwd2d64 wl_pair2d64 wl_fwd2d_long wl_inv2d_long wl_tile wl_tail wl_gtile wl_anyaxis wl_fwd wl_inv wl_wpt wl_lift wl_lift_tile wl_axis wl_vlong wl_ext wl_generic; do
-  extra=""; { [ $f = wl_vlong ] || [ $f = wl_inv2d_long ] || [ $f = wl_fwd3d ]; } && extra="-fno-slp-vectorize"          # (as in the Makefile)
+for f in wl_fwd2d wl_fwd3d wl_inv3d wl_level3 wl_pair2d wl_fwd2d64 wl_pair2d64 wl_fwd2d_long wl_inv2d_long wl_tile wl_tail wl_gtile wl_anyaxis wl_fwd wl_inv wl_wpt wl_lift wl_lift_tile wl_axis wl_vlong wl_ext wl_generic; do
+  extra=""; { [ $f = wl_vlong ] || [ $f = wl_inv2d_long ] || [ $f = wl_fwd3d ] || [ $f = wl_inv3d ]; } && extra="-fno-slp-vectorize"          # (as in the Makefile)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -DWL_BUILDING_LIB $extra \
       -Rpass-analysis=kernel-resource-usage -c $f.hip -o /tmp/kr_$f.o 2>&1 | python3 -c "
 import re, subprocess, sys

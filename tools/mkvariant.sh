@@ -9,7 +9,7 @@ BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=
 OBJS=""
 for f in $S/*.o; do b=$(basename $f .o); skip=0; for t in "$@"; do [ "$b.hip" = "$t" ] && skip=1; done; [ $skip = 0 ] && OBJS="$OBJS $f"; done
 for t in "$@"; do
-  extra=""; case $t in wl_vlong.hip|wl_inv2d_long.hip|wl_fwd3d.hip) extra="-fno-slp-vectorize";; esac
+  extra=""; case $t in wl_vlong.hip|wl_inv2d_long.hip|wl_fwd3d.hip|wl_inv3d.hip) extra="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc $BASE $extra $FLAGS -c $S/$t -o $O/${t%.hip}.o &
 done
 wait

@@ -29,7 +29,7 @@ def demangle(names):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--so", default=os.path.join(ROOT, "wavelets.jl_amd", "libwavelets_mi355x.so"))
-    ap.add_argument("--filter", default=r"k_fwd2d_pair<8, 2, 1, 0, 0>|k_fwd3d_one<(float, 4|double, 2), 8, (2|4)>|k_fwd2d_lds<8, 1, 0>|k_inv2d_pair<8|k_inv2d_lds_long<float, (10|16), 1, [23], 0, [12]>|"
+    ap.add_argument("--filter", default=r"k_fwd2d_pair<8, 2, 1, 0, 0>|k_fwd3d_one<(float, 4|double, 2), 8, (2|4)>|k_inv3d_one<float, 4, 8, 2>|k_level3_lds<float, 8, 4, [01]>|k_fwd2d_lds<8, 1, 0>|k_inv2d_pair<8|k_inv2d_lds_long<float, (10|16), 1, [23], 0, [12]>|"
                                        r"k_fwd2d_lds_long<16, 20, 1>|k_fwd1d_multi<float, 8, 1>|k_lift1d_fwd3<float, 0, 1>|k_lift2d_fwd<float, 0, 8>|"
                                        r"k_fwd2d_tileB<8>|k_fwd2d_pair64<8, 2, 1>|k_inv2d_stream<float, 10, 2>")
     args = ap.parse_args()

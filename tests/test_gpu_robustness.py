@@ -83,6 +83,8 @@ FILTER_CASES = [
     ("1-D long filter", (1 << 18,), "db8", 10, np.float32, {}),
     ("3-D axis kernels + tail3", (128, 128, 128), "db4", 7, np.float32, {}),
     ("3-D odd box", (100, 60, 36), "db2", 2, np.float32, {}),
+    ("3-D one-pass levels, Float64, partly filled waves", (200, 48, 40), "db3", 2, np.float64, {"WL_3D_ONE_MIN_ANY": 0, "WL_I3D_ONE_MIN_ANY": 0, "WL_I3D_ONE_F64_FMAX": 8}),
+    ("3-D one-pass levels, 8-byte lanes", (300, 26, 30), "db4", 1, np.float32, {"WL_3D_ONE_MIN_ANY": 0, "WL_I3D_ONE_MIN_ANY": 0}),
 ]
 
 
@@ -242,7 +244,9 @@ def test_hipgraph_capture_and_replay(gpu, W, oracle):
              ((4096, 4096), np.float32, W.wavelet(W.WT.db4), 12, False),
              ((1 << 18,), np.float64, W.wavelet(W.WT.db2), 18, False),
              ((1 << 18,), np.float32, W.wavelet(W.WT.cdf97, W.WT.Lifting), 18, True),
-             ((512, 512), np.float32, W.wavelet(W.WT.cdf97, W.WT.Lifting), 9, True)]
+             ((512, 512), np.float32, W.wavelet(W.WT.cdf97, W.WT.Lifting), 9, True),
+             ((256, 128, 64), np.float32, W.wavelet(W.WT.db4), 5, False),           # round 6: k_fwd3d_one + k_level3_lds + k_tail3
+             ((128, 64, 256), np.float64, W.wavelet(W.WT.db2), 4, False)]
     s = torch.cuda.Stream()
     for shape, dtype, wt, L, lifting in cases:
         inputs = [rng_array(shape, dtype, 11 + k) for k in range(3)]

@@ -119,3 +119,35 @@ def test_soak_ti_denoise_batch(gpu, W):
         got[it] = _flat(y).reshape(-1).view(i64).sum()
     want = torch.stack(ref).repeat((n + NROT - 1) // NROT)[:n]
     assert int((got != want).sum().item()) == 0
+
+
+@pytest.mark.parametrize("wname,inverse,expect", [("db4", False, "k_fwd3d_one"), ("db2", True, "k_inv3d_one"), ("db3", False, "k_fwd3d_one")])
+def test_soak_3d_one_pass_levels(gpu, W, wname, inverse, expect):
+    """Round 6: the one-pass 3-D levels (k_fwd3d_one: landing ring of F + 2 planes tied to the dim-3 sums, vmcnt(F + 1);
+    k_inv3d_one: two rounds of SH + 2 columns in flight, vmcnt(SH + 2)) on a 512 x 512 x 128 box (256 MiB in rotation x 3)."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(777)
+    wt = W.wavelet(getattr(W.WT, wname))
+    xs = [torch.randn(128, 512, 512, generator=gen, dtype=torch.float32, device="cuda").permute(2, 1, 0) for _ in range(NROT)]
+    ys = [W.similar(xs[0]) for _ in range(NROT)]
+    W.reserve_workspace(xs[0], 1, full=True)
+    f = W.idwt_oop_ if inverse else W.dwt_oop_
+    i64 = torch.int64
+
+    def csum(y):
+        return y.permute(2, 1, 0).reshape(-1).view(i64).sum()          # (the raw buffer: Julia layout = permuted view of a contiguous tensor)
+
+    nlaunch = 1500
+    ref = torch.zeros(NROT, dtype=i64, device="cuda")
+    for r in range(NROT):
+        f(ys[r], xs[r], wt, 1)
+        assert W.last_kernel() == expect, (W.last_kernel(), expect)
+        ref[r] = csum(ys[r])
+    got = torch.zeros(nlaunch, dtype=i64, device="cuda")
+    for it in range(nlaunch):
+        r = it % NROT
+        f(ys[r], xs[r], wt, 1)
+        got[it] = csum(ys[r])
+    want = ref.repeat((nlaunch + NROT - 1) // NROT)[:nlaunch]
+    bad = int((got != want).sum().item())
+    assert bad == 0, "%d of %d launches (%s, %s) differ from the first transform of the same input" % (bad, nlaunch, expect, wname)

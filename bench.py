@@ -884,7 +884,7 @@ def annotate_secondary(rows):
     except (OSError, ValueError):
         pass
     taps = {"sym8": 16, "batt6": 59, "sym5": 10, "db4": 8}
-    case_of = [("C2", "c2"), ("1-D dwt db4 filter 2^24", "c2"), ("1-D dwt cdf9/7", "c4"), ("3-D dwt db4 filter 512^3 f32", "dwt3d"), ("2-D dwt cdf9/7", "lift2d"),
+    case_of = [("C2", "c2"), ("1-D dwt db4 filter 2^24", "c2"), ("1-D dwt cdf9/7", "c4"), ("3-D dwt db4 filter 512^3 f32", "dwt3d"), ("3-D idwt db4 filter 512^3 f32", "idwt3d"), ("2-D dwt cdf9/7", "lift2d"),
                ("2-D idwt cdf9/7", "lift2d_inv"), ("2-D dwt sym8", "sym8_fwd"), ("2-D idwt sym8", "sym8_inv"), ("1-D modwt", "modwt"),
                ("2-D dwt batt6", "batt6")]
     for row in rows:

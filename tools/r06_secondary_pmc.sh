@@ -19,6 +19,7 @@ run4() {   # name cmd...
   echo "done $nm"
 }
 run4 dwt3d       python $R/tools/run_case.py dwt3d 6
+run4 idwt3d      python $R/tools/run_case.py idwt3d 6
 run4 lift2d      python $R/tools/run_case.py lift2d 8
 run4 lift2d_inv  python $R/tools/run_case.py lift2d_inv 8
 run4 sym8_fwd    $B filt=sym8 L=13 rot=2 reps=8 warm=2 check=0

@@ -70,6 +70,10 @@ elif case == "dwt3d":
     x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
     y = W.similar(x)
     fn = lambda: W.dwt_oop_(y, x, db4, 9)
+elif case == "idwt3d":
+    x = torch.randn(512, 512, 512, generator=g, dtype=torch.float32).cuda().permute(2, 1, 0)
+    y = W.similar(x)
+    fn = lambda: W.idwt_oop_(y, x, db4, 9)
 elif case == "batt6":                        # 59 taps: the two-pass line kernels of wl_vlong.hip (k_vl_lines)
     x = torch.randn(8192, 8192, generator=g, dtype=torch.float32).cuda().t()
     y = W.similar(x)

@@ -22,6 +22,7 @@ CASES = collections.OrderedDict([
     ("c2", ("C2: 1-D dwt db4 2^24 f32", 2 * (1 << 24) * 4, "k_fwd1d_multi<float, 8, 1>")),
     ("c4", ("C4: 1-D dwt cdf9/7 lifting 2^24 f32", 2 * (1 << 24) * 4, "k_lift1d_fwd3<float, 0, 1>")),
     ("dwt3d", ("3-D dwt db4 512^3 f32 (level 1: the one-pass kernel)", 2 * 512 ** 3 * 4, "k_fwd3d_one<float, 4, 8, 2>")),
+    ("idwt3d", ("3-D idwt db4 512^3 f32 (level 1: the one-pass inverse kernel)", 2 * 512 ** 3 * 4, "k_inv3d_one<float, 4, 8, 2>")),
     ("lift2d", ("2-D dwt cdf9/7 lifting 8192^2 f32", 2 * 8192 * 8192 * 4, None)),
     ("lift2d_inv", ("2-D idwt cdf9/7 lifting 8192^2 f32", 2 * 8192 * 8192 * 4, None)),
     ("sym8_fwd", ("2-D dwt sym8 (16 taps) 8192^2 f32", 2 * 8192 * 8192 * 4, None)),

@@ -105,7 +105,7 @@ def test_cube_axis_stream_kernels(gpu, W, oracle, dtype):
                 xd = dev(W, x)
                 y = host(W, W.dwt(xd, wt, L))
                 kf = W.last_kernel()
-                k1 = "k_fwd3d_one" if (n >= 128 and len(wt.qmf) <= 8) else "k_fwd_axis_stream"     # (round 6: lines of 128 ... 1024)
+                k1 = "k_fwd3d_one" if (n >= 128 and (len(wt.qmf) <= 8 or dtype == np.float32)) else "k_fwd_axis_stream"     # (round 6; 10 taps: Float32 only)
                 if 4096 < n ** 3 <= 1 << 18:
                     k1 = "k_level3_lds"                                                            # (round 6: small levels in one launch)
                 assert (kf == ("k_tail3" if n ** 3 <= 4096 else k1)) == (len(wt.qmf) <= 10), (n, fname, kf)
@@ -2005,7 +2005,7 @@ def test_3d_one_pass_level(gpu, W, oracle, dtype):
                 y1 = host(W, W.dwt(xd, wt, L))
                 k = W.last_kernel()
                 W.clear_options()
-                assert k == ("k_fwd3d_one" if len(wt.qmf) <= 8 else k0), (shape, fname, k)
+                assert k == ("k_fwd3d_one" if (len(wt.qmf) <= 8 or dtype == np.float32) else k0), (shape, fname, k)     # (10 taps: Float32, 8-byte lanes)
                 assert np.array_equal(y0, y1), (shape, L, fname, tj, int((y0 != y1).sum()))
     # the default gate: 128^3 and up take it without options
     for n in (128, 256):

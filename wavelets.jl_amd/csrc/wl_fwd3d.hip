@@ -1,4 +1,4 @@
-// wl_fwd3d.hip -- one forward 3-D filter-bank level in ONE pass over HBM (both element types, even F <= 8, lines of 128 ... 1024).
+// wl_fwd3d.hip -- one forward 3-D filter-bank level in ONE pass over HBM (both element types, even F <= 8 -- 10 taps in Float32 --, lines of 32 ... 1024).
 //
 //   k_fwd3d_one<T, RPL, F, NW>    reference: planes -> rows -> columns of one level, transforms_filter.jl:246-263
 //
@@ -125,9 +125,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_fwd3d_one(Fwd3DArgs<T, F> a)
     typedef typename Vx<T, 2>::type T2;                        // {scaling, detail} of one row in the exchange
     typedef typename Vx<T, RPL>::type V;                       // the lane's RPL rows
     typedef typename Vx<T, 4>::type X4;                        // two exchange rows: one 16- / 32-byte LDS access
-    constexpr int SH = (F - 2) / 2, KR = F + 2, RS = 8, U = 4, D = KR;
+    constexpr int SH = (F - 2) / 2, KR = F + 2, RS = (F <= 8) ? 8 : 10, U = RS / 2, D = KR;      // (10 taps: a 10-slot ring, groups of 5 steps)
     constexpr int NQ = RPL / 2, NE = 10 + 2 * (NQ - 1);        // scaling (and detail) rows a lane produces; its dim-1 window in rows
-    static_assert(F >= 2 && F <= 8 && (F % 2) == 0, "8-slot column ring");
+    static_assert(F >= 2 && F <= 10 && (F % 2) == 0, "column ring of 8 (10) slots");
+    static_assert(F <= 8 || (sizeof(T) == 4 && RPL == 2), "10 taps: Float32 on 8-byte lanes only (ring of 10 x 4 planes)");
     static_assert(RPL == 2 || RPL == 4, "two or four rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -331,7 +332,8 @@ bool fwd3d_one_ok(int F, const T *cur, int64_t c1, int64_t c2, const T *y, int64
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (opt("WL_3D_ONE", 1) == 0) return false;
-    if (F < 2 || F > 8 || (F & 1)) return false;
+    if (F < 2 || F > 10 || (F & 1)) return false;
+    if (F == 10 && (sizeof(T) != 4 || (n[0] % 4) != 0 || opt("WL_3D_ONE_F10", 1) == 0)) return false;      // (10 taps: Float32 on 8-byte lanes)
     const int64_t n0 = n[0], n1 = n[1], n2 = n[2];
     if (fwd3d_rpl<T>(n0) == 0) return false;
     if (n1 < 16 || (n1 % 2) != 0 || n1 > (1 << 20) || n2 < 16 || (n2 % 2) != 0 || n2 > (1 << 20)) return false;
@@ -375,23 +377,34 @@ static hipError_t launch_fwd3d_f(hipStream_t st, const Taps<T> &taps, const T *c
     Fwd3DArgs<T, F> a;
     a.src = cur; a.c1 = c1; a.c2 = c2; a.y = y; a.y1 = y1; a.y2 = y2; a.ll = ll;
     a.n0 = (int)n[0]; a.n1 = (int)n[1]; a.n2 = (int)n[2];
-    const int rpl = fwd3d_rpl<T>(n[0]);
+    constexpr int RS = (F <= 8) ? 8 : 10;
+    const int rpl = (F == 10) ? 2 : fwd3d_rpl<T>(n[0]);
     if (rpl == 0) return hipErrorInvalidValue;
     const int W = fwd3d_waves(a.n0, rpl);
     a.ntile = (a.n2 + 3) / 4;
     // segment length: the largest multiple of 8 columns <= the requested one that leaves >= 8 waves per CU; a length that divides n1 is
     // preferred over a longer one that does not (the last segment of a non-dividing length recomputes columns of its neighbour)
     int TJ = (int)opt("WL_3D_ONE_TJ", 64);
-    if (TJ < 8 || (TJ % 8) != 0) TJ = 64;
-    while (TJ > 8 && (TJ > a.n1 || (int64_t)a.ntile * ((a.n1 + TJ - 1) / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ -= 8;
+    TJ = (TJ / RS) * RS;
+    if (TJ < RS) TJ = RS;
+    while (TJ > RS && (TJ > a.n1 || (int64_t)a.ntile * ((a.n1 + TJ - 1) / TJ) * W < (int64_t)cu_count * opt("WL_3D_ONE_WAVES", 8))) TJ -= RS;
     if (TJ > a.n1) return hipErrorInvalidValue;
-    for (int t = TJ; t >= 8 && t >= TJ - 16; t -= 8)
+    for (int t = TJ; t >= RS && t >= TJ - 2 * RS; t -= RS)
         if ((a.n1 % t) == 0) { TJ = t; break; }
     a.TJ = TJ;
     a.nseg = (a.n1 + TJ - 1) / TJ;
     a.tp = shrink<T, F>(taps);
     const unsigned nwg = (unsigned)(a.ntile * a.nseg);
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (F == 10) {
+        if constexpr (sizeof(T) == 4) {
+            if (W == 1) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
+            if (W == 2) return launch_fwd3d_inst<T, 2, F, 2>(st, nwg, a);
+            if (W == 4) return launch_fwd3d_inst<T, 2, F, 4>(st, nwg, a);
+            return launch_fwd3d_inst<T, 2, F, 8>(st, nwg, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if constexpr (sizeof(T) == 4) {
         if (rpl == 2 && W == 1) return launch_fwd3d_inst<T, 2, F, 1>(st, nwg, a);
         if (rpl == 2 && W == 2) return launch_fwd3d_inst<T, 2, F, 2>(st, nwg, a);
         if (rpl == 2 && W == 4) return launch_fwd3d_inst<T, 2, F, 4>(st, nwg, a);
@@ -416,6 +429,7 @@ hipError_t fwd3d_one_launch(hipStream_t st, const Taps<T> &taps, const T *cur, i
     case 4: return launch_fwd3d_f<T, 4>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
     case 6: return launch_fwd3d_f<T, 6>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
     case 8: return launch_fwd3d_f<T, 8>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
+    case 10: return launch_fwd3d_f<T, 10>(st, taps, cur, c1, c2, y, y1, y2, ll, n, cu_count);
     default: return hipErrorInvalidValue;
     }
 }

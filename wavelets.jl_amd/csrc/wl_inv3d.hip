@@ -294,8 +294,11 @@ bool inv3d_one_ok(int F, const T *x, int64_t x1, int64_t x2, const T *ll, const 
     //   256^3 db2 46 -> 33, haar 44 -> 22;  Float64 512^3 db2 839 -> 446, 256^3 db2 105 -> 70;
     //   not taken: 256^3 db4 60 -> 67, 512 x 512 x 256 db4 221 -> 272 (half the resident waves), Float64 512^3 db4 830 -> 1067
     if (sizeof(T) == 8 && F > opt("WL_I3D_ONE_F64_FMAX", 4)) return false;
-    const long long gate = any_tier ? opt("WL_I3D_ONE_MIN_ANY", (long long)1 << 24)
-                                    : (F <= 4 ? opt("WL_I3D_ONE_MIN", (long long)1 << 24) : opt("WL_I3D_ONE_MIN_LONG", (long long)1 << 27));
+    // 2 / 4 taps: ahead down to about 10^6 elements on every tier (120^3 db2 23.6 -> 9.9, 128^3 19.4 -> 10.0, 200^3 54 -> 22, Float64 200^3
+    // 96 -> 35); 6 / 8 taps: 2^27 elements against the plane + axis kernels, 2^23 against the any-extent passes (240 x 240 x 160 db4 67 -> 59,
+    // 200^3 62 -> 59; 160^3 39 -> 51 not taken)
+    const long long gate = (F <= 4) ? opt("WL_I3D_ONE_MIN", (long long)1 << 20)
+                                    : (any_tier ? opt("WL_I3D_ONE_MIN_ANY", (long long)1 << 23) : opt("WL_I3D_ONE_MIN_LONG", (long long)1 << 27));
     if (n0 * n1 * n2 < gate) return false;
     return true;
 }

@@ -241,8 +241,8 @@ def test_3d_one_pass_and_block_levels_against_axis_passes(gpu, W, seed):
             n2 = 2 * int(r.integers(8, 50))
             while n0 * n1 * n2 > (1 << 23):
                 n1 = max(16, (n1 // 4) * 2)
-        else:                    # block sizes: extents that are multiples of 8
-            n0, n1, n2 = (8 * int(r.integers(2, 13)) for _ in range(3))
+        else:                    # block sizes: any even extents
+            n0, n1, n2 = (2 * int(r.integers(8, 49)) for _ in range(3))
         fname = str(r.choice(["haar", "db2", "db3", "db4", "db4", "sym4", "db5", "sym5"]))
         wt = W.wavelet(getattr(W.WT, fname))
         x = torch.randn(n2, n1, n0, generator=gen, dtype=dt).cuda().permute(2, 1, 0)        # Julia layout

@@ -2074,7 +2074,8 @@ def test_3d_small_levels_in_one_launch(gpu, W, oracle, dtype):
     taps, cubes and non-cubic boxes (extents that are multiples of 8 but not of 16 take the 4^3 blocks), both block sizes forced,
     levels whose windows wrap more than once around a short axis (transforms_filter.jl:246-287)."""
     for shape, L in (((32, 32, 32), 1), ((64, 64, 64), 2), ((64, 32, 16), 1), ((48, 40, 24), 1), ((16, 16, 32), 1), ((32, 64, 128), 3), ((64, 64, 64), 6),
-                     ((96, 96, 96), 2), ((40, 56, 72), 1)):          # (the last two: not shapes of the axis kernels, the gate is 2^20 there)
+                     ((96, 96, 96), 2), ((40, 56, 72), 1), ((50, 50, 50), 1), ((36, 20, 28), 1), ((100, 60, 36), 2)):          # (from 96^3 on: not shapes of the axis kernels, the gate is 2^20 there; the last three: extents that are not
+                                                                                  #  multiples of 8 -- the last block overlaps its neighbour)
         x = rng_array(shape, dtype, shape[0] + shape[2])
         xd = dev(W, x)
         for fname in ("db4", "haar", "db2", "db3", "db5"):

@@ -40,8 +40,10 @@ __global__ void __launch_bounds__(256) k_level3_lds(Level3Args<T, F> a)
 
     const int b = blockIdx.x;
     const int b0 = b % a.nb0, b1 = (b / a.nb0) % a.nb1, b2 = b / (a.nb0 * a.nb1);
-    const int pa0 = P * b0, pa1 = P * b1, pa2 = P * b2;           // first pair of the block per axis
     const int n0 = a.n0, n1 = a.n1, n2 = a.n2, h0 = n0 >> 1, h1 = n1 >> 1, h2 = n2 >> 1;
+    // first pair of the block per axis; extents that are not multiples of 2 P: the last block is moved back to end at the edge and
+    // recomputes what it shares with its neighbour (same values, same addresses)
+    const int pa0 = (P * b0 + P <= h0) ? P * b0 : h0 - P, pa1 = (P * b1 + P <= h1) ? P * b1 : h1 - P, pa2 = (P * b2 + P <= h2) ? P * b2 : h2 - P;
 
     if constexpr (FW) {
         // ---- stage x[2 pa + e] (periodic) ----
@@ -157,7 +159,7 @@ bool level3_lds_ok(int F, const int64_t n[3], bool any_tier)
     if (opt("WL_LEVEL3", 1) == 0) return false;
     if (F < 2 || F > 10 || (F & 1)) return false;
     for (int a = 0; a < 3; ++a)
-        if (n[a] < 16 || (n[a] % 8) != 0 || n[a] > 4096) return false;
+        if (n[a] < 16 || (n[a] % 2) != 0 || n[a] > 4096) return false;
     const int64_t tot = n[0] * n[1] * n[2];
     return tot > 4096 && tot <= (any_tier ? opt("WL_LEVEL3_MAX_ANY", (long long)1 << 20) : opt("WL_LEVEL3_MAX", (long long)1 << 18));
 }
@@ -169,8 +171,8 @@ static hipError_t launch_level3_inst(hipStream_t st, const Level3Args<T, F> &a0,
 {
     constexpr int SH = (F - 2) / 2, E = FW ? (2 * P + F - 2) : 2 * (P + SH), Q = 2 * P;
     Level3Args<T, F> a = a0;
-    a.nb0 = (int)(n[0] / (2 * P)); a.nb1 = (int)(n[1] / (2 * P));
-    const unsigned nwg = (unsigned)(a.nb0 * a.nb1 * (n[2] / (2 * P)));
+    a.nb0 = (int)((n[0] / 2 + P - 1) / P); a.nb1 = (int)((n[1] / 2 + P - 1) / P);
+    const unsigned nwg = (unsigned)(a.nb0 * a.nb1 * ((n[2] / 2 + P - 1) / P));
     const size_t shmem = (size_t)(E * E * E + Q * E * E) * sizeof(T);
     static thread_local int attr_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     int dev = 0;

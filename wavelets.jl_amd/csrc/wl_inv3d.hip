@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_inv3d_one(Inv3DArgs<T, F> a)
 
     // t: step (from -SH: the first SH steps only fill the rings); u: its ring position (t mod R, compile-time); last: nothing follows
     auto step = [&](const int t, const int u, const bool emit, const bool last) __attribute__((always_inline)) {
-        const int zs = plane_s(t), zd = plane_d(t);
-        const int zs1 = plane_s(t + 1), zd1 = plane_d(t + 1);
+        const int zd = plane_d(t), zs1 = plane_s(t + 1);
         // rounds: (s-plane, s-cols) half 0, (s-plane, d-cols) half 1, (d-plane, s-cols) half 0, (d-plane, d-cols) half 1;
         // each requests the round two ahead into the half it has just published
         do_round(0, 0, false, [&]() __attribute__((always_inline)) { request(0, 1, zd, 0); });
@@ -227,7 +226,6 @@ __global__ void __launch_bounds__(64 * NW, 2) k_inv3d_one(Inv3DArgs<T, F> a)
         do_round(0, 0, last, [&]() __attribute__((always_inline)) { if (!last) request(0, 0, zs1, 0); });
         do_round(1, 1, last, [&]() __attribute__((always_inline)) { if (!last) request(1, 0, zs1, 1); });
         finish_plane(RD[(u + SH) % R]);
-        (void)zd1; (void)zs;
         if (!emit) return;
         // ---- dim 3: scaling planes kp - SH .. kp = ring slots (u + 1 + q) mod R, detail planes kp .. kp + SH = slots (u + q) mod R ----
         const int kp = k0 + t;

@@ -103,8 +103,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_inv3d_one(Inv3DArgs<T, F> a)
     const uint32_t vout = (uint32_t)sizeof(V) * (uint32_t)lp;
 
     // global column / plane indices (periodic)
-    auto scol = [&](const int i) __attribute__((always_inline)) { int j = P0 - SH + i; if (j < 0) j += h1; if (j >= h1) j -= h1; return j; };
-    auto dcol = [&](const int i) __attribute__((always_inline)) { int j = P0 + i; if (j >= h1) j -= h1; return j; };
+    int P0l = P0;
+    auto scol = [&](const int i) __attribute__((always_inline)) { int j = P0l - SH + i; if (j < 0) j += h1; if (j >= h1) j -= h1; return j; };
+    auto dcol = [&](const int i) __attribute__((always_inline)) { int j = P0l + i; if (j >= h1) j -= h1; return j; };
 
     V L[2][NC];                                                // two rounds in flight
     V RS[R][4], RD[R][4];                                      // reconstructed planes: 4 output columns each
@@ -112,6 +113,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_inv3d_one(Inv3DArgs<T, F> a)
 
     // request round `rnd` (0: scaling columns, 1: detail columns) of coefficient plane (kind, z) into landing half `half`
     auto request = [&](const int half, const int kind, const int z, const int rnd) __attribute__((always_inline)) {
+        // (the tile origin is made opaque per request: hipcc otherwise hoists the per-lane 64-bit column addresses of every round out of
+        //  the march -- 20 of them -- and spills: 256 VGPRs + scratch against 233, none)
+        asm volatile("" : "+s"(P0l));
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const T *p;
@@ -287,11 +291,13 @@ bool inv3d_one_ok(int F, const T *x, int64_t x1, int64_t x2, const T *ll, const 
     if (((uintptr_t)x & 15) != 0 || ((uintptr_t)out & 15) != 0 || (ll && ((uintptr_t)ll & 15) != 0)) return false;
     if (x == out || ll == out) return false;
     // Where it pays (measured, level 1 alone, us): the dim-1 pass runs on (SH + 2) / 2 times the columns, so the gain shrinks with the
-    // filter length and is gone in Float64 arithmetic beyond 4 taps --
+    // filter length --
     //   Float32 512^3: haar 406 -> 201, db2 418 -> 219, db3 424 -> 352, db4 446 -> 359;  300^3 db4 249 -> 180 (any-extent tier);
     //   256^3 db2 46 -> 33, haar 44 -> 22;  Float64 512^3 db2 839 -> 446, 256^3 db2 105 -> 70;
-    //   not taken: 256^3 db4 60 -> 67, 512 x 512 x 256 db4 221 -> 272 (half the resident waves), Float64 512^3 db4 830 -> 1067
-    if (sizeof(T) == 8 && F > opt("WL_I3D_ONE_F64_FMAX", 4)) return false;
+    //   not taken: 256^3 db4 60 -> 67, 512 x 512 x 256 db4 221 -> 272 (half the resident waves);
+    //   Float64 6 / 8 taps: 512^3 db4 idwt L = 9 1001 -> 837, db3 level 859 -> 619, 300^3 db4 461 -> 297 (lost while the kernel still spilled:
+    //   830 -> 1067 with 28 VGPRs in scratch -- every reload drains the prefetches)
+    if (sizeof(T) == 8 && F > opt("WL_I3D_ONE_F64_FMAX", 8)) return false;
     // 2 / 4 taps: ahead down to about 10^6 elements on every tier (120^3 db2 23.6 -> 9.9, 128^3 19.4 -> 10.0, 200^3 54 -> 22, Float64 200^3
     // 96 -> 35); 6 / 8 taps: 2^27 elements against the plane + axis kernels, 2^23 against the any-extent passes (240 x 240 x 160 db4 67 -> 59,
     // 200^3 62 -> 59; 160^3 39 -> 51 not taken)

@@ -7,6 +7,8 @@ in a thousand, on some boxes only -- the parity tests run each production-size l
 tests/test_isa_async_loads.py (CPU); this is the dynamic half.  Any difference between two transforms of the same input is a
 failure, whatever the oracle says (the oracle comparison of the same shapes lives in test_gpu_parity.py).
 """
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -137,7 +139,7 @@ def test_soak_3d_one_pass_levels(gpu, W, wname, inverse, expect):
     def csum(y):
         return y.permute(2, 1, 0).reshape(-1).view(i64).sum()          # (the raw buffer: Julia layout = permuted view of a contiguous tensor)
 
-    nlaunch = 1500
+    nlaunch = int(os.environ.get("WL_SOAK_3D_LAUNCHES", "1500"))
     ref = torch.zeros(NROT, dtype=i64, device="cuda")
     for r in range(NROT):
         f(ys[r], xs[r], wt, 1)
